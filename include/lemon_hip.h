@@ -1,0 +1,146 @@
+/*
+ * lemon_hip.h -- C ABI of liblemon_hip.so, the MI355X (gfx950) implementation of
+ * LEMoN's kNN + multimodal-neighbour scoring hot path.
+ *
+ * The reference (MLforHealth/LEMoN, 100% Python) has no FFI layer; the seam this
+ * library replaces is the object protocol run_lemon.py uses.  Each entry point
+ * cites the reference call site it stands in for (paths relative to the
+ * reference root).  INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer named *_dev is a DEVICE pointer (hipMalloc / torch data_ptr());
+ *     all matrices are row-major, float32 unless stated, int64 labels like faiss;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every
+ *     call only enqueues work on that stream (no host synchronisation) unless its
+ *     comment says otherwise;
+ *   - return value: 0 = ok, <0 = error (LEMON_E_*); lemon_last_error() returns a
+ *     thread-local description of the last failure;
+ *   - caller owns every output buffer; the library owns only what is inside a
+ *     lemon_index handle; no hidden global state; one handle per thread.
+ *   - numeric contract ("chain" numerics): dot(a,b) is the float32 fmaf chain in
+ *     ascending k starting from +0 (bit-for-bit what v_mfma_f32_32x32x2_f32
+ *     accumulates); ties in every top-k are broken towards the lower index.
+ */
+#ifndef LEMON_HIP_H
+#define LEMON_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LEMON_METRIC_IP 0 /* faiss.IndexFlatIP, --dist_type cosine    (run_lemon.py:166-169) */
+#define LEMON_METRIC_L2 1 /* faiss.IndexFlatL2, --dist_type euclidean (run_lemon.py:170-173) */
+
+#define LEMON_OK 0
+#define LEMON_E_INVALID (-1) /* bad argument (null pointer, d mismatch, k out of range) */
+#define LEMON_E_HIP (-2)     /* a HIP runtime call failed; see lemon_last_error()        */
+#define LEMON_E_NOMEM (-3)   /* device allocation failed                                 */
+
+#define LEMON_MAX_K 64 /* k + (sname == 'train') <= 64; the reference grid tops out at 50+1 (experiments.py:86) */
+
+/* search algorithm selector for lemon_index_set_algo() */
+#define LEMON_ALGO_AUTO 0
+#define LEMON_ALGO_F32_MFMA 1   /* exact fp32 MFMA scan (v_mfma_f32_32x32x2_f32)                       */
+#define LEMON_ALGO_BF16_FILTER 2 /* bf16 MFMA filter with a rigorous error band + exact fp32 re-rank;  */
+                                 /* returns bit-identical results to LEMON_ALGO_F32_MFMA               */
+
+typedef struct lemon_index lemon_index_t;
+
+const char *lemon_last_error(void);
+/* library / device facts, for logs: returns 0 and fills what it can */
+int lemon_version(int *major, int *minor);
+
+/* ---- row-wise helpers ------------------------------------------------------------ */
+
+/* lib/utils/utils.py:39-40 normalize_vectors == F.normalize(p=2, dim=1, eps=1e-12);
+ * call sites run_lemon.py:163-164,230-233.  y_dev may alias x_dev. */
+int lemon_normalize_rows(const float *x_dev, int64_t n, int d, float *y_dev, void *stream);
+
+/* run_lemon.py:169 (IP: 1 - <a_i,b_i>), :173 (L2: sum_k (a_ik-b_ik)^2) -> dists_tr;
+ * run_lemon.py:250-253 -> d_1.  out_dev [n]. */
+int lemon_paired_distance(int metric, const float *a_dev, const float *b_dev, int64_t n, int d,
+                          float *out_dev, void *stream);
+
+/* --normalize_d1, run_lemon.py:244-248: d1[i] = softmax_c(dist(img_i, cls_txt_c))[noisy_label[i]].
+ * cls_txt_dev [C,d] (run_lemon.py:180-190), noisy_label_dev [n] int32. */
+int lemon_d1_normalized(int metric, const float *q_img_dev, int64_t n, int d,
+                        const float *cls_txt_dev, int C, const int32_t *noisy_label_dev,
+                        float *d1_dev, void *stream);
+
+/* ---- flat index (faiss.IndexFlatIP / IndexFlatL2 as used by run_lemon.py) ---------- */
+
+/* faiss.IndexFlatIP(d) / faiss.IndexFlatL2(d): run_lemon.py:167-168,171-172;
+ * lib/baselines/discrepancy_baseline.py:150-155.  Binds to the current HIP device. */
+int lemon_index_create(int metric, int d, lemon_index_t **out);
+int lemon_index_free(lemon_index_t *idx);
+
+/* index.add(x): run_lemon.py:175-176.  Copies x (like faiss) and builds the kernel-side
+ * layouts; may be called repeatedly (appends).  Allocates device memory: NOT capturable
+ * in a hipGraph, and it synchronises `stream` when it has to grow its storage. */
+int lemon_index_add(lemon_index_t *idx, const float *x_dev, int64_t n, void *stream);
+
+int64_t lemon_index_ntotal(const lemon_index_t *idx); /* faiss index.ntotal */
+int lemon_index_dim(const lemon_index_t *idx);        /* faiss index.d      */
+/* device pointer to the stored row-major copy [ntotal, d] (valid until the next add/free) */
+const float *lemon_index_data(const lemon_index_t *idx);
+
+/* index.search(x, k): run_lemon.py:235-236; lib/baselines/discrepancy_baseline.py:166,209.
+ * D_dev [nq,k] float32 and I_dev [nq,k] int64, best first (IP: descending inner product;
+ * L2: ascending SQUARED distance max(0, |q|^2+|x|^2-2<q,x>)).  Slots beyond ntotal get
+ * I=-1 and D=-FLT_MAX (IP) / +FLT_MAX (L2).  1 <= k <= LEMON_MAX_K.
+ * Grows an internal workspace on first use of a larger (nq,k): that first call is not
+ * graph-capturable; later calls with nq,k no larger only enqueue kernels. */
+int lemon_index_search(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
+                       float *D_dev, int64_t *I_dev, void *stream);
+int lemon_index_set_algo(lemon_index_t *idx, int algo);
+
+/* last search's dominant-kernel launch statistics (for bench/roofline bookkeeping) */
+typedef struct {
+    int algo;            /* LEMON_ALGO_* actually used                       */
+    int grid, block;     /* launch geometry of the scan kernel               */
+    int query_panel;     /* query rows per workgroup (B of the scan model)   */
+    int db_splits;       /* how many workgroups share one query panel        */
+    int64_t nq, n;
+    int d, k;
+} lemon_search_info_t;
+int lemon_index_last_search_info(const lemon_index_t *idx, lemon_search_info_t *out);
+
+/* ---- multimodal neighbours (the per-sample loop run_lemon.py:238-307) ------------- */
+
+/*
+ * One call = one split of the reference's scoring loop.
+ *   idx_img / idx_txt : indices over the normalised DB image / text embeddings (same
+ *                       ntotal, d and metric); dists_tr_dev [ntotal] (run_lemon.py:169/173)
+ *   q_img_dev, q_txt_dev [nq,d] normalised query embeddings (run_lemon.py:230-233)
+ *   drop_self : 1 on the train split -- search k+1 (:235-236) then drop result[0] where
+ *               in_db_dev[i] != 0 else result[-1] (:257-263,277-283); in_db_dev [nq] u8,
+ *               may be NULL (= all ones) and is ignored when drop_self == 0
+ *   discrete  : --use_discrete_for_text (:266-267): dists_n = 1 - [tr_label_id[I_n] == q_label_id]
+ *               (int32 ids of the prompt strings; may be NULL when discrete == 0)
+ * Outputs, caller-allocated: d1 [nq]; D_n, dists_n, dists_tr_n, D_m, dists_m, dists_tr_m [nq,k]
+ * float32 with the sign convention of :269-270,285-286; I_n, I_m [nq,k] int64 (may be NULL).
+ * Neighbours that do not exist (ntotal < k+drop_self) give I=-1 and NaN distances.
+ */
+int lemon_neighbors(lemon_index_t *idx_img, lemon_index_t *idx_txt, const float *dists_tr_dev,
+                    const float *q_img_dev, const float *q_txt_dev, int64_t nq, int k,
+                    int drop_self, const uint8_t *in_db_dev, int discrete,
+                    const int32_t *tr_label_id_dev, const int32_t *q_label_id_dev,
+                    float *d1_dev, float *D_n_dev, float *dists_n_dev, float *dists_tr_n_dev,
+                    int64_t *I_n_dev, float *D_m_dev, float *dists_m_dev, float *dists_tr_m_dev,
+                    int64_t *I_m_dev, void *stream);
+
+/* lib/metrics/utils.py:47-82 calc_scores_given_hparams_vectorized (== loop twin :21-45):
+ * score = d_1 + beta*mean_j[e^{-tau_1_n D_n} e^{-tau_2_n dists_tr_n} dists_n] + gamma*(same for m).
+ * hp = {beta, gamma, tau_1_n, tau_2_n, tau_1_m, tau_2_m} (host doubles, passed by value in the
+ * launch).  score_dev [n] float64; d_n_dev / d_m_dev [n] float64 or NULL. */
+int lemon_score(const float *d1_dev, const float *D_n_dev, const float *dists_tr_n_dev,
+                const float *dists_n_dev, const float *D_m_dev, const float *dists_tr_m_dev,
+                const float *dists_m_dev, int64_t n, int k, const double hp[6],
+                double *score_dev, double *d_n_dev, double *d_m_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEMON_HIP_H */

@@ -1,0 +1,285 @@
+// api.hip -- C ABI glue: index lifetime, search dispatch, multimodal-neighbour finalisation.
+#include "common.hpp"
+#include <stdlib.h>
+
+static thread_local char g_err[512] = "";
+
+void lemon_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *lemon_last_error(void) { return g_err; }
+extern "C" int lemon_version(int *major, int *minor) {
+    if (major) *major = 0;
+    if (minor) *minor = 1;
+    return LEMON_OK;
+}
+
+int lemon_permute_rows(const float *src, int64_t n, int d, float *dst, int dpad, hipStream_t s);
+int lemon_search_f32(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, float *D_dev,
+                     int64_t *I_dev, hipStream_t stream);
+int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, float *D_dev,
+                      int64_t *I_dev, hipStream_t stream);
+
+static inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// ---- index lifetime ---------------------------------------------------------------------
+extern "C" int lemon_index_create(int metric, int d, lemon_index_t **out) {
+    LEMON_REQUIRE(out != nullptr, "out pointer");
+    LEMON_REQUIRE(metric == LEMON_METRIC_IP || metric == LEMON_METRIC_L2, "metric");
+    LEMON_REQUIRE(d > 0 && d <= 65536, "0 < d <= 65536");
+    lemon_index_t *idx = (lemon_index_t *)calloc(1, sizeof(lemon_index_t));
+    if (!idx) { lemon_set_error("host allocation failed"); return LEMON_E_NOMEM; }
+    idx->metric = metric;
+    idx->d = d;
+    idx->dpad = (int)round_up64(d, 32);
+    idx->algo = LEMON_ALGO_AUTO;
+    if (hipGetDevice(&idx->device) != hipSuccess) {
+        free(idx);
+        lemon_set_error("hipGetDevice failed: no HIP device available");
+        return LEMON_E_HIP;
+    }
+    *out = idx;
+    return LEMON_OK;
+}
+
+extern "C" int lemon_index_free(lemon_index_t *idx) {
+    if (!idx) return LEMON_OK;
+    void *ptrs[] = {idx->x, idx->xp, idx->xnorm, idx->xh, idx->ws_qp, idx->ws_qnorm,
+                    idx->ws_cand, idx->ws_part, idx->ws_D, idx->ws_I};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    free(idx);
+    return LEMON_OK;
+}
+
+extern "C" int64_t lemon_index_ntotal(const lemon_index_t *idx) { return idx ? idx->n : -1; }
+extern "C" int lemon_index_dim(const lemon_index_t *idx) { return idx ? idx->d : -1; }
+extern "C" const float *lemon_index_data(const lemon_index_t *idx) { return idx ? idx->x : nullptr; }
+
+extern "C" int lemon_index_set_algo(lemon_index_t *idx, int algo) {
+    LEMON_REQUIRE(idx != nullptr, "index handle");
+    LEMON_REQUIRE(algo >= LEMON_ALGO_AUTO && algo <= LEMON_ALGO_BF16_FILTER, "algo");
+    idx->algo = algo;
+    return LEMON_OK;
+}
+
+extern "C" int lemon_index_last_search_info(const lemon_index_t *idx, lemon_search_info_t *out) {
+    LEMON_REQUIRE(idx && out, "null pointer");
+    *out = idx->last;
+    return LEMON_OK;
+}
+
+extern "C" int lemon_index_add(lemon_index_t *idx, const float *x_dev, int64_t n, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LEMON_REQUIRE(idx != nullptr, "index handle");
+    LEMON_REQUIRE(n >= 0, "n >= 0");
+    if (n == 0) return LEMON_OK;
+    LEMON_REQUIRE(x_dev != nullptr, "x_dev");
+    LEMON_REQUIRE(idx->n + n < (int64_t)0xfffffff0u, "ntotal < 2^32");
+    const int d = idx->d, dpad = idx->dpad;
+    const int64_t need = idx->n + n;
+    if (need > idx->cap) {
+        // grow geometrically, rows padded to whole 128-row tiles (pad rows are zero)
+        int64_t cap = idx->cap ? idx->cap : 0;
+        int64_t want = cap * 2 > need ? cap * 2 : need;
+        if (idx->cap == 0) want = need;
+        want = round_up64(want, 128);
+        float *nx = nullptr, *nxp = nullptr, *nxn = nullptr;
+        LEMON_HIP_CHECK(hipStreamSynchronize(stream));
+        if (hipMalloc(&nx, (size_t)want * d * sizeof(float)) != hipSuccess ||
+            hipMalloc(&nxp, (size_t)want * dpad * sizeof(float)) != hipSuccess ||
+            hipMalloc(&nxn, (size_t)want * sizeof(float)) != hipSuccess) {
+            if (nx) (void)hipFree(nx);
+            if (nxp) (void)hipFree(nxp);
+            if (nxn) (void)hipFree(nxn);
+            lemon_set_error("index storage allocation failed (%lld rows x %d)", (long long)want, d);
+            return LEMON_E_NOMEM;
+        }
+        LEMON_HIP_CHECK(hipMemsetAsync(nxp, 0, (size_t)want * dpad * sizeof(float), stream));
+        LEMON_HIP_CHECK(hipMemsetAsync(nxn, 0, (size_t)want * sizeof(float), stream));
+        if (idx->n > 0) {
+            LEMON_HIP_CHECK(hipMemcpyAsync(nx, idx->x, (size_t)idx->n * d * sizeof(float),
+                                           hipMemcpyDeviceToDevice, stream));
+            LEMON_HIP_CHECK(hipMemcpyAsync(nxp, idx->xp, (size_t)idx->n * dpad * sizeof(float),
+                                           hipMemcpyDeviceToDevice, stream));
+            LEMON_HIP_CHECK(hipMemcpyAsync(nxn, idx->xnorm, (size_t)idx->n * sizeof(float),
+                                           hipMemcpyDeviceToDevice, stream));
+        }
+        LEMON_HIP_CHECK(hipStreamSynchronize(stream));
+        if (idx->x) (void)hipFree(idx->x);
+        if (idx->xp) (void)hipFree(idx->xp);
+        if (idx->xnorm) (void)hipFree(idx->xnorm);
+        if (idx->xh) { (void)hipFree(idx->xh); idx->xh = nullptr; }
+        idx->xh_rows = 0;
+        idx->x = nx; idx->xp = nxp; idx->xnorm = nxn; idx->cap = want;
+    }
+    LEMON_HIP_CHECK(hipMemcpyAsync(idx->x + idx->n * d, x_dev, (size_t)n * d * sizeof(float),
+                                   hipMemcpyDeviceToDevice, stream));
+    int rc = lemon_permute_rows(x_dev, n, d, idx->xp + idx->n * dpad, dpad, stream);
+    if (rc) return rc;
+    rc = lemon_rowdot_chain(x_dev, x_dev, n, d, idx->xnorm + idx->n, stream);
+    if (rc) return rc;
+    idx->n = need;
+    return LEMON_OK;
+}
+
+int lemon_search_internal(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, float *D_dev,
+                          int64_t *I_dev, hipStream_t stream) {
+    LEMON_REQUIRE(idx != nullptr, "index handle");
+    LEMON_REQUIRE(nq >= 0, "nq >= 0");
+    LEMON_REQUIRE(k >= 1 && k <= LEMON_MAX_K, "1 <= k <= LEMON_MAX_K");
+    if (nq == 0) return LEMON_OK;
+    LEMON_REQUIRE(q_dev && D_dev && I_dev, "null pointer");
+    int algo = idx->algo;
+    if (algo == LEMON_ALGO_AUTO) algo = LEMON_ALGO_F32_MFMA;
+    if (algo == LEMON_ALGO_BF16_FILTER) return lemon_search_bf16(idx, q_dev, nq, k, D_dev, I_dev, stream);
+    return lemon_search_f32(idx, q_dev, nq, k, D_dev, I_dev, stream);
+}
+
+extern "C" int lemon_index_search(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
+                                  float *D_dev, int64_t *I_dev, void *stream) {
+    return lemon_search_internal(idx, q_dev, nq, k, D_dev, I_dev, (hipStream_t)stream);
+}
+
+// ---- K4: neighbour finalisation ----------------------------------------------------------
+// One thread per (query, slot): self-exclusion offset, sign convention, cross-modal distance by
+// the chain contract on gathered rows, dists_tr gather.  run_lemon.py:256-289,303,306.
+struct NbParams {
+    const float *img_tr, *txt_tr, *dists_tr, *q_img, *q_txt;
+    const float *Dn, *Dm;       // [nq, ks] raw search output
+    const int64_t *In, *Im;
+    const uint8_t *in_db;
+    const int32_t *tr_lab, *q_lab;
+    float *D_n, *dists_n, *dists_tr_n, *D_m, *dists_m, *dists_tr_m;
+    int64_t *I_n, *I_m;
+    int64_t nq;
+    int d, k, ks, metric, drop_self, discrete;
+};
+
+template <bool L2>
+__device__ __forceinline__ float chain_dist(const float *__restrict__ a, const float *__restrict__ b, int d) {
+    float acc = 0.0f;
+    if ((d & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0) {
+        const float4 *a4 = reinterpret_cast<const float4 *>(a);
+        const float4 *b4 = reinterpret_cast<const float4 *>(b);
+        for (int c = 0; c < d / 4; ++c) {
+            const float4 u = a4[c], v = b4[c];
+            if (L2) {
+                float t;
+                t = u.x - v.x; acc = __builtin_fmaf(t, t, acc);
+                t = u.y - v.y; acc = __builtin_fmaf(t, t, acc);
+                t = u.z - v.z; acc = __builtin_fmaf(t, t, acc);
+                t = u.w - v.w; acc = __builtin_fmaf(t, t, acc);
+            } else {
+                acc = __builtin_fmaf(u.x, v.x, acc);
+                acc = __builtin_fmaf(u.y, v.y, acc);
+                acc = __builtin_fmaf(u.z, v.z, acc);
+                acc = __builtin_fmaf(u.w, v.w, acc);
+            }
+        }
+    } else {
+        for (int c = 0; c < d; ++c) {
+            if (L2) { float t = a[c] - b[c]; acc = __builtin_fmaf(t, t, acc); }
+            else acc = __builtin_fmaf(a[c], b[c], acc);
+        }
+    }
+    return L2 ? acc : 1.0f - acc;
+}
+
+__global__ __launch_bounds__(256) void k_neighbors_finalize(NbParams p) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.nq * p.k) return;
+    const int64_t i = t / p.k;
+    const int j = (int)(t % p.k);
+    const int off = (p.drop_self && (p.in_db == nullptr || p.in_db[i])) ? 1 : 0;
+    const int64_t src = i * p.ks + off + j;
+    const int64_t jn = p.In[src], jm = p.Im[src];
+    const float dn = p.Dn[src], dm = p.Dm[src];
+    const float *vi = p.q_img + i * (int64_t)p.d;
+    const float *ti = p.q_txt + i * (int64_t)p.d;
+    const float qnan = __builtin_nanf("");
+    if (p.I_n) p.I_n[t] = jn;
+    if (p.I_m) p.I_m[t] = jm;
+    if (jn < 0) { p.D_n[t] = dn; p.dists_n[t] = qnan; p.dists_tr_n[t] = qnan; }
+    else {
+        const float *yn = p.txt_tr + jn * (int64_t)p.d;
+        if (p.discrete) {
+            p.D_n[t] = dn;
+            p.dists_n[t] = 1.0f - (float)(p.tr_lab[jn] == p.q_lab[i]);
+        } else if (p.metric == LEMON_METRIC_IP) {
+            p.D_n[t] = -dn;
+            p.dists_n[t] = chain_dist<false>(ti, yn, p.d);
+        } else {
+            p.D_n[t] = dn;
+            p.dists_n[t] = chain_dist<true>(ti, yn, p.d);
+        }
+        p.dists_tr_n[t] = p.dists_tr[jn];
+    }
+    if (jm < 0) { p.D_m[t] = dm; p.dists_m[t] = qnan; p.dists_tr_m[t] = qnan; }
+    else {
+        const float *xm = p.img_tr + jm * (int64_t)p.d;
+        if (p.metric == LEMON_METRIC_IP) { p.D_m[t] = -dm; p.dists_m[t] = chain_dist<false>(vi, xm, p.d); }
+        else                             { p.D_m[t] = dm;  p.dists_m[t] = chain_dist<true>(vi, xm, p.d); }
+        p.dists_tr_m[t] = p.dists_tr[jm];
+    }
+}
+
+extern "C" int lemon_neighbors(lemon_index_t *idx_img, lemon_index_t *idx_txt, const float *dists_tr_dev,
+                               const float *q_img_dev, const float *q_txt_dev, int64_t nq, int k,
+                               int drop_self, const uint8_t *in_db_dev, int discrete,
+                               const int32_t *tr_label_id_dev, const int32_t *q_label_id_dev,
+                               float *d1_dev, float *D_n_dev, float *dists_n_dev, float *dists_tr_n_dev,
+                               int64_t *I_n_dev, float *D_m_dev, float *dists_m_dev, float *dists_tr_m_dev,
+                               int64_t *I_m_dev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LEMON_REQUIRE(idx_img && idx_txt, "index handles");
+    LEMON_REQUIRE(idx_img->d == idx_txt->d && idx_img->n == idx_txt->n && idx_img->metric == idx_txt->metric,
+                  "image and text index must agree in d, ntotal and metric");
+    LEMON_REQUIRE(nq >= 0, "nq >= 0");
+    const int ks = k + (drop_self ? 1 : 0);
+    LEMON_REQUIRE(k >= 1 && ks <= LEMON_MAX_K, "1 <= k, k + drop_self <= LEMON_MAX_K");
+    if (nq == 0) return LEMON_OK;
+    LEMON_REQUIRE(dists_tr_dev && q_img_dev && q_txt_dev && d1_dev && D_n_dev && dists_n_dev &&
+                      dists_tr_n_dev && D_m_dev && dists_m_dev && dists_tr_m_dev, "null pointer");
+    LEMON_REQUIRE(!discrete || (tr_label_id_dev && q_label_id_dev), "label ids required when discrete");
+    // raw search outputs live in the image index's neighbour workspace: [2][nq, ks]
+    const int64_t need = 2 * nq * ks;
+    if (need > idx_img->ws_nb) {
+        LEMON_HIP_CHECK(hipStreamSynchronize(stream));
+        if (idx_img->ws_D) (void)hipFree(idx_img->ws_D);
+        if (idx_img->ws_I) (void)hipFree(idx_img->ws_I);
+        idx_img->ws_D = nullptr; idx_img->ws_I = nullptr; idx_img->ws_nb = 0;
+        if (hipMalloc(&idx_img->ws_D, (size_t)need * sizeof(float)) != hipSuccess ||
+            hipMalloc(&idx_img->ws_I, (size_t)need * sizeof(int64_t)) != hipSuccess) {
+            lemon_set_error("neighbour workspace allocation failed");
+            return LEMON_E_NOMEM;
+        }
+        idx_img->ws_nb = need;
+    }
+    float *Dn = idx_img->ws_D, *Dm = idx_img->ws_D + nq * ks;
+    int64_t *In = idx_img->ws_I, *Im = idx_img->ws_I + nq * ks;
+    int rc = lemon_search_internal(idx_img, q_img_dev, nq, ks, Dn, In, stream);   // run_lemon.py:235
+    if (rc) return rc;
+    rc = lemon_search_internal(idx_txt, q_txt_dev, nq, ks, Dm, Im, stream);       // run_lemon.py:236
+    if (rc) return rc;
+    rc = lemon_paired_distance(idx_img->metric, q_img_dev, q_txt_dev, nq, idx_img->d, d1_dev, stream);
+    if (rc) return rc;
+    NbParams p;
+    p.img_tr = idx_img->x; p.txt_tr = idx_txt->x; p.dists_tr = dists_tr_dev;
+    p.q_img = q_img_dev; p.q_txt = q_txt_dev;
+    p.Dn = Dn; p.Dm = Dm; p.In = In; p.Im = Im;
+    p.in_db = in_db_dev; p.tr_lab = tr_label_id_dev; p.q_lab = q_label_id_dev;
+    p.D_n = D_n_dev; p.dists_n = dists_n_dev; p.dists_tr_n = dists_tr_n_dev;
+    p.D_m = D_m_dev; p.dists_m = dists_m_dev; p.dists_tr_m = dists_tr_m_dev;
+    p.I_n = I_n_dev; p.I_m = I_m_dev;
+    p.nq = nq; p.d = idx_img->d; p.k = k; p.ks = ks; p.metric = idx_img->metric;
+    p.drop_self = drop_self; p.discrete = discrete;
+    const int64_t total = nq * k;
+    hipLaunchKernelGGL(k_neighbors_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}

@@ -1,0 +1,101 @@
+// common.hpp -- shared host/device helpers of liblemon_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <float.h>
+#include "../../include/lemon_hip.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ---- error plumbing -------------------------------------------------------------
+void lemon_set_error(const char *fmt, ...);
+
+#define LEMON_HIP_CHECK(expr)                                                              \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            lemon_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return LEMON_E_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+#define LEMON_REQUIRE(cond, msg)                                                           \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            lemon_set_error("invalid argument: %s (%s)", msg, #cond);                      \
+            return LEMON_E_INVALID;                                                        \
+        }                                                                                  \
+    } while (0)
+
+// ---- index object ---------------------------------------------------------------
+// Data layout in HBM (DESIGN.md "Data layout"):
+//   x     [cap, d]        row-major copy of what the caller added (gathers, exact re-rank)
+//   xp    [cap_pad, dpad] same rows, zero padded to dpad = ceil32(d) columns and with every
+//                         group of 8 consecutive k stored as [k0 k2 k4 k6 | k1 k3 k5 k7] so
+//                         that one 16-B LDS read feeds four v_mfma_f32_32x32x2_f32 steps in
+//                         ascending-k order (cap_pad = ceil128(cap), pad rows are zero)
+//   xnorm [cap_pad]       dot(x,x) (chain numerics), used by the L2 epilogue
+struct lemon_index {
+    int metric;
+    int d, dpad;
+    int device;
+    int algo;
+    int64_t n, cap;       // rows stored / rows allocated (cap is a multiple of 128)
+    float *x, *xp, *xnorm;
+    // bf16 filter copies (built lazily by the bf16 path)
+    unsigned short *xh;   // [cap, dpad] bf16 (RNE) of x
+    int64_t xh_rows;      // rows of xh that are up to date
+    float xnorm_max;      // max_j ||x_j||_2 upper bound (host copy), for the filter band
+    // search workspace (grown on demand)
+    int64_t ws_q;         // query rows the workspace is sized for
+    float *ws_qp;         // [ws_q, dpad] permuted queries
+    float *ws_qnorm;      // [ws_q]
+    u64 *ws_cand;         // [ws_cand_rows, CAND_CAP]  (one 128-row region per scan workgroup)
+    int64_t ws_cand_rows;
+    u64 *ws_part;         // [splits_cap, ws_q, LEMON_MAX_K]
+    int64_t ws_part_elems;
+    // neighbours workspace
+    int64_t ws_nb;        // elements
+    float *ws_D;          // [ws_nb]
+    int64_t *ws_I;        // [ws_nb]
+    lemon_search_info_t last;
+};
+
+// ---- key packing: bigger key == better candidate ----------------------------------
+// hi 32 bits: order-preserving map of the float score (to MAXIMISE), lo 32 bits: ~index so
+// that, at equal score, the LOWER database index wins.  key 0 is "no candidate".
+__host__ __device__ inline u32 lemon_f2ord(float f) {
+    u32 u;
+#ifdef __HIP_DEVICE_COMPILE__
+    u = __float_as_uint(f);
+#else
+    memcpy(&u, &f, 4);
+#endif
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float lemon_ord2f(u32 o) {
+    u32 u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    float f;
+#ifdef __HIP_DEVICE_COMPILE__
+    f = __uint_as_float(u);
+#else
+    memcpy(&f, &u, 4);
+#endif
+    return f;
+}
+__host__ __device__ inline u64 lemon_make_key(float score, u32 idx) {
+    return ((u64)lemon_f2ord(score) << 32) | (u64)(0xffffffffu - idx);
+}
+__host__ __device__ inline float lemon_key_score(u64 key) { return lemon_ord2f((u32)(key >> 32)); }
+__host__ __device__ inline u32 lemon_key_index(u64 key) { return 0xffffffffu - (u32)(key & 0xffffffffu); }
+
+#define LEMON_CAND_CAP 256 // candidate slots per query in the scan workspace
+
+// internal entry points shared between translation units
+int lemon_search_internal(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
+                          float *D_dev, int64_t *I_dev, hipStream_t stream);
+int lemon_rowdot_chain(const float *a, const float *b, int64_t n, int d, float *out, hipStream_t s);

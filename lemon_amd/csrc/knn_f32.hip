@@ -1,0 +1,451 @@
+// knn_f32.hip -- exact brute-force top-k scan on the fp32 matrix cores of gfx950.
+//
+// Stands in for faiss IndexFlat{IP,L2}.search as called at run_lemon.py:235-236.
+// One workgroup owns a panel of BQ=128 queries and streams a contiguous range of database
+// tiles (BX=128 rows) through LDS; S = Q.X^T is accumulated by v_mfma_f32_32x32x2_f32 in
+// ascending k, which is bit-for-bit the float32 fmaf chain of the numeric contract, so the
+// scores (and therefore the selected sets, given the index tie rule) are identical to the CPU
+// oracle's.  Selection is fused into the tile epilogue: an accumulator element that beats the
+// query's current k-th best is appended to that query's candidate list (LDS counter, L2-resident
+// list); lists are compacted to the best k by one wavefront whenever they could overflow.
+//
+// Roofline: dense contraction, 2*nq*n*d flop on the fp32 MFMA pipe (157 TFLOP/s dense peak);
+// HBM traffic is one database stream per resident "generation" of workgroups.
+#include "common.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BQ = 128;  // query rows per workgroup
+constexpr int BX = 128;  // database rows per tile
+constexpr int BK = 32;   // k-slice per LDS stage
+constexpr int NT = 256;  // threads per workgroup (4 wavefronts, 2x2 over the 128x128 tile)
+constexpr int CAP = LEMON_CAND_CAP;
+
+// ---- layout kernels ---------------------------------------------------------------------
+// dst[r][8u + (e&1)*4 + (e>>1)] = src[r][8u+e]; zero beyond d.  One thread per (row, 8-group).
+__global__ __launch_bounds__(256) void k_permute_rows(const float *__restrict__ src, int64_t n, int d,
+                                                      float *__restrict__ dst, int dpad) {
+    const int groups = dpad / 8;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * groups) return;
+    const int64_t r = t / groups;
+    const int u = (int)(t % groups);
+    const float *s = src + r * (int64_t)d + 8 * u;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (8 * u + e < d) ? s[e] : 0.0f;
+    float4 *o = reinterpret_cast<float4 *>(dst + r * (int64_t)dpad + 8 * u);
+    o[0] = make_float4(v[0], v[2], v[4], v[6]);
+    o[1] = make_float4(v[1], v[3], v[5], v[7]);
+}
+
+// ---- wave-level selection ---------------------------------------------------------------
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        u64 o = __shfl_xor(v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// v[0..3]: up to 256 distinct keys spread over the wavefront (0 = empty).  Returns, in lane i,
+// the i-th largest key for i < k (0 if fewer exist).  k <= 64.
+__device__ __forceinline__ u64 wave_select_topk(u64 v0, u64 v1, u64 v2, u64 v3, int k, int lane) {
+    u64 res = 0;
+    for (int r = 0; r < k; ++r) {
+        u64 m01 = v0 > v1 ? v0 : v1;
+        u64 m23 = v2 > v3 ? v2 : v3;
+        u64 m = m01 > m23 ? m01 : m23;
+        u64 w = wave_max_u64(m);
+        if (w == 0) break;           // wave-uniform
+        if (lane == r) res = w;
+        if (v0 == w) v0 = 0;
+        if (v1 == w) v1 = 0;
+        if (v2 == w) v2 = 0;
+        if (v3 == w) v3 = 0;
+    }
+    return res;
+}
+
+struct ScanParams {
+    const float *qp;      // [nq_pad, dpad] permuted queries, pad rows zero
+    const float *xp;      // [n_pad,  dpad] permuted database, pad rows zero
+    const float *qnorm;   // [nq_pad]  (L2)
+    const float *xnorm;   // [n_pad]   (L2)
+    u64 *cand;            // [grid, BQ, CAP]  one region per workgroup
+    u64 *part;            // [splits, nq_pad, kk] when splits > 1
+    float *D;             // [nq, kk] when splits == 1
+    int64_t *I;
+    int64_t nq, n;
+    int dpad, kk, metric;
+    int n_tiles, tiles_per_split, splits;
+    int64_t nq_pad;
+};
+
+__device__ __forceinline__ int swz(int r, int c) { return r * BK + 4 * (c ^ ((r >> 1) & 7)); }
+
+// compact one query row's candidate list to its best kk entries (sorted, best first)
+__device__ __forceinline__ void compact_row(u64 *__restrict__ list, int *cnt, float *thr, int row, int kk,
+                                            int lane) {
+    const int n = cnt[row];
+    u64 v0 = (lane < n) ? list[lane] : 0;
+    u64 v1 = (lane + 64 < n) ? list[lane + 64] : 0;
+    u64 v2 = (lane + 128 < n) ? list[lane + 128] : 0;
+    u64 v3 = (lane + 192 < n) ? list[lane + 192] : 0;
+    u64 res = wave_select_topk(v0, v1, v2, v3, kk, lane);
+    const int kept = n < kk ? n : kk;
+    if (lane < kept) list[lane] = res;
+    const u64 kth = __shfl(res, kk - 1);
+    if (lane == 0) {
+        cnt[row] = kept;
+        thr[row] = (kept == kk) ? lemon_key_score(kth) : -INFINITY;
+    }
+}
+
+// global -> register staging of one k-slice: each thread moves 4 16-B chunks per operand.
+// (named registers, not arrays: hipcc keeps by-reference float4 arrays in scratch here)
+__device__ __forceinline__ float4 stage_ld(const float *__restrict__ src, int dpad, int tid, int i) {
+    const int id = tid + NT * i, r = id >> 3, c = id & 7;
+    return *reinterpret_cast<const float4 *>(src + (int64_t)r * dpad + 4 * c);
+}
+__device__ __forceinline__ void stage_st(float *t, int tid, int i, float4 v) {
+    const int id = tid + NT * i, r = id >> 3, c = id & 7;
+    *reinterpret_cast<float4 *>(&t[swz(r, c)]) = v;
+}
+#define STAGE_ISSUE(qsrc, xsrc)                                                                     \
+    do {                                                                                            \
+        rq0 = stage_ld(qsrc, dpad, tid, 0); rq1 = stage_ld(qsrc, dpad, tid, 1);                     \
+        rq2 = stage_ld(qsrc, dpad, tid, 2); rq3 = stage_ld(qsrc, dpad, tid, 3);                     \
+        rx0 = stage_ld(xsrc, dpad, tid, 0); rx1 = stage_ld(xsrc, dpad, tid, 1);                     \
+        rx2 = stage_ld(xsrc, dpad, tid, 2); rx3 = stage_ld(xsrc, dpad, tid, 3);                     \
+    } while (0)
+#define STAGE_COMMIT(tq_, tx_)                                                                      \
+    do {                                                                                            \
+        stage_st(tq_, tid, 0, rq0); stage_st(tq_, tid, 1, rq1); stage_st(tq_, tid, 2, rq2);         \
+        stage_st(tq_, tid, 3, rq3); stage_st(tx_, tid, 0, rx0); stage_st(tx_, tid, 1, rx1);         \
+        stage_st(tx_, tid, 2, rx2); stage_st(tx_, tid, 3, rx3);                                     \
+    } while (0)
+
+// threshold filter + append for one 32x32 accumulator tile; zeroes the accumulator
+__device__ __forceinline__ void epilogue_tile(f32x16 &acc, int rtile, int64_t j, bool jvalid, float xn, int h,
+                                              int metric, const float *s_thr, const float *s_qn, int *s_cnt,
+                                              u64 *__restrict__ cand_panel) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int rbase = rtile + 8 * g + 4 * h;
+        const float4 t4 = *reinterpret_cast<const float4 *>(&s_thr[rbase]);
+        const float4 n4 = *reinterpret_cast<const float4 *>(&s_qn[rbase]);
+        const float th[4] = {t4.x, t4.y, t4.z, t4.w};
+        const float qn[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float s = acc[4 * g + e];
+            if (metric == LEMON_METRIC_L2) {
+                const float dd = __builtin_fmaf(-2.0f, s, qn[e] + xn);
+                s = -(dd > 0.0f ? dd : 0.0f);
+            }
+            if (jvalid && s > th[e]) {
+                const int row = rbase + e;
+                const int slot = atomicAdd(&s_cnt[row], 1);
+                cand_panel[(int64_t)row * CAP + slot] = lemon_make_key(s, (u32)j);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+}
+
+__global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
+    __shared__ __attribute__((aligned(16))) float s_tile[2][2][BQ * BK];  // [buf][Q|X][row*32+..] 64 KiB
+    __shared__ __attribute__((aligned(16))) float s_thr[BQ];
+    __shared__ __attribute__((aligned(16))) float s_qn[BQ];
+    __shared__ int s_cnt[BQ];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const int panel = blockIdx.x / p.splits;
+    const int split = blockIdx.x % p.splits;
+    const int64_t q0 = (int64_t)panel * BQ;
+    const int t_begin = split * p.tiles_per_split;
+    int t_end = t_begin + p.tiles_per_split;
+    if (t_end > p.n_tiles) t_end = p.n_tiles;
+    const int ntile = t_end - t_begin;           // >= 1 by construction
+    const int KT = p.dpad / BK;
+    const int total = ntile * KT;
+    const int dpad = p.dpad;
+    const int metric = p.metric;
+
+    if (tid < BQ) {
+        s_thr[tid] = (q0 + tid < p.nq) ? -INFINITY : INFINITY;  // pad queries never collect
+        s_cnt[tid] = 0;
+        s_qn[tid] = (metric == LEMON_METRIC_L2) ? p.qnorm[q0 + tid] : 0.0f;
+    }
+
+    float4 rq0, rq1, rq2, rq3, rx0, rx1, rx2, rx3;
+    const float *qbase = p.qp + q0 * dpad;
+    const float *xbase = p.xp + (int64_t)t_begin * BX * dpad;
+
+    f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc00[e] = 0.0f; acc01[e] = 0.0f; acc10[e] = 0.0f; acc11[e] = 0.0f; }
+
+    STAGE_ISSUE(qbase, xbase);
+    STAGE_COMMIT(s_tile[0][0], s_tile[0][1]);
+    __syncthreads();
+
+    // one private candidate region per workgroup (panel x split)
+    u64 *cand_panel = p.cand + (int64_t)blockIdx.x * BQ * CAP;
+    const int arow0 = 64 * wr + l31, arow1 = arow0 + 32;
+    const int brow0 = 64 * wc + l31, brow1 = brow0 + 32;
+
+    int kt = 0, jl = 0;  // position of iteration `it` = (tile jl of this split, k-slice kt)
+    for (int it = 0; it < total; ++it) {
+        const int cur = it & 1;
+        int kt_n = kt + 1, jl_n = jl;
+        if (kt_n == KT) { kt_n = 0; jl_n = jl + 1; }
+        if (it + 1 < total) {
+            const float *qs = qbase + kt_n * BK;
+            const float *xs = xbase + (int64_t)jl_n * BX * dpad + kt_n * BK;
+            STAGE_ISSUE(qs, xs);
+        }
+
+        const float *tq = s_tile[cur][0];
+        const float *tx = s_tile[cur][1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(&tq[swz(arow0, 2 * u + h)]);
+            const float4 a1 = *reinterpret_cast<const float4 *>(&tq[swz(arow1, 2 * u + h)]);
+            const float4 b0 = *reinterpret_cast<const float4 *>(&tx[swz(brow0, 2 * u + h)]);
+            const float4 b1 = *reinterpret_cast<const float4 *>(&tx[swz(brow1, 2 * u + h)]);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[m], bv0[m], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[m], bv1[m], acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], bv0[m], acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], bv1[m], acc11, 0, 0, 0);
+            }
+        }
+
+        const bool tile_done = (kt == KT - 1);
+        if (tile_done) {
+            const int64_t jb = (int64_t)(t_begin + jl) * BX + 64 * wc + l31;
+            const int64_t j0 = jb, j1 = jb + 32;
+            const bool v0 = j0 < p.n, v1 = j1 < p.n;
+            const float xn0 = (metric == LEMON_METRIC_L2) ? p.xnorm[j0] : 0.0f;
+            const float xn1 = (metric == LEMON_METRIC_L2) ? p.xnorm[j1] : 0.0f;
+            epilogue_tile(acc00, 64 * wr, j0, v0, xn0, h, metric, s_thr, s_qn, s_cnt, cand_panel);
+            epilogue_tile(acc01, 64 * wr, j1, v1, xn1, h, metric, s_thr, s_qn, s_cnt, cand_panel);
+            epilogue_tile(acc10, 64 * wr + 32, j0, v0, xn0, h, metric, s_thr, s_qn, s_cnt, cand_panel);
+            epilogue_tile(acc11, 64 * wr + 32, j1, v1, xn1, h, metric, s_thr, s_qn, s_cnt, cand_panel);
+        }
+
+        if (it + 1 < total) STAGE_COMMIT(s_tile[cur ^ 1][0], s_tile[cur ^ 1][1]);
+        __syncthreads();
+
+        if (tile_done) {
+            // rows whose list could overflow on the next tile are compacted (wave w owns rows 32w..)
+            const bool last = (it + 1 == total);
+            for (int r = 0; r < 32; ++r) {
+                const int row = 32 * wave + r;
+                if (last || s_cnt[row] > CAP - BX)
+                    compact_row(cand_panel + (int64_t)row * CAP, s_cnt, s_thr, row, p.kk, lane);
+            }
+            __syncthreads();
+        }
+        kt = kt_n; jl = jl_n;
+    }
+
+    // ---- write-out: lists are sorted (best first) after the final compaction --------------
+    for (int r = 0; r < 32; ++r) {
+        const int row = 32 * wave + r;
+        const int64_t q = q0 + row;
+        if (q >= p.nq) continue;
+        const int kept = s_cnt[row];
+        if (lane < p.kk) {
+            const u64 key = (lane < kept) ? cand_panel[(int64_t)row * CAP + lane] : 0;
+            if (p.splits > 1) {
+                p.part[((int64_t)split * p.nq_pad + q) * p.kk + lane] = key;
+            } else {
+                float dv; int64_t iv;
+                if (key) {
+                    const float s = lemon_key_score(key);
+                    dv = (metric == LEMON_METRIC_L2) ? -s : s;
+                    iv = (int64_t)lemon_key_index(key);
+                } else {
+                    dv = (metric == LEMON_METRIC_L2) ? FLT_MAX : -FLT_MAX;
+                    iv = -1;
+                }
+                p.D[q * p.kk + lane] = dv;
+                p.I[q * p.kk + lane] = iv;
+            }
+        }
+    }
+}
+
+// merge the per-split sorted lists of one query (one wavefront per query)
+__global__ __launch_bounds__(256) void k_merge(const u64 *__restrict__ part, int splits, int64_t nq_pad,
+                                               int64_t nq, int kk, int metric, float *__restrict__ D,
+                                               int64_t *__restrict__ I) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    u64 best = 0;  // lane i: i-th best so far
+    const int total = splits * kk;
+    for (int base = 0; base < total; base += 192) {
+        u64 v[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int e = base + 64 * t + lane;
+            u64 key = 0;
+            if (e < total) {
+                const int s = e / kk, pos = e % kk;
+                key = part[((int64_t)s * nq_pad + q) * kk + pos];
+            }
+            v[t] = key;
+        }
+        best = wave_select_topk(best, v[0], v[1], v[2], kk, lane);
+    }
+    if (lane < kk) {
+        float dv; int64_t iv;
+        if (best) {
+            const float s = lemon_key_score(best);
+            dv = (metric == LEMON_METRIC_L2) ? -s : s;
+            iv = (int64_t)lemon_key_index(best);
+        } else {
+            dv = (metric == LEMON_METRIC_L2) ? FLT_MAX : -FLT_MAX;
+            iv = -1;
+        }
+        D[q * kk + lane] = dv;
+        I[q * kk + lane] = iv;
+    }
+}
+
+__global__ void k_fill_empty(float *D, int64_t *I, int64_t total, int metric) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) { D[i] = (metric == LEMON_METRIC_L2) ? FLT_MAX : -FLT_MAX; I[i] = -1; }
+}
+
+inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+}  // namespace
+
+// -----------------------------------------------------------------------------------------
+// host side
+// -----------------------------------------------------------------------------------------
+int lemon_permute_rows(const float *src, int64_t n, int d, float *dst, int dpad, hipStream_t s) {
+    if (n <= 0) return LEMON_OK;
+    const int64_t threads = n * (dpad / 8);
+    hipLaunchKernelGGL(k_permute_rows, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, src, n, d,
+                       dst, dpad);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}
+
+static int ensure_search_ws(lemon_index_t *idx, int64_t nq_pad, int splits, hipStream_t stream) {
+    const int64_t part_elems = (splits > 1) ? (int64_t)splits * nq_pad * LEMON_MAX_K : 0;
+    const int64_t cand_rows = nq_pad * splits;
+    if (nq_pad > idx->ws_q) {
+        LEMON_HIP_CHECK(hipStreamSynchronize(stream));
+        if (idx->ws_qp) (void)hipFree(idx->ws_qp);
+        if (idx->ws_qnorm) (void)hipFree(idx->ws_qnorm);
+        idx->ws_qp = nullptr; idx->ws_qnorm = nullptr; idx->ws_q = 0;
+        if (hipMalloc(&idx->ws_qp, (size_t)nq_pad * idx->dpad * sizeof(float)) != hipSuccess ||
+            hipMalloc(&idx->ws_qnorm, (size_t)nq_pad * sizeof(float)) != hipSuccess) {
+            lemon_set_error("search workspace allocation failed (nq_pad=%lld)", (long long)nq_pad);
+            return LEMON_E_NOMEM;
+        }
+        idx->ws_q = nq_pad;
+    }
+    if (cand_rows > idx->ws_cand_rows) {
+        LEMON_HIP_CHECK(hipStreamSynchronize(stream));
+        if (idx->ws_cand) (void)hipFree(idx->ws_cand);
+        idx->ws_cand = nullptr; idx->ws_cand_rows = 0;
+        if (hipMalloc(&idx->ws_cand, (size_t)cand_rows * CAP * sizeof(u64)) != hipSuccess) {
+            lemon_set_error("candidate workspace allocation failed (%lld rows)", (long long)cand_rows);
+            return LEMON_E_NOMEM;
+        }
+        idx->ws_cand_rows = cand_rows;
+    }
+    if (part_elems > idx->ws_part_elems) {
+        LEMON_HIP_CHECK(hipStreamSynchronize(stream));
+        if (idx->ws_part) (void)hipFree(idx->ws_part);
+        idx->ws_part = nullptr; idx->ws_part_elems = 0;
+        if (hipMalloc(&idx->ws_part, (size_t)part_elems * sizeof(u64)) != hipSuccess) {
+            lemon_set_error("merge workspace allocation failed");
+            return LEMON_E_NOMEM;
+        }
+        idx->ws_part_elems = part_elems;
+    }
+    return LEMON_OK;
+}
+
+// queries are processed in chunks so that the workspace stays bounded (1 GiB of candidates)
+static const int64_t QCHUNK = 1 << 19;
+
+int lemon_search_f32(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, float *D_dev,
+                     int64_t *I_dev, hipStream_t stream) {
+    const int d = idx->d, dpad = idx->dpad;
+    if (idx->n == 0) {
+        const int64_t total = nq * k;
+        hipLaunchKernelGGL(k_fill_empty, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, D_dev,
+                           I_dev, total, idx->metric);
+        LEMON_HIP_CHECK(hipGetLastError());
+        return LEMON_OK;
+    }
+    const int n_tiles = (int)((idx->n + BX - 1) / BX);
+    for (int64_t c0 = 0; c0 < nq; c0 += QCHUNK) {
+        const int64_t cn = (nq - c0) < QCHUNK ? (nq - c0) : QCHUNK;
+        const int64_t nq_pad = round_up(cn, BQ);
+        const int panels = (int)(nq_pad / BQ);
+        // enough workgroups to fill 256 CUs x 2 resident; every split keeps >= 8 tiles of warm-up
+        int splits = 1;
+        if (panels < 1024) {
+            splits = (1024 + panels - 1) / panels;
+            int max_splits = n_tiles / 8;
+            if (max_splits < 1) max_splits = 1;
+            if (splits > max_splits) splits = max_splits;
+        }
+        int tiles_per_split = (n_tiles + splits - 1) / splits;
+        splits = (n_tiles + tiles_per_split - 1) / tiles_per_split;
+
+        int rc = ensure_search_ws(idx, nq_pad, splits, stream);
+        if (rc) return rc;
+        // permuted, zero-padded query panel (+ chain norms for L2)
+        LEMON_HIP_CHECK(hipMemsetAsync(idx->ws_qp, 0, (size_t)nq_pad * dpad * sizeof(float), stream));
+        rc = lemon_permute_rows(q_dev + c0 * d, cn, d, idx->ws_qp, dpad, stream);
+        if (rc) return rc;
+        if (idx->metric == LEMON_METRIC_L2) {
+            LEMON_HIP_CHECK(hipMemsetAsync(idx->ws_qnorm, 0, (size_t)nq_pad * sizeof(float), stream));
+            rc = lemon_rowdot_chain(q_dev + c0 * d, q_dev + c0 * d, cn, d, idx->ws_qnorm, stream);
+            if (rc) return rc;
+        }
+        ScanParams p;
+        p.qp = idx->ws_qp; p.xp = idx->xp; p.qnorm = idx->ws_qnorm; p.xnorm = idx->xnorm;
+        p.cand = idx->ws_cand; p.part = idx->ws_part;
+        p.D = D_dev + c0 * k; p.I = I_dev + c0 * k;
+        p.nq = cn; p.n = idx->n; p.dpad = dpad; p.kk = k; p.metric = idx->metric;
+        p.n_tiles = n_tiles; p.tiles_per_split = tiles_per_split; p.splits = splits; p.nq_pad = nq_pad;
+        const unsigned grid = (unsigned)(panels * splits);
+        hipLaunchKernelGGL(k_scan_f32, dim3(grid), dim3(NT), 0, stream, p);
+        LEMON_HIP_CHECK(hipGetLastError());
+        if (splits > 1) {
+            hipLaunchKernelGGL(k_merge, dim3((unsigned)((cn + 3) / 4)), dim3(256), 0, stream, idx->ws_part,
+                               splits, nq_pad, cn, k, idx->metric, p.D, p.I);
+            LEMON_HIP_CHECK(hipGetLastError());
+        }
+        idx->last.algo = LEMON_ALGO_F32_MFMA;
+        idx->last.grid = (int)grid; idx->last.block = NT;
+        idx->last.query_panel = BQ; idx->last.db_splits = splits;
+    }
+    idx->last.nq = nq; idx->last.n = idx->n; idx->last.d = d; idx->last.k = k;
+    return LEMON_OK;
+}

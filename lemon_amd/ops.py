@@ -1,0 +1,121 @@
+"""Host-side mirror of the reference's row-wise helpers, running on liblemon_hip.so.
+
+  normalize_vectors      lib/utils/utils.py:39-40
+  paired_distance        run_lemon.py:169,173,250-253
+  d1_normalized          run_lemon.py:244-248
+  calc_scores_given_hparams(_vectorized)   lib/metrics/utils.py:21-82
+
+Inputs are torch CUDA tensors (device memory is torch's job; the arithmetic is the HIP
+library's).  Host inputs are rejected loudly: there is no CPU path in the product.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_METRICS = {"cosine": _lib.METRIC_IP, "ip": _lib.METRIC_IP, "euclidean": _lib.METRIC_L2,
+            "l2": _lib.METRIC_L2, _lib.METRIC_IP: _lib.METRIC_IP, _lib.METRIC_L2: _lib.METRIC_L2}
+
+
+def metric_id(metric):
+    try:
+        return _METRICS[metric]
+    except KeyError:
+        raise ValueError(f"unknown metric {metric!r} (cosine|euclidean)")
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def dev_f32(t, name="tensor"):
+    """Contiguous float32 CUDA tensor (converted if needed); refuses CPU tensors."""
+    if not torch.is_tensor(t):
+        raise TypeError(f"{name}: expected a torch CUDA tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise _lib.LemonHipError(f"{name} lives on {t.device}: the LEMoN hot path only runs on the GPU "
+                                 "(no CPU fallback). Move it with .cuda().")
+    return t.detach().to(torch.float32).contiguous()
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def normalize_vectors(vectors):
+    """F.normalize(vectors, p=2, dim=1) -- lib/utils/utils.py:39-40."""
+    x = dev_f32(vectors, "vectors")
+    assert x.dim() == 2
+    y = torch.empty_like(x)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.lemon_normalize_rows(ptr(x), x.shape[0], x.shape[1], ptr(y), stream_ptr(x.device)),
+                   "lemon_normalize_rows")
+    return y
+
+
+def paired_distance(metric, a, b):
+    a, b = dev_f32(a, "a"), dev_f32(b, "b")
+    assert a.shape == b.shape and a.dim() == 2
+    out = torch.empty(a.shape[0], dtype=torch.float32, device=a.device)
+    lib = _lib.load()
+    with torch.cuda.device(a.device):
+        _lib.check(lib.lemon_paired_distance(metric_id(metric), ptr(a), ptr(b), a.shape[0], a.shape[1],
+                                             ptr(out), stream_ptr(a.device)), "lemon_paired_distance")
+    return out
+
+
+def d1_normalized(metric, q_img, cls_txt, noisy_label):
+    q, c = dev_f32(q_img, "q_img"), dev_f32(cls_txt, "cls_txt")
+    lab = noisy_label.to(device=q.device, dtype=torch.int32).contiguous()
+    out = torch.empty(q.shape[0], dtype=torch.float32, device=q.device)
+    lib = _lib.load()
+    with torch.cuda.device(q.device):
+        _lib.check(lib.lemon_d1_normalized(metric_id(metric), ptr(q), q.shape[0], q.shape[1], ptr(c),
+                                           c.shape[0], ptr(lab), ptr(out), stream_ptr(q.device)),
+                   "lemon_d1_normalized")
+    return out
+
+
+HP_ORDER = ("beta", "gamma", "tau_1_n", "tau_2_n", "tau_1_m", "tau_2_m")
+
+
+def lemon_score(rec, hparams, return_dn=False):
+    """Score aggregation on device arrays.  rec: dict with d_1 [n], D_n, dists_tr_n, dists_n, D_m,
+    dists_tr_m, dists_m [n,k] CUDA tensors.  Returns float64 CUDA tensors."""
+    names = ("d_1", "D_n", "dists_tr_n", "dists_n", "D_m", "dists_tr_m", "dists_m")
+    arrs = [dev_f32(rec[nm], nm) for nm in names]
+    n, k = arrs[1].shape
+    dev = arrs[0].device
+    score = torch.empty(n, dtype=torch.float64, device=dev)
+    dn = torch.empty(n, dtype=torch.float64, device=dev)
+    dm = torch.empty(n, dtype=torch.float64, device=dev)
+    hp = (ctypes.c_double * 6)(*[float(hparams[h]) for h in HP_ORDER])
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(lib.lemon_score(*[ptr(a) for a in arrs], n, k, hp, ptr(score), ptr(dn), ptr(dm),
+                                   stream_ptr(dev)), "lemon_score")
+    return (score, dn, dm) if return_dn else score
+
+
+def _stack_col(df, col, device):
+    return torch.from_numpy(np.stack(df[col].values).astype(np.float32, copy=False)).to(device)
+
+
+def calc_scores_given_hparams_vectorized(df, best_hparams, return_dn=False, torch_arr=False, device="cuda"):
+    """Drop-in for lib/metrics/utils.py:47-82 on the reference's DataFrame schema
+    (run_lemon.py:291-307): returns numpy arrays (torch CPU tensors when torch_arr)."""
+    rec = {c: _stack_col(df, c, device) for c in ("D_n", "dists_tr_n", "dists_n", "D_m", "dists_tr_m", "dists_m")}
+    rec["d_1"] = torch.from_numpy(np.asarray(df["d_1"].values, dtype=np.float32)).to(device)
+    s, dn, dm = lemon_score(rec, best_hparams, return_dn=True)
+    # d_1 is float64 in the reference frame (`d1.item()`): add it back at full precision
+    s = s - rec["d_1"].double() + torch.from_numpy(np.asarray(df["d_1"].values, dtype=np.float64)).to(device)
+    conv = (lambda t: t.cpu()) if torch_arr else (lambda t: t.cpu().numpy())
+    if return_dn:
+        return conv(s), conv(dn), conv(dm)
+    return conv(s)
+
+
+calc_scores_given_hparams = calc_scores_given_hparams_vectorized  # loop twin, lib/metrics/utils.py:21-45

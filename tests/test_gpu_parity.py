@@ -1,0 +1,195 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact D / I for the flat search (integer + chain-numerics float), bit-exact per-sample
+arrays for the neighbour quantities, 1e-9 relative for the float64 score aggregation.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.synth import planted, unit_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_library_loaded_in_process(hip):
+    maps = open("/proc/self/maps").read()
+    assert "liblemon_hip.so" in maps
+
+
+@pytest.mark.parametrize("n,d", [(1, 1), (7, 33), (300, 512), (1000, 768), (257, 100)])
+def test_normalize_rows(hip, oracle, n, d):
+    rng = np.random.default_rng(n * 1000 + d)
+    x = (rng.standard_normal((n, d)) * rng.uniform(0.01, 30, (n, 1))).astype(np.float32)
+    if n > 5:
+        x[3] = 0.0  # zero row -> zeros (F.normalize eps semantics)
+    y = hip.normalize_vectors(cu(x)).cpu().numpy()
+    ref = oracle.normalize_rows(x)
+    assert np.array_equal(y, ref), f"max abs diff {np.abs(y - ref).max()}"
+    tref = torch.nn.functional.normalize(torch.from_numpy(x), p=2, dim=1).numpy()
+    assert np.abs(y - tref).max() <= 2e-7
+
+
+@pytest.mark.parametrize("metric", ["cosine", "euclidean"])
+@pytest.mark.parametrize("n,d", [(1, 8), (130, 40), (1000, 512), (333, 768)])
+def test_paired_distance(hip, oracle, metric, n, d):
+    rng = np.random.default_rng(d + n)
+    a, b = unit_rows(rng, n, d), unit_rows(rng, n, d)
+    got = hip.paired_distance(metric, cu(a), cu(b)).cpu().numpy()
+    assert np.array_equal(got, oracle.paired_distance(metric, a, b))
+
+
+def _search(hip, metric, X, Q, k, algo=None):
+    cls = hip.IndexFlatIP if metric == "ip" else hip.IndexFlatL2
+    idx = cls(X.shape[1] if X.ndim == 2 and X.shape[0] else Q.shape[1])
+    if algo is not None:
+        idx.set_algo(algo)
+    if X.shape[0]:
+        idx.add(cu(X))
+    D, I = idx.search(cu(Q), k)
+    return D.cpu().numpy(), I.cpu().numpy(), idx
+
+
+def _assert_knn_equal(got, ref):
+    (D, I), (Dr, Ir) = got, ref
+    assert np.array_equal(I, Ir), f"{(I != Ir).sum()} index mismatches of {I.size}"
+    assert np.array_equal(D.view(np.uint32), Dr.view(np.uint32)), f"max |dD| {np.abs(D - Dr).max()}"
+
+
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+@pytest.mark.parametrize("nq,n,d,k", [
+    (1, 1, 8, 1), (5, 3, 16, 5), (130, 1000, 40, 10), (128, 128, 32, 64), (257, 1300, 64, 51),
+    (64, 5000, 512, 50), (300, 2049, 768, 5), (1100, 3000, 100, 1), (33, 40000, 96, 51),
+])
+def test_flat_search_bit_exact(hip, oracle, metric, nq, n, d, k):
+    rng = np.random.default_rng(nq * 7 + n * 3 + d + k)
+    X, Q = unit_rows(rng, n, d), unit_rows(rng, nq, d)
+    if metric == "l2":  # IndexFlatL2 is a general index: exercise non-unit norms too
+        X *= rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32)
+        Q *= rng.uniform(0.5, 2.0, (nq, 1)).astype(np.float32)
+    D, I, _ = _search(hip, metric, X, Q, k)
+    _assert_knn_equal((D, I), oracle.knn(metric, X, Q, k))
+
+
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+def test_flat_search_ties_lower_index_wins(hip, oracle, metric):
+    # CIFAR text side: every DB row is one of C prototypes => the whole top-k is ties
+    rng = np.random.default_rng(5)
+    C, n, d, k = 10, 4000, 64, 51
+    proto = unit_rows(rng, C, d)
+    lab = rng.integers(0, C, n)
+    X = proto[lab]
+    Q = proto[rng.integers(0, C, 300)]
+    D, I, _ = _search(hip, metric, X, Q, k)
+    Dr, Ir = oracle.knn(metric, X, Q, k)
+    _assert_knn_equal((D, I), (Dr, Ir))
+    # the tie rule itself: within equal D, indices ascend
+    same = D[:, 1:] == D[:, :-1]
+    assert (I[:, 1:][same] > I[:, :-1][same]).all()
+
+
+def test_flat_search_all_rows_identical(hip, oracle):
+    # adversarial: every candidate ties, every tile passes the filter until the list is full
+    X = np.tile(unit_rows(np.random.default_rng(1), 1, 48), (1500, 1))
+    Q = unit_rows(np.random.default_rng(2), 70, 48)
+    D, I, _ = _search(hip, "ip", X, Q, 20)
+    assert np.array_equal(I, np.tile(np.arange(20), (70, 1)))
+    _assert_knn_equal((D, I), oracle.knn("ip", X, Q, 20))
+
+
+def test_flat_search_ascending_scores_worst_case(hip, oracle):
+    # database sorted so that every later row beats all earlier ones: maximal list churn
+    rng = np.random.default_rng(3)
+    d, n = 32, 3000
+    q = unit_rows(rng, 1, d)
+    noise = unit_rows(rng, n, d)
+    t = np.linspace(0.0, 1.0, n, dtype=np.float32)[:, None]
+    X = (t * q + (1 - t) * 0.1 * noise).astype(np.float32)
+    Q = np.repeat(q, 129, axis=0)
+    D, I, _ = _search(hip, "ip", X, Q, 50)
+    _assert_knn_equal((D, I), oracle.knn("ip", X, Q, 50))
+
+
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+def test_flat_search_padding_and_empty(hip, oracle, metric):
+    rng = np.random.default_rng(9)
+    X, Q = unit_rows(rng, 3, 16), unit_rows(rng, 4, 16)
+    D, I, idx = _search(hip, metric, X, Q, 6)       # k > ntotal -> faiss-style padding
+    _assert_knn_equal((D, I), oracle.knn(metric, X, Q, 6))
+    assert (I[:, 3:] == -1).all()
+    assert idx.ntotal == 3 and idx.d == 16
+    D0, I0 = idx.search(cu(Q[:0]), 3)                # empty query batch
+    assert D0.shape == (0, 3) and I0.shape == (0, 3)
+    De, Ie, _ = _search(hip, metric, X[:0], Q, 2)    # empty index
+    assert (Ie == -1).all()
+
+
+def test_flat_search_incremental_add_and_numpy_io(hip, oracle):
+    rng = np.random.default_rng(11)
+    X, Q = unit_rows(rng, 700, 64), unit_rows(rng, 90, 64)
+    idx = hip.IndexFlatIP(64)
+    idx.add(X[:100]); idx.add(X[100:513]); idx.add(X[513:])     # appends, numpy in
+    D, I = idx.search(Q, 7)                                      # numpy in -> numpy out (faiss contract)
+    assert isinstance(D, np.ndarray) and D.dtype == np.float32 and I.dtype == np.int64
+    _assert_knn_equal((D, I), oracle.knn("ip", X, Q, 7))
+    with pytest.raises(AssertionError):
+        idx.add(X.astype(np.float64))
+    with pytest.raises(ValueError):
+        idx.search(Q, 0)
+
+
+def test_flat_search_cifar_scale(hip, oracle):
+    # C2 shape: 5 000 val queries x 40 000 DB x 512, k+1 = 51
+    rng = np.random.default_rng(21)
+    X, Q = unit_rows(rng, 40000, 512), unit_rows(rng, 2048, 512)
+    D, I, idx = _search(hip, "ip", X, Q, 51)
+    _assert_knn_equal((D, I), oracle.knn("ip", X, Q, 51))
+    info = idx.last_search_info()
+    assert info["n"] == 40000 and info["k"] == 51 and info["grid"] >= 256
+
+
+@pytest.mark.parametrize("metric", ["cosine", "euclidean"])
+@pytest.mark.parametrize("drop_self,discrete", [(False, False), (True, False), (False, True), (True, True)])
+def test_neighbors_record_bit_exact(hip, oracle, metric, drop_self, discrete):
+    k = 5
+    s = planted(seed=0, n_tr=2048, n_q=256, d=64, C=16)
+    img_tr, txt_tr, _, noisy_tr = s["train"]
+    if drop_self:   # train split: queries ARE (mostly) DB rows; a few are not in the DB subset
+        q_img, q_txt, noisy_q = img_tr[:300].copy(), txt_tr[:300].copy(), noisy_tr[:300]
+        in_db = np.ones(300, np.uint8)
+        in_db[::7] = 0
+    else:
+        q_img, q_txt, _, noisy_q = s["query"]
+        in_db = None
+    ref = oracle.neighbors(metric, img_tr, txt_tr, q_img, q_txt, k, drop_self=drop_self, in_db=in_db,
+                           discrete=discrete, tr_label_id=noisy_tr, q_label_id=noisy_q)
+    db = hip.LemonDB(cu(img_tr), cu(txt_tr), metric, tr_label_id=noisy_tr)
+    got = db.neighbors(cu(q_img), cu(q_txt), k, drop_self=drop_self, in_db=in_db, discrete=discrete,
+                       q_label_id=noisy_q)
+    assert np.array_equal(db.dists_tr.cpu().numpy(), ref["dists_tr"])
+    for key in ("I_n", "I_m", "d_1", "D_n", "dists_n", "dists_tr_n", "D_m", "dists_m", "dists_tr_m"):
+        g = got[key].cpu().numpy()
+        assert np.array_equal(g, ref[key]), f"{key}: {(g != ref[key]).sum()} mismatches"
+    # score aggregation (K5) on the device arrays vs the oracle, fixed hparams of train_clip_from_scratch.py:102-109
+    hp = dict(beta=5, gamma=5, tau_1_n=0.1, tau_2_n=5, tau_1_m=0.1, tau_2_m=5)
+    sc = hip.lemon_score(got, hp).cpu().numpy()
+    sref = oracle.score(ref, hp)
+    assert np.allclose(sc, sref, rtol=1e-9, atol=1e-12)
+
+
+def test_d1_normalized(hip, oracle):
+    s = planted(seed=4, n_tr=10, n_q=300, d=64, C=100)
+    q_img, _, _, noisy = s["query"]
+    for metric in ("cosine", "euclidean"):
+        got = hip.d1_normalized(metric, cu(q_img), cu(s["proto"]), torch.from_numpy(noisy)).cpu().numpy()
+        ref = oracle.d1_normalized(metric, q_img, s["proto"], noisy)
+        assert np.abs(got - ref).max() <= 1e-6
+
+
+def test_cpu_tensor_is_refused(hip):
+    with pytest.raises(Exception):
+        hip.normalize_vectors(torch.zeros(4, 4))
