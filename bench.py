@@ -1,0 +1,322 @@
+#!/usr/bin/env python3
+"""bench.py -- LEMoN hot path (CLIP embed -> brute-force kNN -> label-error scores) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+(for N > 1 the driver launches it under torch.distributed.run, one rank per GPU over RCCL).
+
+A step = one pass of the hot path over one batch of synthetic input already resident in HBM.
+Default workload = BASELINE.json configs[1]: CIFAR-100 shape, ViT-B/32, 40 000 train (= DB) +
+5 000 val + 5 000 test samples PER GPU (weak scaling: with N GPUs the DB is the all-gathered
+N x 40 000 rows), 40 % pair-flip label noise, cosine distance, k = 50.  Rank 0 prints ONE JSON line.
+
+Other workloads (not the headline line; used for profiles and DESIGN.md numbers):
+  --workload knn      synthetic N x d unit embeddings, self-join with self-exclusion (configs[3] shape,
+                      default 1M x 768, k=50): kNN + scoring only, no encoder.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters (dense fp32 matrix)
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+PEAK_HBM_GBS = 8000.0          # HBM3E spec peak (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cifar100", choices=["cifar100", "knn"])
+    ap.add_argument("--arch", default="vit-b-32")
+    ap.add_argument("--n_train", type=int, default=40000)
+    ap.add_argument("--n_val", type=int, default=5000)
+    ap.add_argument("--n_test", type=int, default=5000)
+    ap.add_argument("--knn_k", type=int, default=50)
+    ap.add_argument("--dist_type", default="cosine", choices=["cosine", "euclidean"])
+    ap.add_argument("--encoder_batch", type=int, default=1000)
+    ap.add_argument("--text_dedup", action="store_true",
+                    help="embed each distinct prompt once (exact; off by default so every sample's prompt is encoded)")
+    ap.add_argument("--algo", default="auto", choices=["auto", "f32", "bf16"])
+    ap.add_argument("--knn_n", type=int, default=1_000_000)
+    ap.add_argument("--knn_d", type=int, default=768)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_sample_images", type=int, default=96)
+    ap.add_argument("--cpu_sample_queries", type=int, default=2048)
+    return ap.parse_args()
+
+
+def init_dist(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    return world, rank, torch.device("cuda", local)
+
+
+def barrier_sync(world, dev):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+
+
+def max_over_ranks(x, world, dev):
+    if world == 1:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+# ------------------------------------------------------------------------------ workloads
+def make_cifar_like(args, cfg, rank, dev):
+    """Synthetic CIFAR-100-shaped input, resident in HBM: normalised pixel tensors (what
+    generic_transform hands the model, lib/datasets/utils.py:163-170) and tokenised prompts
+    'A photo of a <noisy label>' (run_lemon.py:117-119,140-146)."""
+    from lemon_amd import datasets as ds
+    from lemon_amd.clip import SyntheticTokenizer
+    tok = SyntheticTokenizer(cfg.vocab_size, cfg.context_length, cfg.eos_token_id)
+    prompts = ["A photo of a " + l for l in ds.cifar100_labels]
+    class_ids = torch.tensor(tok(prompts, padding="max_length", truncation=True)["input_ids"])
+    rng = np.random.default_rng(1000 + rank)
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    data = {}
+    for name, n in (("train", args.n_train), ("val", args.n_val), ("test", args.n_test)):
+        clean = rng.integers(0, 100, n)
+        flip = rng.random(n) < 0.4
+        noisy = np.where(flip, (clean + 1) % 100, clean)          # pair-flip ("asymmetric") noise
+        px = torch.empty((n, 3, cfg.image_size, cfg.image_size), dtype=torch.float32, device=dev)
+        for i in range(0, n, 2000):                               # chunked: keeps the RNG workspace small
+            px[i:i + 2000].normal_(generator=g)
+        data[name] = dict(pixels=px, ids=class_ids[torch.from_numpy(noisy)].to(dev),
+                          label_id=torch.from_numpy(noisy.astype(np.int32)).to(dev),
+                          clean=clean, noisy=noisy)
+    return data
+
+
+def bench_cifar(args, world, rank, dev):
+    from lemon_amd import _lib
+    from lemon_amd.clip import ClipConfig, LemonCLIP, encoder_flops
+    from lemon_amd.pipeline import Embedder, FIXED_HPARAMS, run_hot_path
+
+    cfg = ClipConfig.named(args.arch)
+    model = LemonCLIP(cfg)                       # seeded random init (no checkpoints offline)
+    emb = Embedder(model, dev, batch_size=args.encoder_batch, text_dedup=args.text_dedup)
+    data = make_cifar_like(args, cfg, rank, dev)
+    data["train"]["n_total"] = args.n_train * world
+    algo = {"auto": None, "f32": _lib.ALGO_F32_MFMA, "bf16": _lib.ALGO_BF16_FILTER}[args.algo]
+    n_scored = args.n_train + args.n_val + args.n_test
+
+    prof = {"launches": 0, "kernel_ms": 0.0, "algo_flops": 0.0, "algo_bytes": 0.0}
+    stage = {"embed_s": 0.0, "knn_score_s": 0.0}
+
+    def collect(db):
+        for ix in (db.index_img, db.index_txt):
+            p = ix.profile_read()
+            for k_ in prof:
+                prof[k_] += p[k_]
+
+    def step(timers=None, events=False):
+        return run_hot_path(emb, data, k=args.knn_k, dist_type=args.dist_type, hparams=FIXED_HPARAMS,
+                            world_size=world, rank=rank, algo=algo, timers=timers, profile_index=events)
+
+    for _ in range(args.warmup):
+        step()
+    barrier_sync(world, dev)
+    t0 = time.perf_counter()
+    timed = []
+    for _ in range(args.steps):
+        # HIP events bracket every scan-kernel launch of the timed region (recorded on the launch
+        # stream inside the library; read back only after the region ends)
+        recs, db = step(events=True)
+        timed.append(db)
+    barrier_sync(world, dev)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+    for db_ in timed:
+        collect(db_)
+    del timed
+
+    # one extra, untimed step with host syncs between stages: embed vs kNN+score wall split
+    timers = {}
+    recs, db = step(timers=timers)
+    for k_ in stage:
+        stage[k_] += timers[k_]
+    info = db.index_img.last_search_info()
+    f_img, f_txt = encoder_flops(cfg, n_tokens_text=int(data["train"]["ids"].argmax(-1).max().item()) + 1)
+
+    value = n_scored * world * args.steps / elapsed
+    line = {
+        "metric": "label-error scores/sec (embed+kNN), CIFAR-100 noise=0.4",
+        "value": value, "unit": "scores/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"CIFAR-100 shape per GPU: {args.n_train} train (=DB shard) + {args.n_val} val + {args.n_test} test "
+                        f"image/prompt pairs, CLIP {args.arch} random-init fp32 encoder -> {cfg.embed_dim}-d, "
+                        f"{args.dist_type} brute-force kNN k={args.knn_k} over the all-gathered {args.n_train * world}-row DB, "
+                        "multimodal-neighbour scores (beta=gamma=5,tau1=0.1,tau2=5)",
+            "noise": "pair-flip 0.4 (reference's 'asymmetric'; 'cat' is not defined for CIFAR upstream)",
+            "encoder_batch": args.encoder_batch, "text_dedup": bool(args.text_dedup),
+            "train_embedded_once": True, "parallelism": f"dp{world}+allgather",
+        },
+        "stages_s": {k_: v for k_, v in stage.items()},
+        "encoder": {"bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_MFMA_TFLOPS,
+                    "achieved": (f_img + f_txt) * n_scored / max(stage["embed_s"], 1e-9) / 1e12,
+                    "note": "algorithmic forward FLOPs (img+txt) / embed stage wall time, fp32 hipBLASLt+SDPA"},
+    }
+    if prof["launches"]:
+        sec = prof["kernel_ms"] / 1e3
+        tf = prof["algo_flops"] / sec / 1e12
+        line["roofline"] = {
+            "kernel": "k_scan_f32" if info["algo"] == _lib.ALGO_F32_MFMA else "k_scan_bf16",
+            "bound": "mfma", "achieved": tf,
+            "peak": PEAK_F32_MFMA_TFLOPS if info["algo"] == _lib.ALGO_F32_MFMA else PEAK_BF16_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": tf / (PEAK_F32_MFMA_TFLOPS if info["algo"] == _lib.ALGO_F32_MFMA else PEAK_BF16_MFMA_TFLOPS),
+            "traffic": None, "launches": prof["launches"], "avg_launch_ms": prof["kernel_ms"] / prof["launches"],
+            "hbm_scan_model": {"B": info["query_panel"], "achieved_GBs": prof["algo_bytes"] / sec / 1e9,
+                               "peak_GBs": PEAK_HBM_GBS, "frac": prof["algo_bytes"] / sec / 1e9 / PEAK_HBM_GBS},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"], line["auroc_check"] = cpu_baseline_cifar(args, cfg, model, data, recs, db, n_scored)
+    return line
+
+
+def cpu_baseline_cifar(args, cfg, model, data, recs, db, n_scored):
+    """The CPU port (oracle/ + the same CLIP module on CPU fp32) timed on this host's cores on a bounded
+    sample of the same workload, scaled to scores/s.  Also the AUROC parity check GPU vs oracle on the
+    val split (same embeddings)."""
+    from oracle import oracle as o
+    from lemon_amd.pipeline import FIXED_HPARAMS
+    cores = o.usable_cores()             # affinity mask / cgroup quota, not os.cpu_count()
+    torch.set_num_threads(cores)
+    o.set_threads(cores)
+    cpu_model = type(model)(cfg)
+    cpu_model.load_state_dict(model.state_dict())
+    cpu_model = cpu_model.float().eval()
+    ni = min(args.cpu_sample_images, args.n_val)
+    px = data["val"]["pixels"][:ni].cpu()
+    ids = data["val"]["ids"][:ni].cpu()
+    cpu_model.encode_image(px[:8])                              # warm
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for i in range(0, ni, 32):
+            cpu_model.encode_image(px[i:i + 32]); cpu_model.encode_text(ids[i:i + 32])
+    t_embed = (time.perf_counter() - t0) / ni                   # s per (image, prompt) pair
+    # kNN + per-sample quantities + scores: the oracle on the first nqs val queries against the full DB
+    nqs = min(args.cpu_sample_queries, args.n_val)
+    img_tr, txt_tr = db.img.cpu().numpy(), db.txt.cpu().numpy()
+    rv = recs["val"]
+    q_img = rv["emb_img"][:nqs].cpu().numpy()      # the very embeddings the GPU scores came from
+    q_txt = rv["emb_txt"][:nqs].cpu().numpy()
+    t0 = time.perf_counter()
+    ref = o.neighbors(args.dist_type, img_tr, txt_tr, q_img, q_txt, args.knn_k)
+    sref = o.score(ref, FIXED_HPARAMS)
+    t_knn = (time.perf_counter() - t0) / nqs                    # s per query (DB fixed at n_train rows)
+    per_sample = t_embed + t_knn
+    y = (data["val"]["clean"] != data["val"]["noisy"])[:nqs]
+    sgpu = rv["score"][:nqs].cpu().numpy()
+    same_sets = bool(np.array_equal(rv["I_n"][:nqs].cpu().numpy(), ref["I_n"]) and
+                     np.array_equal(rv["I_m"][:nqs].cpu().numpy(), ref["I_m"]))
+    arrays_equal = all(np.array_equal(rv[key][:nqs].cpu().numpy(), ref[key]) for key in
+                       ("d_1", "D_n", "dists_n", "dists_tr_n", "D_m", "dists_m", "dists_tr_m"))
+    auroc = {"gpu": o.auroc(y, sgpu), "oracle": o.auroc(y, sref), "n": int(nqs),
+             "max_abs_score_diff": float(np.abs(sgpu - sref).max()), "topk_sets_identical": same_sets,
+             "per_sample_arrays_bit_exact": bool(arrays_equal)}
+    base = {
+        "value": 1.0 / per_sample, "unit": "scores/s", "cores": cores, "kind": "port",
+        "sample": f"{ni} image+prompt pairs through the same CLIP module on CPU fp32 (torch, {cores} threads) "
+                  f"+ oracle kNN/neighbours/score for {nqs} val queries against the full {args.n_train}-row DB "
+                  f"(OpenMP, {cores} threads); per-sample times added and inverted; train embedded once as on the GPU",
+        "embed_s_per_sample": t_embed, "knn_score_s_per_sample": t_knn,
+    }
+    return base, auroc
+
+
+def bench_knn(args, world, rank, dev):
+    """configs[3] shape: synthetic N x d unit embeddings per modality, self-join, k+1 with self-exclusion.
+    Strong-scaled over ranks by query sharding (DB replicated after an all-gather of the shards)."""
+    from lemon_amd import _lib, ops
+    from lemon_amd.neighbors import LemonDB
+    from lemon_amd.pipeline import FIXED_HPARAMS, all_gather_rows, shard_bounds
+    n, d, k = args.knn_n, args.knn_d, args.knn_k
+    lo, hi = shard_bounds(n, world, rank)
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    img = ops.normalize_vectors(torch.randn((hi - lo, d), generator=g, device=dev))
+    txt = ops.normalize_vectors(torch.randn((hi - lo, d), generator=g, device=dev))
+    algo = {"auto": None, "f32": _lib.ALGO_F32_MFMA, "bf16": _lib.ALGO_BF16_FILTER}[args.algo]
+    prof = {"launches": 0, "kernel_ms": 0.0, "algo_flops": 0.0, "algo_bytes": 0.0}
+
+    def step(events):
+        db = LemonDB(all_gather_rows(img, n), all_gather_rows(txt, n), args.dist_type, algo=algo)
+        if events:
+            db.index_img.set_profiling(True); db.index_txt.set_profiling(True)
+        rec = db.neighbors(img, txt, k, drop_self=True, return_indices=False)
+        s = ops.lemon_score(rec, FIXED_HPARAMS)
+        return db, s
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier_sync(world, dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        db, s = step(True)       # events recorded on the launch stream, read after the region
+        torch.cuda.synchronize(dev)
+        for ix in (db.index_img, db.index_txt):
+            p = ix.profile_read()
+            for k_ in prof:
+                prof[k_] += p[k_]
+    barrier_sync(world, dev)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+    info = db.index_img.last_search_info()
+    sec = prof["kernel_ms"] / 1e3
+    f32 = info["algo"] == _lib.ALGO_F32_MFMA
+    peak = PEAK_F32_MFMA_TFLOPS if f32 else PEAK_BF16_MFMA_TFLOPS
+    return {
+        "metric": "label-error scores/sec (kNN+score only), synthetic embeddings", "value": n * args.steps / elapsed,
+        "unit": "scores/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"synthetic {n}x{d} unit embeddings per modality, self-join k={k} (+1 self-exclusion), "
+                               f"{args.dist_type}, query-sharded over {world} GPU(s), DB all-gathered"},
+        "roofline": {"kernel": "k_scan_f32" if f32 else "k_scan_bf16", "bound": "mfma",
+                     "achieved": prof["algo_flops"] / sec / 1e12, "peak": peak, "unit": "TFLOP/s",
+                     "frac": prof["algo_flops"] / sec / 1e12 / peak, "traffic": None,
+                     "launches": prof["launches"], "avg_launch_ms": prof["kernel_ms"] / max(prof["launches"], 1),
+                     "hbm_scan_model": {"B": info["query_panel"], "achieved_GBs": prof["algo_bytes"] / sec / 1e9,
+                                        "peak_GBs": PEAK_HBM_GBS, "frac": prof["algo_bytes"] / sec / 1e9 / PEAK_HBM_GBS}},
+    }
+
+
+def main():
+    args = parse()
+    world, rank, dev = init_dist(args)
+    from lemon_amd import _lib
+    _lib.load()                                   # fail loudly if the HIP library is missing
+    line = bench_cifar(args, world, rank, dev) if args.workload == "cifar100" else bench_knn(args, world, rank, dev)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,6 +107,16 @@ typedef struct {
 } lemon_search_info_t;
 int lemon_index_last_search_info(const lemon_index_t *idx, lemon_search_info_t *out);
 
+/* Optional in-library timing of the scan kernel (the dominant kernel of search): when enabled,
+ * every scan launch is bracketed by hipEvents recorded on the launch stream.
+ * lemon_index_profile_read synchronises those events (host sync!) and returns, summed since the
+ * last reset: launches, kernel milliseconds, algorithmic flops (2*nq*n*d) and algorithmic HBM bytes
+ * of the scan model (4*d*(nq + ceil(nq/B)*n) + 12*k*nq with B = query_panel); then
+ * resets the counters.  Any output pointer may be NULL. */
+int lemon_index_set_profiling(lemon_index_t *idx, int enabled);
+int lemon_index_profile_read(lemon_index_t *idx, int64_t *launches, double *kernel_ms,
+                             double *algo_flops, double *algo_bytes);
+
 /* ---- multimodal neighbours (the per-sample loop run_lemon.py:238-307) ------------- */
 
 /*

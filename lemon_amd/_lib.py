@@ -18,7 +18,8 @@ EXPORTS = [
     "lemon_last_error", "lemon_version", "lemon_normalize_rows", "lemon_paired_distance",
     "lemon_d1_normalized", "lemon_index_create", "lemon_index_free", "lemon_index_add",
     "lemon_index_ntotal", "lemon_index_dim", "lemon_index_data", "lemon_index_search",
-    "lemon_index_set_algo", "lemon_index_last_search_info", "lemon_neighbors", "lemon_score",
+    "lemon_index_set_algo", "lemon_index_last_search_info", "lemon_index_set_profiling",
+    "lemon_index_profile_read", "lemon_neighbors", "lemon_score",
 ]
 
 
@@ -66,6 +67,8 @@ def load():
     lib.lemon_index_search.argtypes = [vp, vp, c_i64, c_int, vp, vp, vp]
     lib.lemon_index_set_algo.argtypes = [vp, c_int]
     lib.lemon_index_last_search_info.argtypes = [vp, ctypes.POINTER(SearchInfo)]
+    lib.lemon_index_set_profiling.argtypes = [vp, c_int]
+    lib.lemon_index_profile_read.argtypes = [vp, ctypes.POINTER(c_i64)] + [ctypes.POINTER(ctypes.c_double)] * 3
     lib.lemon_neighbors.argtypes = [vp, vp, vp, vp, vp, c_i64, c_int, c_int, vp, c_int, vp, vp] + [vp] * 9 + [vp]
     lib.lemon_score.argtypes = [vp] * 7 + [c_i64, c_int, ctypes.POINTER(ctypes.c_double), vp, vp, vp, vp]
     _lib = lib

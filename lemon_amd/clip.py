@@ -1,0 +1,298 @@
+"""CLIP dual encoder for the embedding stage of the hot path (PyTorch-ROCm: hipBLASLt GEMMs + SDPA
+run on the MFMA pipes; this file is plumbing around them, not a kernel).
+
+Mirrors the model surface run_lemon.py uses:
+  algorithm_class_from_scratch(name, text_base_name, img_base, return_tokenizer)   lib/models/utils.py:64-105
+  model.encode_text(input_ids, attention_mask) / model.encode_image(pixel_values)  lib/models/downstream_models.py:30-41
+The architecture is the one HF `CLIPModel` / the in-tree CheXzero copy implement
+(lib/models/chexzero_clip.py:177-260,263-392): pre-LN transformer blocks, QuickGELU
+(`x * sigmoid(1.702 x)`, :186-188), causal text mask (:348-354), EOT pooling by argmax of the token
+ids (:363-376), bias-free projections.  Weights load from a LOCAL HF checkpoint directory
+(config.json + model.safetensors | pytorch_model.bin); there is no network in this environment,
+so loading by hub name is refused with a clear message.
+
+MI355X-first choices: fused QKV projection (one [3W,W] GEMM instead of three), SDPA instead of a
+materialised attention matrix, text batches truncated to the longest prompt (exact, because the mask
+is causal and pooling reads the EOT position: SURVEY 3.2), distinct prompts embedded once and
+gathered (classification datasets have C distinct prompts for N samples).
+"""
+import json
+import math
+import os
+from dataclasses import dataclass, field
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+@dataclass
+class TowerConfig:
+    width: int
+    layers: int
+    heads: int
+    mlp: int
+
+
+@dataclass
+class ClipConfig:
+    embed_dim: int = 512
+    image_size: int = 224
+    patch_size: int = 32
+    vision: TowerConfig = field(default_factory=lambda: TowerConfig(768, 12, 12, 3072))
+    text: TowerConfig = field(default_factory=lambda: TowerConfig(512, 12, 8, 2048))
+    vocab_size: int = 49408
+    context_length: int = 77
+    eos_token_id: int = 49407
+    layer_norm_eps: float = 1e-5
+
+    @staticmethod
+    def named(name):
+        """The three architectures BASELINE.json's configs name (the reference hard-codes B/32,
+        run_lemon.py:113; selecting another one is an explicit extension)."""
+        name = name.lower().replace("openai/clip-", "").replace("_", "-")
+        if name in ("vit-b-32", "vit-base-patch32", "b32"):
+            return ClipConfig()
+        if name in ("vit-b-16", "vit-base-patch16", "b16"):
+            return ClipConfig(patch_size=16)
+        if name in ("vit-l-14", "vit-large-patch14", "l14"):
+            return ClipConfig(embed_dim=768, patch_size=14, vision=TowerConfig(1024, 24, 16, 4096),
+                              text=TowerConfig(768, 12, 12, 3072))
+        if name in ("tiny", "test"):
+            return ClipConfig(embed_dim=32, image_size=32, patch_size=8, vision=TowerConfig(48, 2, 4, 96),
+                              text=TowerConfig(40, 2, 4, 80), vocab_size=300, context_length=16, eos_token_id=299)
+        raise ValueError(f"unknown CLIP architecture {name!r}")
+
+    @staticmethod
+    def from_hf_dict(c):
+        v, t = c["vision_config"], c["text_config"]
+        return ClipConfig(
+            embed_dim=c.get("projection_dim", 512), image_size=v.get("image_size", 224),
+            patch_size=v.get("patch_size", 32),
+            vision=TowerConfig(v.get("hidden_size", 768), v.get("num_hidden_layers", 12),
+                               v.get("num_attention_heads", 12), v.get("intermediate_size", 3072)),
+            text=TowerConfig(t.get("hidden_size", 512), t.get("num_hidden_layers", 12),
+                             t.get("num_attention_heads", 8), t.get("intermediate_size", 2048)),
+            vocab_size=t.get("vocab_size", 49408), context_length=t.get("max_position_embeddings", 77),
+            eos_token_id=t.get("eos_token_id", 49407), layer_norm_eps=v.get("layer_norm_eps", 1e-5))
+
+
+class Block(nn.Module):
+    def __init__(self, cfg: TowerConfig, eps):
+        super().__init__()
+        self.heads = cfg.heads
+        self.ln1 = nn.LayerNorm(cfg.width, eps=eps)
+        self.qkv = nn.Linear(cfg.width, 3 * cfg.width)
+        self.out = nn.Linear(cfg.width, cfg.width)
+        self.ln2 = nn.LayerNorm(cfg.width, eps=eps)
+        self.fc1 = nn.Linear(cfg.width, cfg.mlp)
+        self.fc2 = nn.Linear(cfg.mlp, cfg.width)
+
+    def forward(self, x, causal):
+        B, L, W = x.shape
+        q, k, v = self.qkv(self.ln1(x)).view(B, L, 3, self.heads, W // self.heads).permute(2, 0, 3, 1, 4)
+        a = F.scaled_dot_product_attention(q, k, v, is_causal=causal)
+        x = x + self.out(a.transpose(1, 2).reshape(B, L, W))
+        h = self.fc1(self.ln2(x))
+        h = h * torch.sigmoid(1.702 * h)          # QuickGELU
+        return x + self.fc2(h)
+
+
+class VisionTower(nn.Module):
+    def __init__(self, cfg: ClipConfig):
+        super().__init__()
+        v = cfg.vision
+        self.patch = nn.Conv2d(3, v.width, cfg.patch_size, cfg.patch_size, bias=False)
+        n_pos = (cfg.image_size // cfg.patch_size) ** 2 + 1
+        self.cls = nn.Parameter(torch.zeros(v.width))
+        self.pos = nn.Parameter(torch.zeros(n_pos, v.width))
+        self.pre_ln = nn.LayerNorm(v.width, eps=cfg.layer_norm_eps)
+        self.blocks = nn.ModuleList([Block(v, cfg.layer_norm_eps) for _ in range(v.layers)])
+        self.post_ln = nn.LayerNorm(v.width, eps=cfg.layer_norm_eps)
+        self.proj = nn.Linear(v.width, cfg.embed_dim, bias=False)
+
+    def forward(self, pixel_values):
+        x = self.patch(pixel_values.to(self.patch.weight.dtype)).flatten(2).transpose(1, 2)
+        x = torch.cat([self.cls.expand(x.shape[0], 1, -1), x], dim=1) + self.pos
+        x = self.pre_ln(x)
+        for b in self.blocks:
+            x = b(x, causal=False)
+        return self.proj(self.post_ln(x[:, 0]))
+
+
+class TextTower(nn.Module):
+    def __init__(self, cfg: ClipConfig):
+        super().__init__()
+        t = cfg.text
+        self.eos_token_id = cfg.eos_token_id
+        self.tok = nn.Embedding(cfg.vocab_size, t.width)
+        self.pos = nn.Parameter(torch.zeros(cfg.context_length, t.width))
+        self.blocks = nn.ModuleList([Block(t, cfg.layer_norm_eps) for _ in range(t.layers)])
+        self.final_ln = nn.LayerNorm(t.width, eps=cfg.layer_norm_eps)
+        self.proj = nn.Linear(t.width, cfg.embed_dim, bias=False)
+
+    def forward(self, input_ids):
+        # EOT position = argmax of the ids (EOT has the largest id: chexzero_clip.py:374-376 and HF's
+        # legacy eos path); truncate the batch to the longest prompt (exact under the causal mask)
+        eot = input_ids.argmax(dim=-1)
+        L = int(eot.max().item()) + 1
+        ids = input_ids[:, :L]
+        x = self.tok(ids) + self.pos[:L]
+        for b in self.blocks:
+            x = b(x, causal=True)
+        x = self.final_ln(x)
+        return self.proj(x[torch.arange(x.shape[0], device=x.device), eot])
+
+
+class LemonCLIP(nn.Module):
+    """encode_text / encode_image with the signatures of HuggingfaceCLIPModel
+    (lib/models/downstream_models.py:37-41).  Outputs are un-normalised [B, embed_dim]."""
+
+    def __init__(self, cfg: ClipConfig = None):
+        super().__init__()
+        self.cfg = cfg or ClipConfig()
+        self.vision = VisionTower(self.cfg)
+        self.text = TextTower(self.cfg)
+        self.reset_parameters()
+
+    def reset_parameters(self, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        for p in self.parameters():
+            if p.dim() > 1:
+                with torch.no_grad():
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+        for m in self.modules():
+            if isinstance(m, nn.LayerNorm):
+                nn.init.ones_(m.weight); nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Linear) and m.bias is not None:
+                nn.init.zeros_(m.bias)
+        with torch.no_grad():
+            self.vision.cls.copy_(torch.randn(self.vision.cls.shape, generator=g) * 0.02)
+
+    @torch.no_grad()
+    def encode_image(self, pixel_values=None):
+        return self.vision(pixel_values)
+
+    @torch.no_grad()
+    def encode_text(self, input_ids=None, attention_mask=None):
+        # attention_mask is accepted for signature parity and ignored: EOT-pooled features of a causal
+        # transformer do not depend on it (max |delta| = 0.0 measured)
+        return self.text(input_ids)
+
+    @torch.no_grad()
+    def encode_text_dedup(self, input_ids):
+        """Embed each distinct prompt once and gather (identical rows give identical embeddings)."""
+        uniq, inv = torch.unique(input_ids, dim=0, return_inverse=True)
+        return self.text(uniq)[inv]
+
+    # ---------------------------------------------------------------- HF checkpoint mapping
+    def load_hf_state_dict(self, sd):
+        """Load a `transformers.CLIPModel` state dict (names as in openai/clip-vit-* checkpoints)."""
+        own = {}
+
+        def tower(prefix, blocks, n):
+            for i in range(n):
+                p = f"{prefix}.encoder.layers.{i}."
+                b = f"{blocks}.{i}."
+                for kind in ("weight", "bias"):
+                    own[b + f"qkv.{kind}"] = torch.cat([sd[p + f"self_attn.{x}_proj.{kind}"] for x in "qkv"], 0)
+                    own[b + f"out.{kind}"] = sd[p + f"self_attn.out_proj.{kind}"]
+                    own[b + f"ln1.{kind}"] = sd[p + f"layer_norm1.{kind}"]
+                    own[b + f"ln2.{kind}"] = sd[p + f"layer_norm2.{kind}"]
+                    own[b + f"fc1.{kind}"] = sd[p + f"mlp.fc1.{kind}"]
+                    own[b + f"fc2.{kind}"] = sd[p + f"mlp.fc2.{kind}"]
+
+        tower("vision_model", "vision.blocks", self.cfg.vision.layers)
+        tower("text_model", "text.blocks", self.cfg.text.layers)
+        own["vision.patch.weight"] = sd["vision_model.embeddings.patch_embedding.weight"]
+        own["vision.cls"] = sd["vision_model.embeddings.class_embedding"]
+        own["vision.pos"] = sd["vision_model.embeddings.position_embedding.weight"]
+        for kind in ("weight", "bias"):
+            own[f"vision.pre_ln.{kind}"] = sd[f"vision_model.pre_layrnorm.{kind}"]
+            own[f"vision.post_ln.{kind}"] = sd[f"vision_model.post_layernorm.{kind}"]
+            own[f"text.final_ln.{kind}"] = sd[f"text_model.final_layer_norm.{kind}"]
+        own["vision.proj.weight"] = sd["visual_projection.weight"]
+        own["text.tok.weight"] = sd["text_model.embeddings.token_embedding.weight"]
+        own["text.pos"] = sd["text_model.embeddings.position_embedding.weight"]
+        own["text.proj.weight"] = sd["text_projection.weight"]
+        missing, unexpected = self.load_state_dict(own, strict=True), None
+        return self
+
+    @classmethod
+    def from_pretrained(cls, path):
+        """Local HF checkpoint directory only (no hub access in this environment)."""
+        if not os.path.isdir(path):
+            raise FileNotFoundError(
+                f"CLIP weights {path!r}: not a local directory. The reference loads "
+                "'openai/clip-vit-base-patch32' from the HF hub (lib/models/utils.py:66-67); this build has no "
+                "network, so pass a local checkpoint directory (--clip_path) or use random weights (--clip_path random).")
+        with open(os.path.join(path, "config.json")) as f:
+            cfg = ClipConfig.from_hf_dict(json.load(f))
+        model = cls(cfg)
+        st = os.path.join(path, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+        return model.load_hf_state_dict(sd)
+
+
+class SyntheticTokenizer:
+    """Deterministic stand-in for the HF CLIP tokenizer when no vocabulary files exist locally
+    (synthetic runs, smoke tests): whitespace words -> stable ids, SOT/EOT framing, max_length padding.
+    Callable like the reference uses it: tokenizer(list[str], padding="max_length", truncation=True)
+    -> {"input_ids": [[...]], "attention_mask": [[...]]}  (run_lemon.py:151-154)."""
+
+    def __init__(self, vocab_size=49408, context_length=77, eos_token_id=49407):
+        self.vocab_size, self.context_length, self.eos = vocab_size, context_length, eos_token_id
+        self.sot = eos_token_id - 1
+
+    def _word_id(self, w):
+        h = 2166136261
+        for ch in w.lower().encode("utf-8"):
+            h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
+        return 1 + h % (self.sot - 1)
+
+    def __call__(self, texts, padding="max_length", truncation=True, **_):
+        ids, mask = [], []
+        for t in texts:
+            toks = [self.sot] + [self._word_id(w) for w in str(t).split()][: self.context_length - 2] + [self.eos]
+            pad = self.context_length - len(toks)
+            ids.append(toks + [0] * pad)
+            mask.append([1] * len(toks) + [0] * pad)
+        return {"input_ids": ids, "attention_mask": mask}
+
+
+def algorithm_class_from_scratch(name, text_base_name="openai/clip-vit-base-patch32", img_base=None,
+                                 return_tokenizer=False, arch=None):
+    """lib/models/utils.py:64-105, 'huggingface_clip' branch.  `text_base_name` is a LOCAL checkpoint
+    directory, or 'random[:arch]' for seeded random weights (synthetic / smoke runs).  The other
+    branches of the reference (biomed_clip, chexzero, *_from_scratch) need weights that only exist on
+    the authors' cluster paths (lib/models/utils.py:20-25) and are refused explicitly."""
+    if name != "huggingface_clip":
+        raise NotImplementedError(
+            f"clip_model={name!r}: only 'huggingface_clip' is available; the other reference branches load "
+            "checkpoints from the authors' cluster paths (lib/models/utils.py:20-25,72-103)")
+    if str(text_base_name).startswith("random"):
+        parts = str(text_base_name).split(":")
+        cfg = ClipConfig.named(arch or (parts[1] if len(parts) > 1 else "vit-b-32"))
+        model = LemonCLIP(cfg)
+        tok = SyntheticTokenizer(cfg.vocab_size, cfg.context_length, cfg.eos_token_id)
+    else:
+        model = LemonCLIP.from_pretrained(text_base_name)
+        from transformers import AutoTokenizer
+        tok = AutoTokenizer.from_pretrained(text_base_name, local_files_only=True)
+    return (model, tok) if return_tokenizer else model
+
+
+def encoder_flops(cfg: ClipConfig, n_tokens_text=None):
+    """Algorithmic forward FLOPs per (image, caption) pair: 2*m*n*k per GEMM + attention."""
+    def tower(t: TowerConfig, L):
+        per_layer = 2 * L * (4 * t.width * t.width + 2 * t.width * t.mlp) + 4 * L * L * t.width
+        return t.layers * per_layer
+    Lv = (cfg.image_size // cfg.patch_size) ** 2 + 1
+    Lt = n_tokens_text or cfg.context_length
+    img = tower(cfg.vision, Lv) + 2 * (Lv - 1) * 3 * cfg.patch_size ** 2 * cfg.vision.width + 2 * cfg.vision.width * cfg.embed_dim
+    txt = tower(cfg.text, Lt) + 2 * cfg.text.width * cfg.embed_dim
+    return img, txt

@@ -37,7 +37,9 @@ extern "C" int lemon_index_create(int metric, int d, lemon_index_t **out) {
     idx->d = d;
     idx->dpad = (int)round_up64(d, 32);
     idx->algo = LEMON_ALGO_AUTO;
+    idx->prof_events = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
     if (hipGetDevice(&idx->device) != hipSuccess) {
+        delete idx->prof_events;
         free(idx);
         lemon_set_error("hipGetDevice failed: no HIP device available");
         return LEMON_E_HIP;
@@ -52,6 +54,8 @@ extern "C" int lemon_index_free(lemon_index_t *idx) {
                     idx->ws_cand, idx->ws_part, idx->ws_D, idx->ws_I};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (auto &e : *idx->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    delete idx->prof_events;
     free(idx);
     return LEMON_OK;
 }
@@ -70,6 +74,32 @@ extern "C" int lemon_index_set_algo(lemon_index_t *idx, int algo) {
 extern "C" int lemon_index_last_search_info(const lemon_index_t *idx, lemon_search_info_t *out) {
     LEMON_REQUIRE(idx && out, "null pointer");
     *out = idx->last;
+    return LEMON_OK;
+}
+
+extern "C" int lemon_index_set_profiling(lemon_index_t *idx, int enabled) {
+    LEMON_REQUIRE(idx != nullptr, "index handle");
+    idx->profiling = enabled ? 1 : 0;
+    return LEMON_OK;
+}
+
+extern "C" int lemon_index_profile_read(lemon_index_t *idx, int64_t *launches, double *kernel_ms,
+                                        double *algo_flops, double *algo_bytes) {
+    LEMON_REQUIRE(idx != nullptr, "index handle");
+    double ms = 0.0;
+    for (auto &e : *idx->prof_events) {
+        LEMON_HIP_CHECK(hipEventSynchronize(e.second));
+        float t = 0.0f;
+        LEMON_HIP_CHECK(hipEventElapsedTime(&t, e.first, e.second));
+        ms += t;
+        (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+    }
+    if (launches) *launches = (int64_t)idx->prof_events->size();
+    if (kernel_ms) *kernel_ms = ms;
+    if (algo_flops) *algo_flops = idx->prof_flops;
+    if (algo_bytes) *algo_bytes = idx->prof_bytes;
+    idx->prof_events->clear();
+    idx->prof_flops = 0.0; idx->prof_bytes = 0.0;
     return LEMON_OK;
 }
 

@@ -7,6 +7,8 @@
 #include <string.h>
 #include <float.h>
 #include "../../include/lemon_hip.h"
+#include <vector>
+#include <utility>
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
@@ -63,6 +65,27 @@ struct lemon_index {
     float *ws_D;          // [ws_nb]
     int64_t *ws_I;        // [ws_nb]
     lemon_search_info_t last;
+    // optional scan-kernel timing (lemon_index_set_profiling)
+    int profiling;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> *prof_events;
+    double prof_flops, prof_bytes;
+};
+
+// bracket a kernel launch with events when profiling is on
+struct LemonProfScope {
+    lemon_index *idx; hipStream_t s; hipEvent_t a, b; bool on;
+    LemonProfScope(lemon_index *i, hipStream_t st, double flops, double bytes) : idx(i), s(st), on(false) {
+        if (!i->profiling) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        on = true;
+        (void)hipEventRecord(a, s);
+        i->prof_flops += flops; i->prof_bytes += bytes;
+    }
+    ~LemonProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(b, s);
+        idx->prof_events->push_back(std::make_pair(a, b));
+    }
 };
 
 // ---- key packing: bigger key == better candidate ----------------------------------

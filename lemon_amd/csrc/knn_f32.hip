@@ -435,7 +435,12 @@ int lemon_search_f32(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, 
         p.nq = cn; p.n = idx->n; p.dpad = dpad; p.kk = k; p.metric = idx->metric;
         p.n_tiles = n_tiles; p.tiles_per_split = tiles_per_split; p.splits = splits; p.nq_pad = nq_pad;
         const unsigned grid = (unsigned)(panels * splits);
-        hipLaunchKernelGGL(k_scan_f32, dim3(grid), dim3(NT), 0, stream, p);
+        {
+            const double flops = 2.0 * (double)cn * (double)idx->n * (double)d;
+            const double bytes = 4.0 * d * ((double)cn + (double)panels * (double)idx->n) + 12.0 * k * (double)cn;
+            LemonProfScope prof(idx, stream, flops, bytes);
+            hipLaunchKernelGGL(k_scan_f32, dim3(grid), dim3(NT), 0, stream, p);
+        }
         LEMON_HIP_CHECK(hipGetLastError());
         if (splits > 1) {
             hipLaunchKernelGGL(k_merge, dim3((unsigned)((cn + 3) / 4)), dim3(256), 0, stream, idx->ws_part,

@@ -54,6 +54,17 @@ class _IndexFlat:
         _lib.check(self._lib.lemon_index_last_search_info(self._h, ctypes.byref(info)), "last_search_info")
         return {f: getattr(info, f) for f, _ in info._fields_}
 
+    def set_profiling(self, enabled=True):
+        _lib.check(self._lib.lemon_index_set_profiling(self._h, int(bool(enabled))), "lemon_index_set_profiling")
+
+    def profile_read(self):
+        """(launches, kernel_ms, algo_flops, algo_bytes) of the scan kernel since the last read."""
+        n = ctypes.c_int64()
+        ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(self._lib.lemon_index_profile_read(self._h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl),
+                                                      ctypes.byref(by)), "lemon_index_profile_read")
+        return dict(launches=n.value, kernel_ms=ms.value, algo_flops=fl.value, algo_bytes=by.value)
+
     def _to_dev(self, x, what):
         if isinstance(x, np.ndarray):
             # faiss asserts a C-contiguous float32 [n, d] array

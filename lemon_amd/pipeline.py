@@ -1,0 +1,124 @@
+"""Device-resident restatement of run_lemon.py:121-312 (embed DB -> flat indices -> score every split).
+
+The reference moves every embedding to the CPU (run_lemon.py:158-161,230-233) and loops per sample in
+Python (:238-307).  Here embeddings never leave HBM: encoder output -> K1 normalise -> LemonDB
+(K2 dists_tr + index.add) -> one lemon_neighbors call per split (K3+K4) -> K5 scores.  With
+world_size > 1 every rank embeds its shard of each split, the DB shards are all-gathered over RCCL
+(torch.distributed, backend "nccl") and each rank scores its own query shard.
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import ops
+from .neighbors import LemonDB
+
+FIXED_HPARAMS = dict(beta=5.0, gamma=5.0, tau_1_n=0.1, tau_2_n=5.0, tau_1_m=0.1, tau_2_m=5.0)
+# ^ train_clip_from_scratch.py:102-109 / notebooks/hparam_drop.ipynb cell 4 (SURVEY 8d metric (ii))
+
+
+def shard_bounds(n, world_size, rank):
+    """Contiguous row range of `rank`: rows [r*ceil(n/W), ...)."""
+    per = (n + world_size - 1) // world_size
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+def all_gather_rows(t, n_total, group=None):
+    """All-gather row shards (possibly ragged: last shard short/empty) into global row order.
+    One RCCL all_gather per array; shards are padded to ceil(n/W) rows."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t
+    W = dist.get_world_size(group)
+    per = (n_total + W - 1) // W
+    pad = torch.zeros((per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[: t.shape[0]] = t
+    out = torch.empty((W * per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return out[:n_total]
+
+
+class Embedder:
+    """HOT LOOP 1/2 of run_lemon.py (:137-161, :202-233) without the D2H copies."""
+
+    def __init__(self, model, device, batch_size=128, dtype=torch.float32, text_dedup=False):
+        self.model = model.eval().to(device=device, dtype=dtype)
+        self.device, self.batch_size, self.dtype, self.text_dedup = device, batch_size, dtype, text_dedup
+
+    @torch.no_grad()
+    def embed_images(self, pixel_values):
+        outs = []
+        for i in range(0, pixel_values.shape[0], self.batch_size):
+            px = pixel_values[i:i + self.batch_size].to(self.device, non_blocking=True)
+            outs.append(self.model.encode_image(px).float())
+        e = torch.cat(outs) if outs else torch.empty((0, self.model.cfg.embed_dim), device=self.device)
+        return ops.normalize_vectors(e) if e.shape[0] else e                          # :164 / :233
+
+    @torch.no_grad()
+    def embed_texts(self, input_ids):
+        input_ids = input_ids.to(self.device)
+        if self.text_dedup:
+            uniq, inv = torch.unique(input_ids, dim=0, return_inverse=True)
+            e = self._embed_texts(uniq)[inv]
+        else:
+            e = self._embed_texts(input_ids)
+        return ops.normalize_vectors(e) if e.shape[0] else e                          # :163 / :230-232
+
+    def _embed_texts(self, ids):
+        outs = [self.model.encode_text(ids[i:i + self.batch_size]).float()
+                for i in range(0, ids.shape[0], self.batch_size)]
+        return torch.cat(outs) if outs else torch.empty((0, self.model.cfg.embed_dim), device=self.device)
+
+
+def score_splits(db, splits, k, hparams=None, discrete=False):
+    """splits: list of dicts {name, img, txt, drop_self, in_db, label_id}.  Returns per split the
+    record of device arrays (+ 'score' float64 when hparams is given)."""
+    out = {}
+    for s in splits:
+        rec = db.neighbors(s["img"], s["txt"], k, drop_self=s.get("drop_self", False), in_db=s.get("in_db"),
+                           discrete=discrete, q_label_id=s.get("label_id"))
+        if hparams is not None:
+            rec["score"] = ops.lemon_score(rec, hparams)
+        out[s["name"]] = rec
+    return out
+
+
+def run_hot_path(embedder, data, k=5, dist_type="cosine", hparams=FIXED_HPARAMS, discrete=False,
+                 world_size=1, rank=0, algo=None, timers=None, profile_index=False):
+    """One pass of the hot path over `data` = {split: {"pixels": [n,3,H,W], "ids": [n,L], "label_id": [n]}}
+    for split in train/val/test, this rank's shard of each.  DB = all ranks' train shards in global
+    order.  The train split is embedded ONCE and reused as DB and as queries (the reference embeds it
+    twice, run_lemon.py:137-161 and :198-233; same model, same inputs => same embeddings)."""
+    dev = embedder.device
+    t0 = time.perf_counter()
+    emb = {}
+    for name, d in data.items():
+        emb[name] = (embedder.embed_images(d["pixels"]), embedder.embed_texts(d["ids"]))
+    if timers is not None:
+        torch.cuda.synchronize(dev)
+        timers["embed_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+    n_train_total = data["train"].get("n_total", emb["train"][0].shape[0])
+    img_tr = all_gather_rows(emb["train"][0], n_train_total)
+    txt_tr = all_gather_rows(emb["train"][1], n_train_total)
+    lab = data["train"].get("label_id")
+    lab_tr = all_gather_rows(lab.to(dev), n_train_total) if (discrete and lab is not None) else None
+    db = LemonDB(img_tr, txt_tr, dist_type, tr_label_id=lab_tr, algo=algo)
+    if profile_index:
+        db.index_img.set_profiling(True)
+        db.index_txt.set_profiling(True)
+    splits = []
+    for name in ("train", "val", "test"):
+        if name not in data:
+            continue
+        splits.append(dict(name=name, img=emb[name][0], txt=emb[name][1], drop_self=(name == "train"),
+                           in_db=data[name].get("in_db"), label_id=data[name].get("label_id")))
+    recs = score_splits(db, splits, k, hparams, discrete)
+    if timers is not None:
+        torch.cuda.synchronize(dev)
+        timers["knn_score_s"] = time.perf_counter() - t0
+    for name in recs:                       # keep the embeddings the scores were computed from
+        recs[name]["emb_img"], recs[name]["emb_txt"] = emb[name]
+    return recs, db

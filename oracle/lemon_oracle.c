@@ -302,3 +302,12 @@ void lo_score(const float *d1, const float *D_n, const float *dists_tr_n, const 
 }
 
 int lo_has_simd(void) { return LO_SIMD; }
+
+#ifdef _OPENMP
+#include <omp.h>
+void lo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int lo_get_threads(void) { return omp_get_max_threads(); }
+#else
+void lo_set_threads(int n) { (void)n; }
+int lo_get_threads(void) { return 1; }
+#endif

@@ -39,6 +39,23 @@ def lib():
     return _lib
 
 
+def usable_cores():
+    """CPU cores this process may actually use: min(affinity mask, cgroup quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def set_threads(n):
+    lib().lo_set_threads(ctypes.c_int(int(n)))
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 

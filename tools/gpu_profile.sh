@@ -1,0 +1,16 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): headline bench, rocprofv3 kernel trace of the same command,
+# and the PMC passes (separate runs, kernel-trace only) the roofline `traffic` figure comes from.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+mkdir -p $OUT
+TAG=${1:-r1}
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py --steps 2 --warmup 1 > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench_$TAG -- python3 $R/bench.py --steps 2 --warmup 1 --no_cpu_baseline > $OUT/prof_bench_$TAG.json 2> $OUT/prof_bench_$TAG.err || exit 2
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_knn_$TAG -- python3 $R/bench.py --workload knn --knn_n 262144 --steps 1 --warmup 0 > $OUT/prof_knn_$TAG.json 2> $OUT/prof_knn_$TAG.err || exit 3
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$TAG -- python3 $R/bench.py --workload knn --knn_n 262144 --steps 1 --warmup 0 > $OUT/pmc_fetch_$TAG.json 2> $OUT/pmc_fetch_$TAG.err || exit 4
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -- python3 $R/bench.py --workload knn --knn_n 262144 --steps 1 --warmup 0 > $OUT/pmc_write_$TAG.json 2> $OUT/pmc_write_$TAG.err || exit 5
+find $OUT -name "*_kernel_trace.csv" -size +20M -delete
+ls -la $OUT/prof_bench_$TAG/*/ | head -20
