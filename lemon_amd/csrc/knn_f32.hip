@@ -42,32 +42,29 @@ __global__ __launch_bounds__(256) void k_permute_rows(const float *__restrict__ 
 }
 
 // ---- wave-level selection ---------------------------------------------------------------
-__device__ __forceinline__ u64 wave_max_u64(u64 v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        u64 o = __shfl_xor(v, off);
-        v = o > v ? o : v;
-    }
-    return v;
-}
+// Rank-select: up to 256 distinct keys (4 per lane, 0 = empty) are parked in a per-wave LDS
+// scratch; every lane then streams all of them back (broadcast reads) and counts, for each of its
+// own keys, how many are larger.  rank < k  <=>  the key is among the k best, and the rank IS its
+// position in the sorted output.  No cross-lane dependency chains (the old k-round butterfly
+// arg-max was latency bound: ~30k cycles per list; this is ~2.3k VALU instructions).
+struct Ranked { int r0, r1, r2, r3; };
 
-// v[0..3]: up to 256 distinct keys spread over the wavefront (0 = empty).  Returns, in lane i,
-// the i-th largest key for i < k (0 if fewer exist).  k <= 64.
-__device__ __forceinline__ u64 wave_select_topk(u64 v0, u64 v1, u64 v2, u64 v3, int k, int lane) {
-    u64 res = 0;
-    for (int r = 0; r < k; ++r) {
-        u64 m01 = v0 > v1 ? v0 : v1;
-        u64 m23 = v2 > v3 ? v2 : v3;
-        u64 m = m01 > m23 ? m01 : m23;
-        u64 w = wave_max_u64(m);
-        if (w == 0) break;           // wave-uniform
-        if (lane == r) res = w;
-        if (v0 == w) v0 = 0;
-        if (v1 == w) v1 = 0;
-        if (v2 == w) v2 = 0;
-        if (v3 == w) v3 = 0;
+__device__ __forceinline__ Ranked wave_rank_keys(u64 v0, u64 v1, u64 v2, u64 v3, int n_bound,
+                                                  u64 *__restrict__ sk, int lane) {
+    sk[lane] = v0; sk[lane + 64] = v1; sk[lane + 128] = v2; sk[lane + 192] = v3;
+    __builtin_amdgcn_wave_barrier();
+    Ranked r = {0, 0, 0, 0};
+    const int n2 = __builtin_amdgcn_readfirstlane((n_bound + 1) & ~1);
+    const ulonglong2 *sk2 = reinterpret_cast<const ulonglong2 *>(sk);
+    for (int j = 0; j < n2 / 2; ++j) {
+        const ulonglong2 kk = sk2[j];
+        r.r0 += (kk.x > v0) + (kk.y > v0);
+        r.r1 += (kk.x > v1) + (kk.y > v1);
+        r.r2 += (kk.x > v2) + (kk.y > v2);
+        r.r3 += (kk.x > v3) + (kk.y > v3);
     }
-    return res;
+    __builtin_amdgcn_wave_barrier();
+    return r;
 }
 
 struct ScanParams {
@@ -89,20 +86,25 @@ __device__ __forceinline__ int swz(int r, int c) { return r * BK + 4 * (c ^ ((r 
 
 // compact one query row's candidate list to its best kk entries (sorted, best first)
 __device__ __forceinline__ void compact_row(u64 *__restrict__ list, int *cnt, float *thr, int row, int kk,
-                                            int lane) {
-    const int n = cnt[row];
-    u64 v0 = (lane < n) ? list[lane] : 0;
-    u64 v1 = (lane + 64 < n) ? list[lane + 64] : 0;
-    u64 v2 = (lane + 128 < n) ? list[lane + 128] : 0;
-    u64 v3 = (lane + 192 < n) ? list[lane + 192] : 0;
-    u64 res = wave_select_topk(v0, v1, v2, v3, kk, lane);
+                                            int lane, u64 *__restrict__ sk) {
+    const int n = __builtin_amdgcn_readfirstlane(cnt[row]);
+    const u64 v0 = (lane < n) ? list[lane] : 0;
+    const u64 v1 = (lane + 64 < n) ? list[lane + 64] : 0;
+    const u64 v2 = (lane + 128 < n) ? list[lane + 128] : 0;
+    const u64 v3 = (lane + 192 < n) ? list[lane + 192] : 0;
+    const Ranked r = wave_rank_keys(v0, v1, v2, v3, n, sk, lane);
     const int kept = n < kk ? n : kk;
-    if (lane < kept) list[lane] = res;
-    const u64 kth = __shfl(res, kk - 1);
-    if (lane == 0) {
-        cnt[row] = kept;
-        thr[row] = (kept == kk) ? lemon_key_score(kth) : -INFINITY;
+    if (v0 && r.r0 < kk) list[r.r0] = v0;
+    if (v1 && r.r1 < kk) list[r.r1] = v1;
+    if (v2 && r.r2 < kk) list[r.r2] = v2;
+    if (v3 && r.r3 < kk) list[r.r3] = v3;
+    if (kept == kk) {   // the key of rank kk-1 is the new admission threshold
+        if (v0 && r.r0 == kk - 1) thr[row] = lemon_key_score(v0);
+        if (v1 && r.r1 == kk - 1) thr[row] = lemon_key_score(v1);
+        if (v2 && r.r2 == kk - 1) thr[row] = lemon_key_score(v2);
+        if (v3 && r.r3 == kk - 1) thr[row] = lemon_key_score(v3);
     }
+    if (lane == 0) cnt[row] = kept;
 }
 
 // global -> register staging of one k-slice: each thread moves 4 16-B chunks per operand.
@@ -163,6 +165,7 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
     __shared__ __attribute__((aligned(16))) float s_thr[BQ];
     __shared__ __attribute__((aligned(16))) float s_qn[BQ];
     __shared__ int s_cnt[BQ];
+    __shared__ __attribute__((aligned(16))) u64 s_keys[NT / 64][256];   // rank-select scratch, one per wave
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -256,8 +259,10 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
             const bool last = (it + 1 == total);
             for (int r = 0; r < 32; ++r) {
                 const int row = 32 * wave + r;
-                if (last || s_cnt[row] > CAP - BX)
-                    compact_row(cand_panel + (int64_t)row * CAP, s_cnt, s_thr, row, p.kk, lane);
+                const int c = s_cnt[row];
+                // also compact as soon as kk candidates exist while no threshold is set yet (warm-up)
+                if (last || c > CAP - BX || (c >= p.kk && s_thr[row] == -INFINITY))
+                    compact_row(cand_panel + (int64_t)row * CAP, s_cnt, s_thr, row, p.kk, lane, s_keys[wave]);
             }
             __syncthreads();
         }
@@ -295,8 +300,10 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
 __global__ __launch_bounds__(256) void k_merge(const u64 *__restrict__ part, int splits, int64_t nq_pad,
                                                int64_t nq, int kk, int metric, float *__restrict__ D,
                                                int64_t *__restrict__ I) {
-    const int lane = threadIdx.x & 63;
-    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ __attribute__((aligned(16))) u64 s_keys[4][256];
+    __shared__ __attribute__((aligned(16))) u64 s_best[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
     if (q >= nq) return;
     u64 best = 0;  // lane i: i-th best so far
     const int total = splits * kk;
@@ -312,7 +319,16 @@ __global__ __launch_bounds__(256) void k_merge(const u64 *__restrict__ part, int
             }
             v[t] = key;
         }
-        best = wave_select_topk(best, v[0], v[1], v[2], kk, lane);
+        const Ranked r = wave_rank_keys(best, v[0], v[1], v[2], 256, s_keys[wave], lane);
+        s_best[wave][lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (best && r.r0 < kk) s_best[wave][r.r0] = best;
+        if (v[0] && r.r1 < kk) s_best[wave][r.r1] = v[0];
+        if (v[1] && r.r2 < kk) s_best[wave][r.r2] = v[1];
+        if (v[2] && r.r3 < kk) s_best[wave][r.r3] = v[2];
+        __builtin_amdgcn_wave_barrier();
+        best = s_best[wave][lane];
+        __builtin_amdgcn_wave_barrier();
     }
     if (lane < kk) {
         float dv; int64_t iv;
