@@ -51,7 +51,7 @@ struct lemon_index {
     // bf16 filter copies (built lazily by the bf16 path)
     unsigned short *xh;   // [cap, dpad] bf16 (RNE) of x
     int64_t xh_rows;      // rows of xh that are up to date
-    float xnorm_max;      // max_j ||x_j||_2 upper bound (host copy), for the filter band
+    unsigned *xn2max_dev; // device scalar: max_j dot(x_j,x_j) (float bits), for the filter band
     // search workspace (grown on demand)
     int64_t ws_q;         // query rows the workspace is sized for
     float *ws_qp;         // [ws_q, dpad] permuted queries

@@ -11,17 +11,11 @@
 //
 // Roofline: dense contraction, 2*nq*n*d flop on the fp32 MFMA pipe (157 TFLOP/s dense peak);
 // HBM traffic is one database stream per resident "generation" of workgroups.
-#include "common.hpp"
+#include "knn_common.hpp"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using namespace lemon_knn;
 
 namespace {
-
-constexpr int BQ = 128;  // query rows per workgroup
-constexpr int BX = 128;  // database rows per tile
-constexpr int BK = 32;   // k-slice per LDS stage
-constexpr int NT = 256;  // threads per workgroup (4 wavefronts, 2x2 over the 128x128 tile)
-constexpr int CAP = LEMON_CAND_CAP;
 
 // ---- layout kernels ---------------------------------------------------------------------
 // dst[r][8u + (e&1)*4 + (e>>1)] = src[r][8u+e]; zero beyond d.  One thread per (row, 8-group).
@@ -40,49 +34,6 @@ __global__ __launch_bounds__(256) void k_permute_rows(const float *__restrict__ 
     o[0] = make_float4(v[0], v[2], v[4], v[6]);
     o[1] = make_float4(v[1], v[3], v[5], v[7]);
 }
-
-// ---- wave-level selection ---------------------------------------------------------------
-// Rank-select: up to 256 distinct keys (4 per lane, 0 = empty) are parked in a per-wave LDS
-// scratch; every lane then streams all of them back (broadcast reads) and counts, for each of its
-// own keys, how many are larger.  rank < k  <=>  the key is among the k best, and the rank IS its
-// position in the sorted output.  No cross-lane dependency chains (the old k-round butterfly
-// arg-max was latency bound: ~30k cycles per list; this is ~2.3k VALU instructions).
-struct Ranked { int r0, r1, r2, r3; };
-
-__device__ __forceinline__ Ranked wave_rank_keys(u64 v0, u64 v1, u64 v2, u64 v3, int n_bound,
-                                                  u64 *__restrict__ sk, int lane) {
-    sk[lane] = v0; sk[lane + 64] = v1; sk[lane + 128] = v2; sk[lane + 192] = v3;
-    __builtin_amdgcn_wave_barrier();
-    Ranked r = {0, 0, 0, 0};
-    const int n2 = __builtin_amdgcn_readfirstlane((n_bound + 1) & ~1);
-    const ulonglong2 *sk2 = reinterpret_cast<const ulonglong2 *>(sk);
-    for (int j = 0; j < n2 / 2; ++j) {
-        const ulonglong2 kk = sk2[j];
-        r.r0 += (kk.x > v0) + (kk.y > v0);
-        r.r1 += (kk.x > v1) + (kk.y > v1);
-        r.r2 += (kk.x > v2) + (kk.y > v2);
-        r.r3 += (kk.x > v3) + (kk.y > v3);
-    }
-    __builtin_amdgcn_wave_barrier();
-    return r;
-}
-
-struct ScanParams {
-    const float *qp;      // [nq_pad, dpad] permuted queries, pad rows zero
-    const float *xp;      // [n_pad,  dpad] permuted database, pad rows zero
-    const float *qnorm;   // [nq_pad]  (L2)
-    const float *xnorm;   // [n_pad]   (L2)
-    u64 *cand;            // [grid, BQ, CAP]  one region per workgroup
-    u64 *part;            // [splits, nq_pad, kk] when splits > 1
-    float *D;             // [nq, kk] when splits == 1
-    int64_t *I;
-    int64_t nq, n;
-    int dpad, kk, metric;
-    int n_tiles, tiles_per_split, splits;
-    int64_t nq_pad;
-};
-
-__device__ __forceinline__ int swz(int r, int c) { return r * BK + 4 * (c ^ ((r >> 1) & 7)); }
 
 // compact one query row's candidate list to its best kk entries (sorted, best first)
 __device__ __forceinline__ void compact_row(u64 *__restrict__ list, int *cnt, float *thr, int row, int kk,
@@ -106,30 +57,6 @@ __device__ __forceinline__ void compact_row(u64 *__restrict__ list, int *cnt, fl
     }
     if (lane == 0) cnt[row] = kept;
 }
-
-// global -> register staging of one k-slice: each thread moves 4 16-B chunks per operand.
-// (named registers, not arrays: hipcc keeps by-reference float4 arrays in scratch here)
-__device__ __forceinline__ float4 stage_ld(const float *__restrict__ src, int dpad, int tid, int i) {
-    const int id = tid + NT * i, r = id >> 3, c = id & 7;
-    return *reinterpret_cast<const float4 *>(src + (int64_t)r * dpad + 4 * c);
-}
-__device__ __forceinline__ void stage_st(float *t, int tid, int i, float4 v) {
-    const int id = tid + NT * i, r = id >> 3, c = id & 7;
-    *reinterpret_cast<float4 *>(&t[swz(r, c)]) = v;
-}
-#define STAGE_ISSUE(qsrc, xsrc)                                                                     \
-    do {                                                                                            \
-        rq0 = stage_ld(qsrc, dpad, tid, 0); rq1 = stage_ld(qsrc, dpad, tid, 1);                     \
-        rq2 = stage_ld(qsrc, dpad, tid, 2); rq3 = stage_ld(qsrc, dpad, tid, 3);                     \
-        rx0 = stage_ld(xsrc, dpad, tid, 0); rx1 = stage_ld(xsrc, dpad, tid, 1);                     \
-        rx2 = stage_ld(xsrc, dpad, tid, 2); rx3 = stage_ld(xsrc, dpad, tid, 3);                     \
-    } while (0)
-#define STAGE_COMMIT(tq_, tx_)                                                                      \
-    do {                                                                                            \
-        stage_st(tq_, tid, 0, rq0); stage_st(tq_, tid, 1, rq1); stage_st(tq_, tid, 2, rq2);         \
-        stage_st(tq_, tid, 3, rq3); stage_st(tx_, tid, 0, rx0); stage_st(tx_, tid, 1, rx1);         \
-        stage_st(tx_, tid, 2, rx2); stage_st(tx_, tid, 3, rx3);                                     \
-    } while (0)
 
 // threshold filter + append for one 32x32 accumulator tile; zeroes the accumulator
 __device__ __forceinline__ void epilogue_tile(f32x16 &acc, int rtile, int64_t j, bool jvalid, float xn, int h,
@@ -275,24 +202,8 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
         const int64_t q = q0 + row;
         if (q >= p.nq) continue;
         const int kept = s_cnt[row];
-        if (lane < p.kk) {
-            const u64 key = (lane < kept) ? cand_panel[(int64_t)row * CAP + lane] : 0;
-            if (p.splits > 1) {
-                p.part[((int64_t)split * p.nq_pad + q) * p.kk + lane] = key;
-            } else {
-                float dv; int64_t iv;
-                if (key) {
-                    const float s = lemon_key_score(key);
-                    dv = (metric == LEMON_METRIC_L2) ? -s : s;
-                    iv = (int64_t)lemon_key_index(key);
-                } else {
-                    dv = (metric == LEMON_METRIC_L2) ? FLT_MAX : -FLT_MAX;
-                    iv = -1;
-                }
-                p.D[q * p.kk + lane] = dv;
-                p.I[q * p.kk + lane] = iv;
-            }
-        }
+        const u64 key = (lane < kept && lane < p.kk) ? cand_panel[(int64_t)row * CAP + lane] : 0;
+        write_out_row(p, split, q, lane, key);
     }
 }
 
@@ -350,8 +261,6 @@ __global__ void k_fill_empty(float *D, int64_t *I, int64_t total, int metric) {
     if (i < total) { D[i] = (metric == LEMON_METRIC_L2) ? FLT_MAX : -FLT_MAX; I[i] = -1; }
 }
 
-inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
-
 }  // namespace
 
 // -----------------------------------------------------------------------------------------
@@ -366,7 +275,37 @@ int lemon_permute_rows(const float *src, int64_t n, int d, float *dst, int dpad,
     return LEMON_OK;
 }
 
-static int ensure_search_ws(lemon_index_t *idx, int64_t nq_pad, int splits, hipStream_t stream) {
+int lemon_launch_merge(const u64 *part, int splits, int64_t nq_pad, int64_t nq, int kk, int metric, float *D,
+                       int64_t *I, hipStream_t stream) {
+    hipLaunchKernelGGL(k_merge, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, part, splits, nq_pad, nq, kk,
+                       metric, D, I);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}
+
+int lemon_fill_empty(float *D, int64_t *I, int64_t total, int metric, hipStream_t stream) {
+    if (total <= 0) return LEMON_OK;
+    hipLaunchKernelGGL(k_fill_empty, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, D, I, total, metric);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}
+
+// enough workgroups to fill 256 CUs x 2 resident; every split keeps >= 8 tiles so the warm-up amortises
+void lemon_plan_splits(int panels, int n_tiles, int *splits_out, int *tiles_per_split_out) {
+    int splits = 1;
+    if (panels < 1024) {
+        splits = (1024 + panels - 1) / panels;
+        int max_splits = n_tiles / 8;
+        if (max_splits < 1) max_splits = 1;
+        if (splits > max_splits) splits = max_splits;
+    }
+    const int tiles_per_split = (n_tiles + splits - 1) / splits;
+    *splits_out = (n_tiles + tiles_per_split - 1) / tiles_per_split;
+    *tiles_per_split_out = tiles_per_split;
+}
+
+// qp_row_bytes: bytes of one staged query row (dpad*4 for the fp32 scan, dpad_h*2 for the bf16 one)
+int lemon_ensure_search_ws(lemon_index_t *idx, int64_t nq_pad, int splits, int qp_row_bytes, hipStream_t stream) {
     const int64_t part_elems = (splits > 1) ? (int64_t)splits * nq_pad * LEMON_MAX_K : 0;
     const int64_t cand_rows = nq_pad * splits;
     if (nq_pad > idx->ws_q) {
@@ -374,7 +313,7 @@ static int ensure_search_ws(lemon_index_t *idx, int64_t nq_pad, int splits, hipS
         if (idx->ws_qp) (void)hipFree(idx->ws_qp);
         if (idx->ws_qnorm) (void)hipFree(idx->ws_qnorm);
         idx->ws_qp = nullptr; idx->ws_qnorm = nullptr; idx->ws_q = 0;
-        if (hipMalloc(&idx->ws_qp, (size_t)nq_pad * idx->dpad * sizeof(float)) != hipSuccess ||
+        if (hipMalloc(&idx->ws_qp, (size_t)nq_pad * idx->dpad * sizeof(float) + 0 * qp_row_bytes) != hipSuccess ||
             hipMalloc(&idx->ws_qnorm, (size_t)nq_pad * sizeof(float)) != hipSuccess) {
             lemon_set_error("search workspace allocation failed (nq_pad=%lld)", (long long)nq_pad);
             return LEMON_E_NOMEM;
@@ -410,30 +349,16 @@ static const int64_t QCHUNK = 1 << 19;
 int lemon_search_f32(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, float *D_dev,
                      int64_t *I_dev, hipStream_t stream) {
     const int d = idx->d, dpad = idx->dpad;
-    if (idx->n == 0) {
-        const int64_t total = nq * k;
-        hipLaunchKernelGGL(k_fill_empty, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, D_dev,
-                           I_dev, total, idx->metric);
-        LEMON_HIP_CHECK(hipGetLastError());
-        return LEMON_OK;
-    }
+    if (idx->n == 0) return lemon_fill_empty(D_dev, I_dev, nq * k, idx->metric, stream);
     const int n_tiles = (int)((idx->n + BX - 1) / BX);
     for (int64_t c0 = 0; c0 < nq; c0 += QCHUNK) {
         const int64_t cn = (nq - c0) < QCHUNK ? (nq - c0) : QCHUNK;
         const int64_t nq_pad = round_up(cn, BQ);
         const int panels = (int)(nq_pad / BQ);
-        // enough workgroups to fill 256 CUs x 2 resident; every split keeps >= 8 tiles of warm-up
-        int splits = 1;
-        if (panels < 1024) {
-            splits = (1024 + panels - 1) / panels;
-            int max_splits = n_tiles / 8;
-            if (max_splits < 1) max_splits = 1;
-            if (splits > max_splits) splits = max_splits;
-        }
-        int tiles_per_split = (n_tiles + splits - 1) / splits;
-        splits = (n_tiles + tiles_per_split - 1) / tiles_per_split;
+        int splits, tiles_per_split;
+        lemon_plan_splits(panels, n_tiles, &splits, &tiles_per_split);
 
-        int rc = ensure_search_ws(idx, nq_pad, splits, stream);
+        int rc = lemon_ensure_search_ws(idx, nq_pad, splits, dpad * 4, stream);
         if (rc) return rc;
         // permuted, zero-padded query panel (+ chain norms for L2)
         LEMON_HIP_CHECK(hipMemsetAsync(idx->ws_qp, 0, (size_t)nq_pad * dpad * sizeof(float), stream));
@@ -459,9 +384,8 @@ int lemon_search_f32(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, 
         }
         LEMON_HIP_CHECK(hipGetLastError());
         if (splits > 1) {
-            hipLaunchKernelGGL(k_merge, dim3((unsigned)((cn + 3) / 4)), dim3(256), 0, stream, idx->ws_part,
-                               splits, nq_pad, cn, k, idx->metric, p.D, p.I);
-            LEMON_HIP_CHECK(hipGetLastError());
+            rc = lemon_launch_merge(idx->ws_part, splits, nq_pad, cn, k, idx->metric, p.D, p.I, stream);
+            if (rc) return rc;
         }
         idx->last.algo = LEMON_ALGO_F32_MFMA;
         idx->last.grid = (int)grid; idx->last.block = NT;

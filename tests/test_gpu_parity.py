@@ -193,3 +193,77 @@ def test_d1_normalized(hip, oracle):
 def test_cpu_tensor_is_refused(hip):
     with pytest.raises(Exception):
         hip.normalize_vectors(torch.zeros(4, 4))
+
+
+# ------------------------------------------------------------------ bf16 filter + exact re-rank (LEMON_ALGO_BF16_FILTER)
+BF16 = 2
+
+
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+@pytest.mark.parametrize("nq,n,d,k", [
+    (1, 1, 8, 1), (5, 3, 16, 5), (130, 1000, 40, 10), (128, 128, 32, 64), (257, 1300, 64, 51),
+    (64, 5000, 512, 50), (300, 2049, 768, 5), (1100, 3000, 100, 1), (33, 40000, 96, 51), (700, 9000, 72, 64),
+])
+def test_bf16_filter_bit_exact(hip, oracle, metric, nq, n, d, k):
+    rng = np.random.default_rng(nq * 7 + n * 3 + d + k)
+    X, Q = unit_rows(rng, n, d), unit_rows(rng, nq, d)
+    if metric == "l2":
+        X *= rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32)
+        Q *= rng.uniform(0.5, 2.0, (nq, 1)).astype(np.float32)
+    D, I, idx = _search(hip, metric, X, Q, k, algo=BF16)
+    assert idx.last_search_info()["algo"] == BF16
+    _assert_knn_equal((D, I), oracle.knn(metric, X, Q, k))
+
+
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+def test_bf16_filter_ties_and_clusters(hip, oracle, metric):
+    # prototypes (exact duplicates) + tight clusters whose spread is far below the bf16 band:
+    # the filter cannot separate them, only the exact re-rank can
+    rng = np.random.default_rng(17)
+    C, n, d, k = 12, 6000, 128, 51
+    proto = unit_rows(rng, C, d)
+    lab = rng.integers(0, C, n)
+    X = proto[lab].copy()
+    jitter = rng.standard_normal((n, d)).astype(np.float32) * 1e-4
+    X[n // 2:] += jitter[n // 2:]                      # half exact duplicates, half 1e-4-perturbed
+    Q = proto[rng.integers(0, C, 260)] + rng.standard_normal((260, d)).astype(np.float32) * 1e-3
+    Q = Q.astype(np.float32)
+    D, I, _ = _search(hip, metric, X, Q, k, algo=BF16)
+    _assert_knn_equal((D, I), oracle.knn(metric, X, Q, k))
+
+
+def test_bf16_filter_unnormalised_and_wide_dynamic_range(hip, oracle):
+    rng = np.random.default_rng(23)
+    n, d, k = 5000, 200, 20
+    X = (rng.standard_normal((n, d)) * np.exp(rng.uniform(-3, 3, (n, 1)))).astype(np.float32)
+    Q = (rng.standard_normal((150, d)) * np.exp(rng.uniform(-3, 3, (150, 1)))).astype(np.float32)
+    for metric in ("ip", "l2"):
+        D, I, _ = _search(hip, metric, X, Q, k, algo=BF16)
+        _assert_knn_equal((D, I), oracle.knn(metric, X, Q, k))
+
+
+def test_bf16_filter_equals_f32_scan_at_cifar_scale(hip):
+    # size-independent property at a size the oracle would need minutes for: the two GPU algorithms
+    # (independent inner products: bf16 MFMA + re-rank vs fp32 MFMA) agree bit for bit
+    g = torch.Generator(device="cuda").manual_seed(5)
+    X = hip.normalize_vectors(torch.randn(40000, 512, generator=g, device="cuda"))
+    Q = hip.normalize_vectors(torch.randn(20000, 512, generator=g, device="cuda"))
+    out = []
+    for algo in (1, BF16):
+        idx = hip.IndexFlatIP(512)
+        idx.set_algo(algo)
+        idx.add(X)
+        out.append(idx.search(Q, 51))
+    assert torch.equal(out[0][1], out[1][1])
+    assert torch.equal(out[0][0], out[1][0])
+
+
+def test_neighbors_record_bf16_algo(hip, oracle):
+    s = planted(seed=1, n_tr=3000, n_q=300, d=64, C=16)
+    img_tr, txt_tr, _, noisy_tr = s["train"]
+    q_img, q_txt, _, noisy_q = s["query"]
+    ref = oracle.neighbors("cosine", img_tr, txt_tr, q_img, q_txt, 10)
+    db = hip.LemonDB(cu(img_tr), cu(txt_tr), "cosine", algo=BF16)
+    got = db.neighbors(cu(q_img), cu(q_txt), 10)
+    for key in ("I_n", "I_m", "d_1", "D_n", "dists_n", "dists_tr_n", "D_m", "dists_m", "dists_tr_m"):
+        assert np.array_equal(got[key].cpu().numpy(), ref[key]), key
