@@ -1,0 +1,60 @@
+"""GPU: end-to-end `python -m lemon_amd.run_lemon` on synthetic data (no files needed): outputs,
+record schema (run_lemon.py:291-307) and the DB-subset / self-exclusion path."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+COLS = ["sset", "idx", "actual_label", "actual_label_text", "noisy_label", "noisy_label_text", "is_mislabel",
+        "is_correct_label", "d_1", "dists_n", "D_n", "dists_tr_n", "dists_m", "D_m", "dists_tr_m"]
+
+
+def _run(tmp_path, *extra):
+    from lemon_amd.run_lemon import main
+    out = str(tmp_path / "run")
+    rc = main(["--output_dir", out, "--dataset", "cifar10", "--noise_type", "asymmetric", "--data_root", "synthetic:1500",
+               "--clip_path", "random:tiny", "--hparam_grid", "small", "--debug", *extra])
+    assert rc == 0
+    return out
+
+
+def test_cli_full_run_outputs_and_schema(hip, tmp_path):
+    out = _run(tmp_path, "--knn_k", "5")
+    for f in ("args.json", "res.pkl", "know_val_labels_scores.csv", "done"):
+        assert os.path.exists(os.path.join(out, f)), f
+    res = pickle.load(open(os.path.join(out, "res.pkl"), "rb"))
+    df = res["df"]
+    assert list(df.columns[:len(COLS)]) == COLS
+    assert set(df.sset.unique()) == {"val", "test"} and len(df) == 300          # --debug skips train
+    assert df["D_n"].iloc[0].shape == (5,) and df["D_n"].iloc[0].dtype == np.float32
+    assert (df["D_n"].iloc[0] <= 0).all()                                          # cosine: D_n = -IP (A14)
+    agg = res["agg_results"]["know_val_labels"]
+    assert {"beta", "gamma", "thres", "tau_1_n", "tau_2_n", "tau_1_m", "tau_2_m", "selected_val", "val", "test"} <= set(agg)
+    assert 0.0 <= agg["val"]["AUROC"] <= 1.0 and "F1_optimal" in agg["test"]
+    assert 0.3 < df.is_mislabel.mean() < 0.5
+
+
+def test_cli_train_split_db_subset_and_skip_hparam(hip, tmp_path):
+    from lemon_amd.run_lemon import main
+    out = str(tmp_path / "run2")
+    rc = main(["--output_dir", out, "--dataset", "cifar100", "--noise_type", "symmetric", "--data_root", "synthetic:1000",
+               "--clip_path", "random:tiny", "--knn_k", "3", "--compr_dataset_size_limit", "300", "--skip_hparam_optim",
+               "--dist_type", "euclidean", "--use_discrete_for_text"])
+    assert rc == 0
+    res = pickle.load(open(os.path.join(out, "res.pkl"), "rb"))
+    df = res["df"]
+    assert "agg_results" not in res and os.path.exists(os.path.join(out, "need_hparam_optim"))
+    assert (df.sset == "train").sum() == 800 and (df.sset == "val").sum() == 100
+    tr = df[df.sset == "train"]
+    assert set(np.unique(np.concatenate(list(tr["dists_n"])))) <= {0.0, 1.0}       # discrete text metric
+    assert os.path.exists(os.path.join(out, "out.txt"))                             # Tee (no --debug)
+
+
+def test_cli_cat_noise_on_cifar_raises(hip, tmp_path):
+    from lemon_amd.run_lemon import main
+    with pytest.raises(NotImplementedError):
+        main(["--output_dir", str(tmp_path / "x"), "--dataset", "cifar100", "--noise_type", "cat",
+              "--data_root", "synthetic:200", "--clip_path", "random:tiny", "--debug"])
