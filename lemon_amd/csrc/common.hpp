@@ -54,6 +54,8 @@ struct lemon_index {
     unsigned *xn2max_dev; // device scalar: max_j dot(x_j,x_j) (float bits), for the filter band
     // search workspace (grown on demand)
     int64_t ws_q;         // query rows the workspace is sized for
+    int64_t ws_qp_row_bytes;  // bytes per staged query row the workspace is sized for
+    int dpad_h;           // column pitch of xh (0 until the bf16 copy exists)
     float *ws_qp;         // [ws_q, dpad] permuted queries
     float *ws_qnorm;      // [ws_q]
     u64 *ws_cand;         // [ws_cand_rows, CAND_CAP]  (one 128-row region per scan workgroup)

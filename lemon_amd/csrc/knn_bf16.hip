@@ -97,7 +97,8 @@ __device__ __forceinline__ float exact_score(const float *__restrict__ q, const 
 // re-score the pending rows of one query exactly, merge with its exact top-k, tighten the thresholds
 __device__ __forceinline__ void compact_row_h(const ScanParamsH &p, u64 *__restrict__ list, int row, int64_t q,
                                               int lane, int *s_cnt, int *s_kept, float *s_thr_lo, const float *s_eps,
-                                              const float *s_qn, u64 *__restrict__ sk, u64 *__restrict__ sb) {
+                                              const float *s_qn, u64 *__restrict__ sk, u64 *__restrict__ sb,
+                                              bool bias_qn = false) {
     const int n_p = __builtin_amdgcn_readfirstlane(s_cnt[row]);
     const int kept = __builtin_amdgcn_readfirstlane(s_kept[row]);
     const int kk = p.b.kk;
@@ -135,7 +136,9 @@ __device__ __forceinline__ void compact_row_h(const ScanParamsH &p, u64 *__restr
             const float T = lemon_key_score(kth);
             // admit s~ > T - eps; round the bound DOWN (a few ulps of slack never hurts correctness)
             const float lo = T - s_eps[row];
-            s_thr_lo[row] = lo - fabsf(lo) * 2.4e-7f - 1e-37f;
+            // bias_qn (Q-stationary L2 filter): the filter compares 2 s~ - |x|^2, i.e. -D + |q|^2
+            const float b = bias_qn ? s_qn[row] : 0.0f;
+            s_thr_lo[row] = (lo + b) - (fabsf(lo) + b) * 2.4e-7f - 1e-37f;
         }
     }
 }
@@ -302,10 +305,230 @@ __global__ __launch_bounds__(NT, 2) void k_scan_bf16(ScanParamsH p) {
     }
 }
 
+
+// ======================================================================================
+// Q-stationary variant (d <= 1024): the query fragments never leave the registers.
+//
+// The streaming kernel above re-reads its 128-query panel from L2/MALL for every database tile
+// (393 KB per workgroup at d=768: 64 panels per XCD thrash the 4 MB L2, PMC FETCH_SIZE ~ every staged
+// byte).  Here a wavefront owns 32 queries and keeps their bf16 rows in VGPRs for the whole scan
+// (16*KT x 4 VGPRs = 192 at d=768; one wave per SIMD, 512-register budget), as the B operand of
+// v_mfma_f32_32x32x16_bf16; only X tiles (128 rows x 64 k = 16 KB per stage) stream through LDS as
+// the A operand, shared by the 4 waves.  Global traffic per flop halves, the L2 only sees the X
+// stream that every workgroup reads in the same order, and the accumulator layout puts ONE query on
+// each lane (col = lane&31), so the admission threshold is a per-lane scalar: a 16-value v_max3
+// tree + one compare per accumulator tile instead of a compare+branch per element.
+// ======================================================================================
+// one 32x32 accumulator tile: a[e] = s~(db row jb + (e&3) + 8(e>>2), this lane's query)
+__device__ __forceinline__ void qs_filter_tile(f32x16 a, float th, int64_t jb, bool l2,
+                                               const float *__restrict__ xnorm, int64_t n, int *cnt,
+                                               u32 *__restrict__ pend) {
+    if (l2) {   // monotone proxy of -D: 2 s~ - |x|^2 (the query norm is folded into th)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 xn4 = *reinterpret_cast<const float4 *>(&xnorm[jb + 8 * g]);
+            a[4 * g + 0] = __builtin_fmaf(2.0f, a[4 * g + 0], -xn4.x);
+            a[4 * g + 1] = __builtin_fmaf(2.0f, a[4 * g + 1], -xn4.y);
+            a[4 * g + 2] = __builtin_fmaf(2.0f, a[4 * g + 2], -xn4.z);
+            a[4 * g + 3] = __builtin_fmaf(2.0f, a[4 * g + 3], -xn4.w);
+        }
+    }
+    const float m0 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+    const float m1 = fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7]));
+    const float m2 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11]));
+    const float m3 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
+    const float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    if (m > th) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t j = jb + (e & 3) + 8 * (e >> 2);
+            if (a[e] > th && j < n) {
+                const int slot = atomicAdd(cnt, 1);
+                pend[slot] = (u32)j;
+            }
+        }
+    }
+}
+
+// LDS-DMA of one 16 KB X stage (128 rows x 128 B): each wave moves its 32 rows with four 1-KiB
+// global_load_lds_dwordx4.  The LDS image is lane-linear (M0 base + 16*lane), so the bank swizzle
+// of swz() is applied to the per-lane SOURCE chunk instead (guide rule 21).
+__device__ __forceinline__ void qs_dma_stage(const float *__restrict__ src, int dpad, float *lds_stage, int wave,
+                                             int lane) {
+    const int rl = lane >> 3, c = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 32 * wave + 8 * i + rl;
+        const float *g = src + (int64_t)r * dpad + 4 * (c ^ ((r >> 1) & 7));
+        float *l = lds_stage + (32 * wave + 8 * i) * BK;      // wave-uniform
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                         (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+    }
+}
+
+// MFMA with the stationary operand (B = query fragment) and the accumulator in the ACCUMULATOR half
+// of the unified register file: at d=768 the query fragments alone are 192 registers, which hipcc
+// would otherwise keep in (and exhaust) the 256 architectural VGPRs, serialising every LDS read
+// behind its MFMA.  "a" constraints pin both to AGPRs (64 acc + 192 query = all 256); the A
+// fragments, addresses and the epilogue live in VGPRs.  First step of a tile uses C = 0.
+__device__ __forceinline__ void mfma_qs_init(f32x16 &acc, bf16x8 a, const bf16x8 &bq) {
+    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "a"(bq));
+}
+__device__ __forceinline__ void mfma_qs(f32x16 &acc, bf16x8 a, const bf16x8 &bq) {
+    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(bq));
+}
+
+template <int KT>
+__global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
+    static_assert(KT % 4 == 0, "stage ring of 4 needs KT % 4 == 0");
+    constexpr int KS = 4 * KT;                 // 16-wide k steps
+    constexpr int NB = 4;                      // LDS stage ring; 3 stages of DMA in flight
+    // ONE shared array (a second __shared__ object next to LDS-DMA staging makes hipcc drain vmcnt
+    // before every k-step's first ds_read: guide 5, trap (a))
+    __shared__ __attribute__((aligned(16))) float smem[NB * BX * BK + 5 * BQ + (NT / 64) * (512 + 128)];
+    float *s_x = smem;                                   // [NB][128*32]
+    float *s_thr_lo = smem + NB * BX * BK;               // [128]
+    float *s_qn = s_thr_lo + BQ;
+    float *s_eps = s_qn + BQ;
+    int *s_cnt = reinterpret_cast<int *>(s_eps + BQ);
+    int *s_kept = s_cnt + BQ;
+    u64 *s_keys = reinterpret_cast<u64 *>(s_kept + BQ);  // [4][256]
+    u64 *s_best = s_keys + (NT / 64) * 256;              // [4][64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const int panel = blockIdx.x / p.b.splits;
+    const int split = blockIdx.x % p.b.splits;
+    const int64_t q0 = (int64_t)panel * BQ;
+    const int t_begin = split * p.b.tiles_per_split;
+    int t_end = t_begin + p.b.tiles_per_split;
+    if (t_end > p.b.n_tiles) t_end = p.b.n_tiles;
+    const int ntile = t_end - t_begin;
+    const int dpad = p.dpad_h / 2;             // row pitch in 4-byte words
+    const bool l2 = p.b.metric == LEMON_METRIC_L2;
+
+    if (tid < BQ) {
+        const bool valid = q0 + tid < p.b.nq;
+        const float qn = p.b.qnorm[q0 + tid];
+        const float xn2 = __uint_as_float(*p.xn2max);
+        float eps = p.c_rel * sqrtf(qn) * sqrtf(xn2) * 1.002f + 1e-30f;
+        if (l2) eps = 2.0f * eps + 4.8e-7f * (qn + xn2);
+        s_eps[tid] = eps;
+        s_qn[tid] = qn;
+        s_thr_lo[tid] = valid ? -INFINITY : INFINITY;
+        s_cnt[tid] = 0;
+        s_kept[tid] = 0;
+    }
+
+    // ---- stationary operand: this lane's query row, all k ----
+    const int qrow_l = 32 * wave + l31;
+    bf16x8 qf[KS];
+    {
+        const __bf16 *qsrc = p.qh + (q0 + qrow_l) * (int64_t)p.dpad_h + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const bf16x8 *>(qsrc + 16 * s);
+    }
+
+    f32x16 acc0, acc1, acc2, acc3;
+
+    const float *xbase = reinterpret_cast<const float *>(p.xh + (int64_t)t_begin * BX * p.dpad_h);
+    const int total = ntile * KT;              // >= 4
+    // stage s -> ring slot s & 3.  Prologue: stages 0,1,2 in flight, wait for stage 0.
+    qs_dma_stage(xbase, dpad, s_x, wave, lane);
+    qs_dma_stage(xbase + BK, dpad, s_x + BX * BK, wave, lane);
+    qs_dma_stage(xbase + 2 * BK, dpad, s_x + 2 * BX * BK, wave, lane);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    u64 *cand_panel = p.b.cand + (int64_t)blockIdx.x * BQ * CAP;
+    u32 *my_pend = reinterpret_cast<u32 *>(cand_panel + (int64_t)qrow_l * CAP + LEMON_MAX_K);
+
+    for (int jl = 0; jl < ntile; ++jl) {
+        const float *xt = xbase + (int64_t)jl * BX * dpad;
+#pragma clang loop unroll(full)
+        for (int kt = 0; kt < KT; ++kt) {
+            const int t = jl * KT + kt;
+            const bool more = t + 3 < total;
+            if (more) {   // stage t+3 into the slot stage t-1 was read from (everyone passed last barrier)
+                const float *src = (kt + 3 < KT) ? xt + (kt + 3) * BK
+                                                 : xt + (int64_t)BX * dpad + (kt + 3 - KT) * BK;
+                qs_dma_stage(src, dpad, s_x + ((kt + 3) & 3) * BX * BK, wave, lane);
+            }
+            const float *tx = s_x + (kt & 3) * BX * BK;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bf16x8 a0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(l31, 2 * u + h)]));
+                const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(32 + l31, 2 * u + h)]));
+                const bf16x8 a2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(64 + l31, 2 * u + h)]));
+                const bf16x8 a3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(96 + l31, 2 * u + h)]));
+                if (kt == 0 && u == 0) {
+                    mfma_qs_init(acc0, a0, qf[0]); mfma_qs_init(acc1, a1, qf[0]);
+                    mfma_qs_init(acc2, a2, qf[0]); mfma_qs_init(acc3, a3, qf[0]);
+                } else {
+                    mfma_qs(acc0, a0, qf[4 * kt + u]); mfma_qs(acc1, a1, qf[4 * kt + u]);
+                    mfma_qs(acc2, a2, qf[4 * kt + u]); mfma_qs(acc3, a3, qf[4 * kt + u]);
+                }
+            }
+            if (kt == KT - 1) {
+                // MFMA results are read by VALU next: hipcc pads nothing around asm, so wait out the
+                // 16-pass MFMA latency here (once per tile)
+                asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc0), "+a"(acc1), "+a"(acc2), "+a"(acc3));
+                // ---- epilogue: acc[ni][e] = s~(db row 32ni + (e&3) + 8(e>>2) + 4h, query lane&31) ----
+                const float th = s_thr_lo[qrow_l];
+                const int64_t jb = (int64_t)(t_begin + jl) * BX + 4 * h;
+                qs_filter_tile(acc0, th, jb, l2, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_pend);
+                qs_filter_tile(acc1, th, jb + 32, l2, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_pend);
+                qs_filter_tile(acc2, th, jb + 64, l2, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_pend);
+                qs_filter_tile(acc3, th, jb + 96, l2, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_pend);
+            }
+            // stage t+1 must have landed (all waves' parts) before anyone reads it: leave only the two
+            // youngest stages (8 DMA instructions) in flight, then rendezvous
+            if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS reads/atomics retired
+            __builtin_amdgcn_s_barrier();
+            if (kt == KT - 1) {
+                const bool last = (jl + 1 == ntile);
+                for (int r = 0; r < 32; ++r) {
+                    const int row = 32 * wave + r;
+                    const int c = s_cnt[row];
+                    const bool warm = (s_thr_lo[row] == -INFINITY) && (c + s_kept[row] >= p.b.kk);
+                    if (c > 0 && (last || c > PEND_CAP - BX || warm))
+                        compact_row_h(p, cand_panel + (int64_t)row * CAP, row, q0 + row, lane, s_cnt, s_kept, s_thr_lo,
+                                      s_eps, s_qn, s_keys + wave * 256, s_best + wave * 64, l2);
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    for (int r = 0; r < 32; ++r) {
+        const int row = 32 * wave + r;
+        const int64_t q = q0 + row;
+        if (q >= p.b.nq) continue;
+        const int kept = s_kept[row];
+        const u64 key = (lane < kept && lane < p.b.kk) ? cand_panel[(int64_t)row * CAP + lane] : 0;
+        write_out_row(p.b, split, q, lane, key);
+    }
+}
+
 }  // namespace
 
+// column pitch of the bf16 copies: the Q-stationary kernel is instantiated for 256/512/768
+// (at 1024 the stationary operand alone would need all 256 architectural VGPRs)
+static int bf16_pitch(int d) {
+    if (d <= 256) return 256;
+    if (d <= 512) return 512;
+    if (d <= 768) return 768;
+    return (int)round_up(d, BKH);
+}
+
 static int ensure_bf16_copy(lemon_index_t *idx, hipStream_t stream) {
-    const int dpad_h = (int)round_up(idx->d, BKH);
+    const int dpad_h = bf16_pitch(idx->d);
+    idx->dpad_h = dpad_h;
     if (!idx->xh) {
         // cap rows + one extra tile of zero rows so the last tile never reads past the allocation
         LEMON_HIP_CHECK(hipStreamSynchronize(stream));
@@ -340,7 +563,7 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
     if (idx->n == 0) return lemon_fill_empty(D_dev, I_dev, nq * k, idx->metric, stream);
     int rc = ensure_bf16_copy(idx, stream);
     if (rc) return rc;
-    const int dpad_h = (int)round_up(d, BKH);
+    const int dpad_h = idx->dpad_h;
     const int n_tiles = (int)((idx->n + BX - 1) / BX);
     for (int64_t c0 = 0; c0 < nq; c0 += QCHUNK_H) {
         const int64_t cn = (nq - c0) < QCHUNK_H ? (nq - c0) : QCHUNK_H;
@@ -378,7 +601,12 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
             const double flops = 2.0 * (double)cn * (double)idx->n * (double)d;
             const double bytes = 2.0 * d * ((double)cn + (double)panels * (double)idx->n) + 12.0 * k * (double)cn;
             LemonProfScope prof(idx, stream, flops, bytes);
-            hipLaunchKernelGGL(k_scan_bf16, dim3(grid), dim3(NT), 0, stream, p);
+            switch (dpad_h <= 768 ? dpad_h / BKH : 0) {
+                case 4:  hipLaunchKernelGGL(k_scan_bf16_qs<4>, dim3(grid), dim3(NT), 0, stream, p); break;
+                case 8:  hipLaunchKernelGGL(k_scan_bf16_qs<8>, dim3(grid), dim3(NT), 0, stream, p); break;
+                case 12: hipLaunchKernelGGL(k_scan_bf16_qs<12>, dim3(grid), dim3(NT), 0, stream, p); break;
+                default: hipLaunchKernelGGL(k_scan_bf16, dim3(grid), dim3(NT), 0, stream, p); break;
+            }
         }
         LEMON_HIP_CHECK(hipGetLastError());
         if (splits > 1) {

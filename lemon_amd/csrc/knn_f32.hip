@@ -308,17 +308,20 @@ void lemon_plan_splits(int panels, int n_tiles, int *splits_out, int *tiles_per_
 int lemon_ensure_search_ws(lemon_index_t *idx, int64_t nq_pad, int splits, int qp_row_bytes, hipStream_t stream) {
     const int64_t part_elems = (splits > 1) ? (int64_t)splits * nq_pad * LEMON_MAX_K : 0;
     const int64_t cand_rows = nq_pad * splits;
-    if (nq_pad > idx->ws_q) {
+    int64_t row_bytes = (int64_t)idx->dpad * 4 > qp_row_bytes ? (int64_t)idx->dpad * 4 : qp_row_bytes;
+    if (row_bytes < idx->ws_qp_row_bytes) row_bytes = idx->ws_qp_row_bytes;
+    if (nq_pad > idx->ws_q || row_bytes > idx->ws_qp_row_bytes) {
+        const int64_t rows = nq_pad > idx->ws_q ? nq_pad : idx->ws_q;
         LEMON_HIP_CHECK(hipStreamSynchronize(stream));
         if (idx->ws_qp) (void)hipFree(idx->ws_qp);
         if (idx->ws_qnorm) (void)hipFree(idx->ws_qnorm);
-        idx->ws_qp = nullptr; idx->ws_qnorm = nullptr; idx->ws_q = 0;
-        if (hipMalloc(&idx->ws_qp, (size_t)nq_pad * idx->dpad * sizeof(float) + 0 * qp_row_bytes) != hipSuccess ||
-            hipMalloc(&idx->ws_qnorm, (size_t)nq_pad * sizeof(float)) != hipSuccess) {
+        idx->ws_qp = nullptr; idx->ws_qnorm = nullptr; idx->ws_q = 0; idx->ws_qp_row_bytes = 0;
+        if (hipMalloc(&idx->ws_qp, (size_t)rows * row_bytes) != hipSuccess ||
+            hipMalloc(&idx->ws_qnorm, (size_t)rows * sizeof(float)) != hipSuccess) {
             lemon_set_error("search workspace allocation failed (nq_pad=%lld)", (long long)nq_pad);
             return LEMON_E_NOMEM;
         }
-        idx->ws_q = nq_pad;
+        idx->ws_q = rows; idx->ws_qp_row_bytes = row_bytes;
     }
     if (cand_rows > idx->ws_cand_rows) {
         LEMON_HIP_CHECK(hipStreamSynchronize(stream));
