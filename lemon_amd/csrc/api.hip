@@ -50,7 +50,7 @@ extern "C" int lemon_index_create(int metric, int d, lemon_index_t **out) {
 
 extern "C" int lemon_index_free(lemon_index_t *idx) {
     if (!idx) return LEMON_OK;
-    void *ptrs[] = {idx->x, idx->xp, idx->xnorm, idx->xh, idx->xn2max_dev, idx->ws_qp, idx->ws_qnorm,
+    void *ptrs[] = {idx->x, idx->xp, idx->xnorm, idx->xh, idx->xh_stats, idx->xn2max_dev, idx->ws_qp, idx->ws_qnorm,
                     idx->ws_cand, idx->ws_part, idx->ws_D, idx->ws_I};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -144,6 +144,7 @@ extern "C" int lemon_index_add(lemon_index_t *idx, const float *x_dev, int64_t n
         if (idx->xp) (void)hipFree(idx->xp);
         if (idx->xnorm) (void)hipFree(idx->xnorm);
         if (idx->xh) { (void)hipFree(idx->xh); idx->xh = nullptr; }
+        if (idx->xh_stats) { (void)hipFree(idx->xh_stats); idx->xh_stats = nullptr; }
         idx->xh_rows = 0;
         idx->x = nx; idx->xp = nxp; idx->xnorm = nxn; idx->cap = want;
     }

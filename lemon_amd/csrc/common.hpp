@@ -49,9 +49,10 @@ struct lemon_index {
     int64_t n, cap;       // rows stored / rows allocated (cap is a multiple of 128)
     float *x, *xp, *xnorm;
     // bf16 filter copies (built lazily by the bf16 path)
-    unsigned short *xh;   // [cap, dpad] bf16 (RNE) of x
+    unsigned short *xh;   // [cap, dpad_h] bf16 (RNE) of x
+    float *xh_stats;      // [2, cap]: measured ||x-xh||^2 and ||xh||^2 per row
     int64_t xh_rows;      // rows of xh that are up to date
-    unsigned *xn2max_dev; // device scalar: max_j dot(x_j,x_j) (float bits), for the filter band
+    unsigned *xn2max_dev; // device scalars (float bits): max dot(x,x), max ||x-xh||^2, max ||xh||^2
     // search workspace (grown on demand)
     int64_t ws_q;         // query rows the workspace is sized for
     int64_t ws_qp_row_bytes;  // bytes per staged query row the workspace is sized for

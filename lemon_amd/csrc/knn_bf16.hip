@@ -1,24 +1,23 @@
 // knn_bf16.hip -- LEMON_ALGO_BF16_FILTER: bf16 MFMA filter scan + exact float32 re-rank.
 //
-// Same skeleton as knn_f32.hip (a workgroup owns 128 queries and streams database tiles through
-// LDS) but the tile product runs on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate, half the
-// staged bytes) over bf16 (round-to-nearest-even) copies of Q and X.  The approximate score s~ is
-// only a FILTER:
-//     |s~(q,x) - s(q,x)| <= eps(q) := C_REL(d) * ||q|| * max_j ||x_j||        (bound derived below)
-// where s is the float32 fmaf-chain score of the numeric contract.  With T = the exact score of
-// the query's current k-th best (rows are visited in ascending index, so a later row only matters
-// if s > T strictly), every row that can still enter the top-k satisfies s~ > T - eps: those rows
-// are appended (index only) to the query's pending list.  When a list could overflow, one
-// wavefront re-scores its pending rows EXACTLY (one lane per row walks the float32 fmaf chain over
-// the original data), merges them with the exact top-k by rank-select and tightens T.  The result
-// is bit-identical to LEMON_ALGO_F32_MFMA and to the CPU oracle; no fallback path is needed
-// because the band is a proof, not a heuristic.
+// The tile product runs on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate, half the staged bytes)
+// over bf16 (round-to-nearest-even) copies of Q and X.  The approximate score s~ is only a FILTER with
+// a proven error bound
+//     |s~(q,x) - s(q,x)| <= eps(q) := ||q||*max_j||x_j - xh_j|| + ||q - qh||*max_j||xh_j||     (rounding)
+//                                    + 3*d*2^-24 * ||q||*max_j||x_j||                          (fp32 sums)
+// (identity  sum q x - sum qh xh = sum q (x-xh) + sum (q-qh) xh  + Cauchy-Schwarz; the residual norms
+// are MEASURED when the bf16 copies are made, which is ~2.4x tighter than the a-priori 2^-7 bound),
+// where s is the float32 fmaf-chain score of the numeric contract.
 //
-// eps: bf16 RNE has relative error <= 2^-8 per element, so for exact arithmetic on rounded inputs
-// |sum qh_i xh_i - sum q_i x_i| <= (2*2^-8 + 2^-16) sum |q_i x_i| <= (2^-7 + 2^-16) ||q|| ||x||
-// (Cauchy-Schwarz).  Float32 accumulation adds at most ~d*2^-24 sum|q_i x_i| on either side (the
-// MFMA's and the chain's); we budget 8*d*2^-24 for both, inflate the norms by 2^-10 for their own
-// rounding, and add an absolute 1e-30 for subnormal inputs.
+// Candidate bookkeeping is the fp32 scan's (keys = ord(score)<<32 | ~index, per-query lists, rank-select
+// compaction) but on APPROXIMATE keys: with tau = the k-th largest s~ seen so far, k rows have exact
+// score >= tau - eps, so a row can only be in the top-k if s~ + eps >= tau - eps.  Rows with
+// s~ <= tau - 2 eps are dropped (at the tile epilogue, or at a "light" compaction, which needs no
+// database access and keeps the thresholds fresh); everything else survives to ONE exact re-scoring
+// pass at the end (one lane per row walks the fp32 chain over the original data), followed by an exact
+// rank-select.  If the band holds more rows than a list can carry (concentrated data), the list is
+// re-scored exactly on the spot and cut to k.  The band is a proof, so there is no fallback path and the
+// output is bit-identical to LEMON_ALGO_F32_MFMA and the CPU oracle.
 #include "knn_common.hpp"
 
 using namespace lemon_knn;
@@ -27,30 +26,43 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int PEND_CAP = (CAP - LEMON_MAX_K) * 2;  // 384 u32 row indices behind the 64 exact keys
-constexpr int BKH = 64;                            // bf16 k-slice per LDS stage (128 B rows, like fp32 BK=32)
+constexpr int BKH = 64;   // bf16 k-slice per LDS stage (128 B rows, like fp32 BK=32)
 
-// f32 [n,d] -> bf16 [*, dpad_h] (RNE, zero padded columns); one thread per 8 outputs
+// f32 [n,d] -> bf16 [*, dpad_h] (RNE, zero padded columns), one wavefront per row, plus the row's
+// measured rounding residual ||x - xh||^2 and ||xh||^2 (float32 sums; consumers inflate them)
 __global__ __launch_bounds__(256) void k_convert_bf16(const float *__restrict__ src, int64_t n, int d,
-                                                      __bf16 *__restrict__ dst, int dpad_h) {
-    const int groups = dpad_h / 8;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * groups) return;
-    const int64_t r = t / groups;
-    const int u = (int)(t % groups);
-    const float *s = src + r * (int64_t)d + 8 * u;
-    bf16x8 o;
+                                                      __bf16 *__restrict__ dst, int dpad_h,
+                                                      float *__restrict__ res2, float *__restrict__ hn2) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const float *s = src + r * (int64_t)d;
+    float e2 = 0.0f, h2 = 0.0f;
+    for (int u = lane; u < dpad_h / 8; u += 64) {
+        bf16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (__bf16)((8 * u + e < d) ? s[e] : 0.0f);
-    *reinterpret_cast<bf16x8 *>(dst + r * (int64_t)dpad_h + 8 * u) = o;
+        for (int e = 0; e < 8; ++e) {
+            const float v = (8 * u + e < d) ? s[8 * u + e] : 0.0f;
+            const __bf16 b = (__bf16)v;
+            const float vb = (float)b;
+            const float dv = v - vb;
+            e2 = __builtin_fmaf(dv, dv, e2);
+            h2 = __builtin_fmaf(vb, vb, h2);
+            o[e] = b;
+        }
+        *reinterpret_cast<bf16x8 *>(dst + r * (int64_t)dpad_h + 8 * u) = o;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { e2 += __shfl_xor(e2, off); h2 += __shfl_xor(h2, off); }
+    if (lane == 0) { res2[r] = e2; hn2[r] = h2; }
 }
 
-// max of non-negative floats through their bit patterns
+// max of non-negative floats through their bit patterns (NaN -> +inf: the band then admits everything)
 __global__ __launch_bounds__(256) void k_max_nonneg(const float *__restrict__ v, int64_t n, unsigned *__restrict__ out) {
     float m = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float x = v[i];
-        m = (x > m || x != x) ? x : m;      // NaN/Inf propagate: the band then admits everything
+        m = (x > m || x != x) ? x : m;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -64,10 +76,20 @@ struct ScanParamsH {
     ScanParams b;              // qp / xp unused here
     const __bf16 *qh, *xh;     // [nq_pad, dpad_h], [n_pad, dpad_h]
     const float *q, *x;        // originals, row-major [nq, d], [n, d]
-    const unsigned *xn2max;    // device scalar: max_j dot(x_j,x_j) as float bits
+    const float *qres2, *qhn2; // [nq_pad] measured ||q-qh||^2, ||qh||^2
+    const unsigned *xstat;     // device scalars (float bits): [0] max dot(x,x), [1] max ||x-xh||^2, [2] max ||xh||^2
     int d, dpad_h;
-    float c_rel;
 };
+
+// proven bound on |s~ - s| for one query (see file header); for L2 the bound on the key -D
+__device__ __forceinline__ float band_eps(const ScanParamsH &p, float qn, float qres2, bool l2) {
+    const float xn2 = __uint_as_float(p.xstat[0]), xr2 = __uint_as_float(p.xstat[1]), xh2 = __uint_as_float(p.xstat[2]);
+    const float nq = sqrtf(qn) * 1.0005f;
+    float eps = (nq * sqrtf(xr2) + sqrtf(qres2) * sqrtf(xh2)) * 1.002f
+              + 3.0f * (float)p.d * 5.9604645e-8f * nq * sqrtf(xn2) * 1.002f + 1e-30f;
+    if (l2) eps = 2.0f * eps + 4.8e-7f * (qn + xn2);
+    return eps;
+}
 
 // exact score of the numeric contract for (query row, db row j); key to MAXIMISE
 __device__ __forceinline__ float exact_score(const float *__restrict__ q, const float *__restrict__ x, int d,
@@ -76,7 +98,7 @@ __device__ __forceinline__ float exact_score(const float *__restrict__ q, const 
     if ((d & 3) == 0) {
         const float4 *q4 = reinterpret_cast<const float4 *>(q);
         const float4 *x4 = reinterpret_cast<const float4 *>(x);
-#pragma unroll 4
+#pragma unroll 8
         for (int c = 0; c < d / 4; ++c) {
             const float4 a = q4[c], b = x4[c];
             acc = __builtin_fmaf(a.x, b.x, acc);
@@ -94,28 +116,62 @@ __device__ __forceinline__ float exact_score(const float *__restrict__ q, const 
     return acc;
 }
 
-// re-score the pending rows of one query exactly, merge with its exact top-k, tighten the thresholds
-__device__ __forceinline__ void compact_row_h(const ScanParamsH &p, u64 *__restrict__ list, int row, int64_t q,
-                                              int lane, int *s_cnt, int *s_kept, float *s_thr_lo, const float *s_eps,
-                                              const float *s_qn, u64 *__restrict__ sk, u64 *__restrict__ sb,
-                                              bool bias_qn = false) {
-    const int n_p = __builtin_amdgcn_readfirstlane(s_cnt[row]);
-    const int kept = __builtin_amdgcn_readfirstlane(s_kept[row]);
+// admission bound from tau (k-th largest approximate score): rows with s~ <= tau - 2 eps are out
+__device__ __forceinline__ float bound_from_tau(float tau, float eps) {
+    const float lo = tau - 2.0f * eps;
+    return lo - fabsf(lo) * 2.4e-7f - 1e-37f;          // rounded DOWN
+}
+
+// "light" compaction of one query's approximate-key list: no database access.  Keeps every key that
+// can still be in the exact top-k (s~ > tau - 2 eps), sorted best first, and refreshes the bound.
+// Returns the number of keys kept.
+__device__ __forceinline__ int compact_light(u64 *__restrict__ list, int *cnt, float *thr_lo, float *thr_key,
+                                             int row, int kk, float eps, int lane, u64 *__restrict__ sk) {
+    const int n = __builtin_amdgcn_readfirstlane(cnt[row]);
+    const u64 v0 = (lane < n) ? list[lane] : 0;
+    const u64 v1 = (lane + 64 < n) ? list[lane + 64] : 0;
+    const u64 v2 = (lane + 128 < n) ? list[lane + 128] : 0;
+    const u64 v3 = (lane + 192 < n) ? list[lane + 192] : 0;
+    const Ranked r = wave_rank_keys(v0, v1, v2, v3, n, sk, lane);
+    if (n < kk) return n;                               // nothing to drop yet, list stays as is
+    // tau = score of the key of rank kk-1: exactly one lane owns it; broadcast by ballot + shuffle
+    // (NOT through LDS: hipcc may forward a lane's own earlier read of the scratch slot across
+    // __builtin_amdgcn_wave_barrier, which is a scheduling barrier, not a memory fence)
+    const u64 mine = (v0 && r.r0 == kk - 1) ? v0 : (v1 && r.r1 == kk - 1) ? v1
+                   : (v2 && r.r2 == kk - 1) ? v2 : (v3 && r.r3 == kk - 1) ? v3 : 0;
+    const int src = __ffsll((long long)__ballot(mine != 0)) - 1;
+    const float lo = bound_from_tau(lemon_key_score(__shfl(mine, src)), eps);
+    const bool k0 = v0 && lemon_key_score(v0) > lo, k1 = v1 && lemon_key_score(v1) > lo;
+    const bool k2 = v2 && lemon_key_score(v2) > lo, k3 = v3 && lemon_key_score(v3) > lo;
+    if (k0) list[r.r0] = v0;                            // kept keys are a prefix of the sorted order
+    if (k1) list[r.r1] = v1;
+    if (k2) list[r.r2] = v2;
+    if (k3) list[r.r3] = v3;
+    const int kept = __builtin_popcountll(__ballot(k0)) + __builtin_popcountll(__ballot(k1)) +
+                     __builtin_popcountll(__ballot(k2)) + __builtin_popcountll(__ballot(k3));
+    if (lane == 0) { cnt[row] = kept; thr_lo[row] = lo; thr_key[row] = lo; }
+    return kept;
+}
+
+// exact compaction: re-score every entry of the list with the fp32 chain, keep the exact top-kk
+// (sorted, exact keys).  Used once per query at the end of the scan, and when a band overflows.
+__device__ __forceinline__ void compact_exact(const ScanParamsH &p, u64 *__restrict__ list, int *cnt, float *thr_lo,
+                                              float *thr_key, int row, int64_t q, float eps, float qn, int lane,
+                                              u64 *__restrict__ sk, u64 *__restrict__ sb) {
+    const int n = __builtin_amdgcn_readfirstlane(cnt[row]);
     const int kk = p.b.kk;
-    const u32 *pend = reinterpret_cast<const u32 *>(list + LEMON_MAX_K);
     const float *qrow = p.q + q * (int64_t)p.d;
-    const float qn = s_qn[row];
     const bool l2 = p.b.metric == LEMON_METRIC_L2;
-    u64 best = (lane < kept) ? list[lane] : 0;
+    u64 best = 0;
 #pragma unroll 1
-    for (int base = 0; base < n_p; base += 64) {     // one exact chain per lane, then a 128-key rank merge
+    for (int base = 0; base < n; base += 64) {          // one exact chain per lane, then a 128-key rank merge
         const int e = base + lane;
         u64 key = 0;
-        if (e < n_p) {
-            const u32 j = pend[e];
+        if (e < n) {
+            const u32 j = lemon_key_index(list[e]);
             const float *xrow = p.x + (int64_t)j * p.d;
             const float s = exact_score(qrow, xrow, p.d, l2, qn, l2 ? p.b.xnorm[j] : 0.0f);
-            key = (s == s) ? lemon_make_key(s, j) : 0;           // NaN is never selected (as in the fp32 scan)
+            key = (s == s) ? lemon_make_key(s, j) : 0;  // NaN is never selected (as in the fp32 scan)
         }
         const Ranked r = wave_rank_keys(best, key, 0, 0, 128, sk, lane);
         sb[lane] = 0;
@@ -130,20 +186,41 @@ __device__ __forceinline__ void compact_row_h(const ScanParamsH &p, u64 *__restr
     const int have = __builtin_popcountll(__ballot(best != 0));
     const u64 kth = __shfl(best, kk - 1);
     if (lane == 0) {
-        s_cnt[row] = 0;
-        s_kept[row] = have;
-        if (have == kk) {
-            const float T = lemon_key_score(kth);
-            // admit s~ > T - eps; round the bound DOWN (a few ulps of slack never hurts correctness)
-            const float lo = T - s_eps[row];
-            // bias_qn (Q-stationary L2 filter): the filter compares 2 s~ - |x|^2, i.e. -D + |q|^2
-            const float b = bias_qn ? s_qn[row] : 0.0f;
-            s_thr_lo[row] = (lo + b) - (fabsf(lo) + b) * 2.4e-7f - 1e-37f;
+        cnt[row] = have;
+        if (have == kk) { const float lo = bound_from_tau(lemon_key_score(kth), eps); thr_lo[row] = lo; thr_key[row] = lo; }
+    }
+}
+
+// shared post-tile maintenance for the rows of one wavefront
+__device__ __forceinline__ void maintain_rows(const ScanParamsH &p, u64 *__restrict__ cand_panel, int wave, int lane,
+                                              int64_t q0, bool last, int *s_cnt, float *s_thr_lo, float *s_thr_key,
+                                              const float *s_eps, const float *s_qn, u64 *sk, u64 *sb, bool bias_qn) {
+    for (int r = 0; r < 32; ++r) {
+        const int row = __builtin_amdgcn_readfirstlane(32 * wave + r);
+        const int c = s_cnt[row];
+        u64 *list = cand_panel + (int64_t)row * CAP;
+        const float eps = s_eps[row];
+        if (last) {
+            if (c > 0) compact_exact(p, list, s_cnt, s_thr_lo, s_thr_key, row, q0 + row, eps, s_qn[row], lane, sk, sb);
+            continue;
+        }
+        const bool warm = (s_thr_key[row] == -INFINITY) && (c >= p.b.kk);
+        if (c > CAP - BX || warm) {
+            const int kept = compact_light(list, s_cnt, s_thr_lo, s_thr_key, row, p.b.kk, eps, lane, sk);
+            if (kept > CAP - BX)      // the band itself does not fit: settle it exactly
+                compact_exact(p, list, s_cnt, s_thr_lo, s_thr_key, row, q0 + row, eps, s_qn[row], lane, sk, sb);
+            // Q-stationary L2 filter compares 2 s~ - |x|^2 = key + |q|^2
+            if (bias_qn && lane == 0 && s_thr_key[row] != -INFINITY) {
+                const float b = s_qn[row], lo = s_thr_key[row];
+                s_thr_lo[row] = (lo + b) - (fabsf(lo) + b) * 2.4e-7f - 1e-37f;
+            }
         }
     }
 }
 
-// filter one 32x32 accumulator tile: append the row index of every element above its row's bound
+// ======================================================================================
+// streaming variant (any d): both operands staged through LDS, like the fp32 scan
+// ======================================================================================
 template <bool L2>
 __device__ __forceinline__ void epilogue_tile_h(f32x16 &acc, int rtile, u32 j, bool jvalid, float xn, int h,
                                                 const float *s_thr_lo, const float *s_qn, int *s_cnt,
@@ -168,7 +245,7 @@ __device__ __forceinline__ void epilogue_tile_h(f32x16 &acc, int rtile, u32 j, b
             if (jvalid && s > th[e]) {
                 const int row = rbase + e;
                 const int slot = atomicAdd(&s_cnt[row], 1);
-                reinterpret_cast<u32 *>(cand_panel + (int64_t)row * CAP + LEMON_MAX_K)[slot] = j;
+                cand_panel[(int64_t)row * CAP + slot] = lemon_make_key(s, j);
             }
         }
     }
@@ -180,9 +257,9 @@ __global__ __launch_bounds__(NT, 2) void k_scan_bf16(ScanParamsH p) {
     __shared__ __attribute__((aligned(16))) float s_tile[2][2][BQ * BK];  // bf16 pairs: 128 rows x 64 bf16
     __shared__ __attribute__((aligned(16))) float s_thr_lo[BQ];
     __shared__ __attribute__((aligned(16))) float s_qn[BQ];
+    __shared__ float s_thr_key[BQ];
     __shared__ float s_eps[BQ];
     __shared__ int s_cnt[BQ];
-    __shared__ int s_kept[BQ];
     __shared__ __attribute__((aligned(16))) u64 s_keys[NT / 64][256];
     __shared__ __attribute__((aligned(16))) u64 s_best[NT / 64][64];
 
@@ -207,14 +284,11 @@ __global__ __launch_bounds__(NT, 2) void k_scan_bf16(ScanParamsH p) {
     if (tid < BQ) {
         const bool valid = q0 + tid < p.b.nq;
         const float qn = p.b.qnorm[q0 + tid];
-        const float xn2 = __uint_as_float(*p.xn2max);
-        float eps = p.c_rel * sqrtf(qn) * sqrtf(xn2) * 1.002f + 1e-30f;
-        if (metric == LEMON_METRIC_L2) eps = 2.0f * eps + 4.8e-7f * (qn + xn2);
-        s_eps[tid] = eps;
+        s_eps[tid] = band_eps(p, qn, p.qres2[q0 + tid], metric == LEMON_METRIC_L2);
         s_qn[tid] = qn;
         s_thr_lo[tid] = valid ? -INFINITY : INFINITY;
+        s_thr_key[tid] = valid ? -INFINITY : INFINITY;
         s_cnt[tid] = 0;
-        s_kept[tid] = 0;
     }
 
     float4 rq0, rq1, rq2, rq3, rx0, rx1, rx2, rx3;
@@ -281,15 +355,8 @@ __global__ __launch_bounds__(NT, 2) void k_scan_bf16(ScanParamsH p) {
         __syncthreads();
 
         if (tile_done) {
-            const bool last = (it + 1 == total);
-            for (int r = 0; r < 32; ++r) {
-                const int row = 32 * wave + r;
-                const int c = s_cnt[row];
-                const bool warm = (s_thr_lo[row] == -INFINITY) && (c + s_kept[row] >= p.b.kk);
-                if (c > 0 && (last || c > PEND_CAP - BX || warm))
-                    compact_row_h(p, cand_panel + (int64_t)row * CAP, row, q0 + row, lane, s_cnt, s_kept, s_thr_lo,
-                                  s_eps, s_qn, s_keys[wave], s_best[wave]);
-            }
+            maintain_rows(p, cand_panel, wave, lane, q0, it + 1 == total, s_cnt, s_thr_lo, s_thr_key, s_eps, s_qn,
+                          s_keys[wave], s_best[wave], false);
             __syncthreads();
         }
         kt = kt_n; jl = jl_n;
@@ -299,12 +366,11 @@ __global__ __launch_bounds__(NT, 2) void k_scan_bf16(ScanParamsH p) {
         const int row = 32 * wave + r;
         const int64_t q = q0 + row;
         if (q >= p.b.nq) continue;
-        const int kept = s_kept[row];
+        const int kept = s_cnt[row];
         const u64 key = (lane < kept && lane < p.b.kk) ? cand_panel[(int64_t)row * CAP + lane] : 0;
         write_out_row(p.b, split, q, lane, key);
     }
 }
-
 
 // ======================================================================================
 // Q-stationary variant (d <= 1024): the query fragments never leave the registers.
@@ -320,10 +386,10 @@ __global__ __launch_bounds__(NT, 2) void k_scan_bf16(ScanParamsH p) {
 // tree + one compare per accumulator tile instead of a compare+branch per element.
 // ======================================================================================
 // one 32x32 accumulator tile: a[e] = s~(db row jb + (e&3) + 8(e>>2), this lane's query)
-__device__ __forceinline__ void qs_filter_tile(f32x16 a, float th, int64_t jb, bool l2,
+__device__ __forceinline__ void qs_filter_tile(f32x16 a, float th, int64_t jb, bool l2, float qn,
                                                const float *__restrict__ xnorm, int64_t n, int *cnt,
-                                               u32 *__restrict__ pend) {
-    if (l2) {   // monotone proxy of -D: 2 s~ - |x|^2 (the query norm is folded into th)
+                                               u64 *__restrict__ list) {
+    if (l2) {   // monotone proxy of the key -D: 2 s~ - |x|^2 = key + |q|^2 (th carries the same offset)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 xn4 = *reinterpret_cast<const float4 *>(&xnorm[jb + 8 * g]);
@@ -344,7 +410,9 @@ __device__ __forceinline__ void qs_filter_tile(f32x16 a, float th, int64_t jb, b
             const int64_t j = jb + (e & 3) + 8 * (e >> 2);
             if (a[e] > th && j < n) {
                 const int slot = atomicAdd(cnt, 1);
-                pend[slot] = (u32)j;
+                // approximate key: for L2 the clamped -D~ = min(0, proxy - |q|^2)
+                const float s = l2 ? fminf(0.0f, a[e] - qn) : a[e];
+                list[slot] = lemon_make_key(s, (u32)j);
             }
         }
     }
@@ -387,12 +455,12 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
     // before every k-step's first ds_read: guide 5, trap (a))
     __shared__ __attribute__((aligned(16))) float smem[NB * BX * BK + 5 * BQ + (NT / 64) * (512 + 128)];
     float *s_x = smem;                                   // [NB][128*32]
-    float *s_thr_lo = smem + NB * BX * BK;               // [128]
+    float *s_thr_lo = smem + NB * BX * BK;               // [128] bound the epilogue compares against
     float *s_qn = s_thr_lo + BQ;
     float *s_eps = s_qn + BQ;
-    int *s_cnt = reinterpret_cast<int *>(s_eps + BQ);
-    int *s_kept = s_cnt + BQ;
-    u64 *s_keys = reinterpret_cast<u64 *>(s_kept + BQ);  // [4][256]
+    float *s_thr_key = s_eps + BQ;                       // [128] same bound in key units (L2: without |q|^2)
+    int *s_cnt = reinterpret_cast<int *>(s_thr_key + BQ);
+    u64 *s_keys = reinterpret_cast<u64 *>(s_cnt + BQ);   // [4][256]
     u64 *s_best = s_keys + (NT / 64) * 256;              // [4][64]
 
     const int tid = threadIdx.x;
@@ -413,14 +481,11 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
     if (tid < BQ) {
         const bool valid = q0 + tid < p.b.nq;
         const float qn = p.b.qnorm[q0 + tid];
-        const float xn2 = __uint_as_float(*p.xn2max);
-        float eps = p.c_rel * sqrtf(qn) * sqrtf(xn2) * 1.002f + 1e-30f;
-        if (l2) eps = 2.0f * eps + 4.8e-7f * (qn + xn2);
-        s_eps[tid] = eps;
+        s_eps[tid] = band_eps(p, qn, p.qres2[q0 + tid], l2);
         s_qn[tid] = qn;
         s_thr_lo[tid] = valid ? -INFINITY : INFINITY;
+        s_thr_key[tid] = valid ? -INFINITY : INFINITY;
         s_cnt[tid] = 0;
-        s_kept[tid] = 0;
     }
 
     // ---- stationary operand: this lane's query row, all k ----
@@ -441,10 +506,11 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
     qs_dma_stage(xbase + BK, dpad, s_x + BX * BK, wave, lane);
     qs_dma_stage(xbase + 2 * BK, dpad, s_x + 2 * BX * BK, wave, lane);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __syncthreads();
 
     u64 *cand_panel = p.b.cand + (int64_t)blockIdx.x * BQ * CAP;
-    u32 *my_pend = reinterpret_cast<u32 *>(cand_panel + (int64_t)qrow_l * CAP + LEMON_MAX_K);
+    u64 *my_list = cand_panel + (int64_t)qrow_l * CAP;
+    const float my_qn = l2 ? p.b.qnorm[q0 + qrow_l] : 0.0f;
 
     for (int jl = 0; jl < ntile; ++jl) {
         const float *xt = xbase + (int64_t)jl * BX * dpad;
@@ -479,27 +545,26 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
                 // ---- epilogue: acc[ni][e] = s~(db row 32ni + (e&3) + 8(e>>2) + 4h, query lane&31) ----
                 const float th = s_thr_lo[qrow_l];
                 const int64_t jb = (int64_t)(t_begin + jl) * BX + 4 * h;
-                qs_filter_tile(acc0, th, jb, l2, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_pend);
-                qs_filter_tile(acc1, th, jb + 32, l2, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_pend);
-                qs_filter_tile(acc2, th, jb + 64, l2, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_pend);
-                qs_filter_tile(acc3, th, jb + 96, l2, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_pend);
+                qs_filter_tile(acc0, th, jb, l2, my_qn, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_list);
+                qs_filter_tile(acc1, th, jb + 32, l2, my_qn, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_list);
+                qs_filter_tile(acc2, th, jb + 64, l2, my_qn, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_list);
+                qs_filter_tile(acc3, th, jb + 96, l2, my_qn, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_list);
             }
             // stage t+1 must have landed (all waves' parts) before anyone reads it: leave only the two
             // youngest stages (8 DMA instructions) in flight, then rendezvous
-            if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS reads/atomics retired
-            __builtin_amdgcn_s_barrier();
+            // (at a tile end the candidate stores of the epilogue must be visible to the compacting
+            // lanes too: stores share the vmcnt queue and are YOUNGER than the DMAs, so drain fully)
             if (kt == KT - 1) {
-                const bool last = (jl + 1 == ntile);
-                for (int r = 0; r < 32; ++r) {
-                    const int row = 32 * wave + r;
-                    const int c = s_cnt[row];
-                    const bool warm = (s_thr_lo[row] == -INFINITY) && (c + s_kept[row] >= p.b.kk);
-                    if (c > 0 && (last || c > PEND_CAP - BX || warm))
-                        compact_row_h(p, cand_panel + (int64_t)row * CAP, row, q0 + row, lane, s_cnt, s_kept, s_thr_lo,
-                                      s_eps, s_qn, s_keys + wave * 256, s_best + wave * 64, l2);
-                }
+                __syncthreads();                         // full fence: vmcnt(0) + workgroup-scope ordering
+            } else {
+                if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's LDS reads retired
+                __builtin_amdgcn_s_barrier();
+            }
+            if (kt == KT - 1) {
+                maintain_rows(p, cand_panel, wave, lane, q0, jl + 1 == ntile, s_cnt, s_thr_lo, s_thr_key, s_eps, s_qn,
+                              s_keys + wave * 256, s_best + wave * 64, l2);
                 __syncthreads();
             }
         }
@@ -509,7 +574,7 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
         const int row = 32 * wave + r;
         const int64_t q = q0 + row;
         if (q >= p.b.nq) continue;
-        const int kept = s_kept[row];
+        const int kept = s_cnt[row];
         const u64 key = (lane < kept && lane < p.b.kk) ? cand_panel[(int64_t)row * CAP + lane] : 0;
         write_out_row(p.b, split, q, lane, key);
     }
@@ -518,7 +583,7 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
 }  // namespace
 
 // column pitch of the bf16 copies: the Q-stationary kernel is instantiated for 256/512/768
-// (at 1024 the stationary operand alone would need all 256 architectural VGPRs)
+// (at 1024 the stationary operand alone would need all 256 accumulator registers next to the tile)
 static int bf16_pitch(int d) {
     if (d <= 256) return 256;
     if (d <= 512) return 512;
@@ -526,13 +591,22 @@ static int bf16_pitch(int d) {
     return (int)round_up(d, BKH);
 }
 
+static int convert_rows(const float *src, int64_t n, int d, __bf16 *dst, int dpad_h, float *res2, float *hn2,
+                        hipStream_t stream) {
+    if (n <= 0) return LEMON_OK;
+    hipLaunchKernelGGL(k_convert_bf16, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, src, n, d, dst, dpad_h,
+                       res2, hn2);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}
+
 static int ensure_bf16_copy(lemon_index_t *idx, hipStream_t stream) {
     const int dpad_h = bf16_pitch(idx->d);
     idx->dpad_h = dpad_h;
     if (!idx->xh) {
-        // cap rows + one extra tile of zero rows so the last tile never reads past the allocation
         LEMON_HIP_CHECK(hipStreamSynchronize(stream));
         if (hipMalloc(&idx->xh, (size_t)idx->cap * dpad_h * sizeof(unsigned short) + 16) != hipSuccess ||
+            hipMalloc(&idx->xh_stats, (size_t)idx->cap * 2 * sizeof(float)) != hipSuccess ||
             (!idx->xn2max_dev && hipMalloc(&idx->xn2max_dev, 16) != hipSuccess)) {
             lemon_set_error("bf16 copy allocation failed");
             return LEMON_E_NOMEM;
@@ -542,13 +616,15 @@ static int ensure_bf16_copy(lemon_index_t *idx, hipStream_t stream) {
     }
     if (idx->xh_rows < idx->n) {
         const int64_t n_new = idx->n - idx->xh_rows;
-        const int64_t threads = n_new * (dpad_h / 8);
-        hipLaunchKernelGGL(k_convert_bf16, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
-                           idx->x + idx->xh_rows * idx->d, n_new, idx->d,
-                           reinterpret_cast<__bf16 *>(idx->xh) + idx->xh_rows * dpad_h, dpad_h);
-        LEMON_HIP_CHECK(hipGetLastError());
-        LEMON_HIP_CHECK(hipMemsetAsync(idx->xn2max_dev, 0, 4, stream));
+        float *res2 = idx->xh_stats, *hn2 = idx->xh_stats + idx->cap;
+        int rc = convert_rows(idx->x + idx->xh_rows * idx->d, n_new, idx->d,
+                              reinterpret_cast<__bf16 *>(idx->xh) + idx->xh_rows * dpad_h, dpad_h,
+                              res2 + idx->xh_rows, hn2 + idx->xh_rows, stream);
+        if (rc) return rc;
+        LEMON_HIP_CHECK(hipMemsetAsync(idx->xn2max_dev, 0, 16, stream));
         hipLaunchKernelGGL(k_max_nonneg, dim3(256), dim3(256), 0, stream, idx->xnorm, idx->n, idx->xn2max_dev);
+        hipLaunchKernelGGL(k_max_nonneg, dim3(256), dim3(256), 0, stream, res2, idx->n, idx->xn2max_dev + 1);
+        hipLaunchKernelGGL(k_max_nonneg, dim3(256), dim3(256), 0, stream, hn2, idx->n, idx->xn2max_dev + 2);
         LEMON_HIP_CHECK(hipGetLastError());
         idx->xh_rows = idx->n;
     }
@@ -573,29 +649,25 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
         lemon_plan_splits(panels, n_tiles, &splits, &tiles_per_split);
         rc = lemon_ensure_search_ws(idx, nq_pad, splits, dpad_h * 2, stream);
         if (rc) return rc;
-        // bf16 query panel (pad rows zero) + chain norms (band + L2)
+        // bf16 query panel (pad rows zero), chain norms, measured rounding residuals
         __bf16 *qh = reinterpret_cast<__bf16 *>(idx->ws_qp);
+        float *qn = idx->ws_qnorm, *qres2 = idx->ws_qnorm + idx->ws_q, *qhn2 = idx->ws_qnorm + 2 * idx->ws_q;
         LEMON_HIP_CHECK(hipMemsetAsync(qh, 0, (size_t)nq_pad * dpad_h * sizeof(unsigned short), stream));
-        {
-            const int64_t threads = cn * (dpad_h / 8);
-            hipLaunchKernelGGL(k_convert_bf16, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
-                               q_dev + c0 * d, cn, d, qh, dpad_h);
-            LEMON_HIP_CHECK(hipGetLastError());
-        }
-        LEMON_HIP_CHECK(hipMemsetAsync(idx->ws_qnorm, 0, (size_t)nq_pad * sizeof(float), stream));
-        rc = lemon_rowdot_chain(q_dev + c0 * d, q_dev + c0 * d, cn, d, idx->ws_qnorm, stream);
+        LEMON_HIP_CHECK(hipMemsetAsync(idx->ws_qnorm, 0, (size_t)idx->ws_q * 3 * sizeof(float), stream));
+        rc = convert_rows(q_dev + c0 * d, cn, d, qh, dpad_h, qres2, qhn2, stream);
+        if (rc) return rc;
+        rc = lemon_rowdot_chain(q_dev + c0 * d, q_dev + c0 * d, cn, d, qn, stream);
         if (rc) return rc;
 
         ScanParamsH p;
-        p.b.qp = nullptr; p.b.xp = nullptr; p.b.qnorm = idx->ws_qnorm; p.b.xnorm = idx->xnorm;
+        p.b.qp = nullptr; p.b.xp = nullptr; p.b.qnorm = qn; p.b.xnorm = idx->xnorm;
         p.b.cand = idx->ws_cand; p.b.part = idx->ws_part;
         p.b.D = D_dev + c0 * k; p.b.I = I_dev + c0 * k;
         p.b.nq = cn; p.b.n = idx->n; p.b.dpad = dpad_h; p.b.kk = k; p.b.metric = idx->metric;
         p.b.n_tiles = n_tiles; p.b.tiles_per_split = tiles_per_split; p.b.splits = splits; p.b.nq_pad = nq_pad;
         p.qh = qh; p.xh = reinterpret_cast<const __bf16 *>(idx->xh);
-        p.q = q_dev + c0 * d; p.x = idx->x; p.xn2max = idx->xn2max_dev;
+        p.q = q_dev + c0 * d; p.x = idx->x; p.qres2 = qres2; p.qhn2 = qhn2; p.xstat = idx->xn2max_dev;
         p.d = d; p.dpad_h = dpad_h;
-        p.c_rel = 0.0078125f + 1.6e-5f + 8.0f * (float)d * 5.9604645e-8f;   // 2^-7 + 2^-16 + 8 d 2^-24
         const unsigned grid = (unsigned)(panels * splits);
         {
             const double flops = 2.0 * (double)cn * (double)idx->n * (double)d;

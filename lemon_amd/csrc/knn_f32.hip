@@ -317,7 +317,7 @@ int lemon_ensure_search_ws(lemon_index_t *idx, int64_t nq_pad, int splits, int q
         if (idx->ws_qnorm) (void)hipFree(idx->ws_qnorm);
         idx->ws_qp = nullptr; idx->ws_qnorm = nullptr; idx->ws_q = 0; idx->ws_qp_row_bytes = 0;
         if (hipMalloc(&idx->ws_qp, (size_t)rows * row_bytes) != hipSuccess ||
-            hipMalloc(&idx->ws_qnorm, (size_t)rows * sizeof(float)) != hipSuccess) {
+            hipMalloc(&idx->ws_qnorm, (size_t)rows * 3 * sizeof(float)) != hipSuccess) {   // norms + bf16 residual stats
             lemon_set_error("search workspace allocation failed (nq_pad=%lld)", (long long)nq_pad);
             return LEMON_E_NOMEM;
         }

@@ -203,6 +203,7 @@ BF16 = 2
 @pytest.mark.parametrize("nq,n,d,k", [
     (1, 1, 8, 1), (5, 3, 16, 5), (130, 1000, 40, 10), (128, 128, 32, 64), (257, 1300, 64, 51),
     (64, 5000, 512, 50), (300, 2049, 768, 5), (1100, 3000, 100, 1), (33, 40000, 96, 51), (700, 9000, 72, 64),
+    (150, 3000, 1000, 10), (40, 700, 800, 3),      # d > 768: streaming bf16 kernel (queries not register-resident)
 ])
 def test_bf16_filter_bit_exact(hip, oracle, metric, nq, n, d, k):
     rng = np.random.default_rng(nq * 7 + n * 3 + d + k)
