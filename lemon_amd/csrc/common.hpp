@@ -61,6 +61,8 @@ struct lemon_index {
     float *ws_qnorm;      // [ws_q]
     u64 *ws_cand;         // [ws_cand_rows, CAND_CAP]  (one 128-row region per scan workgroup)
     int64_t ws_cand_rows;
+    float *ws_state;      // [grid*128][2] per-query scan state carried across database chunks
+    int64_t ws_state_elems;
     u64 *ws_part;         // [splits_cap, ws_q, LEMON_MAX_K]
     int64_t ws_part_elems;
     // neighbours workspace

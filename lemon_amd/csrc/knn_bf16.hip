@@ -19,6 +19,7 @@
 // re-scored exactly on the spot and cut to k.  The band is a proof, so there is no fallback path and the
 // output is bit-identical to LEMON_ALGO_F32_MFMA and the CPU oracle.
 #include "knn_common.hpp"
+#include <stdlib.h>
 
 using namespace lemon_knn;
 
@@ -79,6 +80,12 @@ struct ScanParamsH {
     const float *qres2, *qhn2; // [nq_pad] measured ||q-qh||^2, ||qh||^2
     const unsigned *xstat;     // device scalars (float bits): [0] max dot(x,x), [1] max ||x-xh||^2, [2] max ||xh||^2
     int d, dpad_h;
+    // database chunking (Q-stationary kernel, splits == 1): one launch scans tiles [chunk_t0, chunk_t1)
+    // for every query panel, so that the chunk is re-read from the 256 MiB Infinity Cache instead of
+    // HBM; per-query state (list length, admission bound) lives in `state` between launches
+    int chunk_t0, chunk_t1, first_chunk, last_chunk;
+    float *state;              // [grid*BQ][2]: {cnt as float bits, thr_key}
+    unsigned long long *phase_dbg;   // diagnostic builds only: [grid][4] cycle sums (loop, epilogue, sync, maintain)
 };
 
 // proven bound on |s~ - s| for one query (see file header); for L2 the bound on the key -D
@@ -122,35 +129,45 @@ __device__ __forceinline__ float bound_from_tau(float tau, float eps) {
     return lo - fabsf(lo) * 2.4e-7f - 1e-37f;          // rounded DOWN
 }
 
-// "light" compaction of one query's approximate-key list: no database access.  Keeps every key that
-// can still be in the exact top-k (s~ > tau - 2 eps), sorted best first, and refreshes the bound.
-// Returns the number of keys kept.
+// "light" compaction of one query's approximate-key list: no database access, no sort.
+//   1. tau = k-th largest approximate score, by a 32-step bisection on the order-preserving score bits
+//      (each step: 4 compares + 4 ballots per lane) -- O(32 n/64) instead of the O(n^2/64) rank-select;
+//   2. every key that can still be in the exact top-k (s~ > tau - 2 eps) is stream-compacted to the
+//      front of the list (ballot prefix sums; order does not matter until the final exact pass);
+//   3. the admission bound is refreshed.  Returns the number of keys kept.
 __device__ __forceinline__ int compact_light(u64 *__restrict__ list, int *cnt, float *thr_lo, float *thr_key,
-                                             int row, int kk, float eps, int lane, u64 *__restrict__ sk) {
+                                             int row, int kk, float eps, int lane) {
     const int n = __builtin_amdgcn_readfirstlane(cnt[row]);
+    if (n < kk) return n;                               // nothing can be dropped yet
     const u64 v0 = (lane < n) ? list[lane] : 0;
     const u64 v1 = (lane + 64 < n) ? list[lane + 64] : 0;
     const u64 v2 = (lane + 128 < n) ? list[lane + 128] : 0;
     const u64 v3 = (lane + 192 < n) ? list[lane + 192] : 0;
-    const Ranked r = wave_rank_keys(v0, v1, v2, v3, n, sk, lane);
-    if (n < kk) return n;                               // nothing to drop yet, list stays as is
-    // tau = score of the key of rank kk-1: exactly one lane owns it; broadcast by ballot + shuffle
-    // (NOT through LDS: hipcc may forward a lane's own earlier read of the scratch slot across
-    // __builtin_amdgcn_wave_barrier, which is a scheduling barrier, not a memory fence)
-    const u64 mine = (v0 && r.r0 == kk - 1) ? v0 : (v1 && r.r1 == kk - 1) ? v1
-                   : (v2 && r.r2 == kk - 1) ? v2 : (v3 && r.r3 == kk - 1) ? v3 : 0;
-    const int src = __ffsll((long long)__ballot(mine != 0)) - 1;
-    const float lo = bound_from_tau(lemon_key_score(__shfl(mine, src)), eps);
+    const u32 o0 = (u32)(v0 >> 32), o1 = (u32)(v1 >> 32), o2 = (u32)(v2 >> 32), o3 = (u32)(v3 >> 32);
+    u32 t = 0;                                          // largest t with #{ord >= t} >= kk  ==  kk-th largest ord
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; --bit) {
+        const u32 cand = t | (1u << bit);
+        const int c = __builtin_popcountll(__ballot(o0 >= cand)) + __builtin_popcountll(__ballot(o1 >= cand)) +
+                      __builtin_popcountll(__ballot(o2 >= cand)) + __builtin_popcountll(__ballot(o3 >= cand));
+        if (c >= kk) t = cand;                          // wave-uniform
+    }
+    const float lo = bound_from_tau(lemon_ord2f(t), eps);
     const bool k0 = v0 && lemon_key_score(v0) > lo, k1 = v1 && lemon_key_score(v1) > lo;
     const bool k2 = v2 && lemon_key_score(v2) > lo, k3 = v3 && lemon_key_score(v3) > lo;
-    if (k0) list[r.r0] = v0;                            // kept keys are a prefix of the sorted order
-    if (k1) list[r.r1] = v1;
-    if (k2) list[r.r2] = v2;
-    if (k3) list[r.r3] = v3;
-    const int kept = __builtin_popcountll(__ballot(k0)) + __builtin_popcountll(__ballot(k1)) +
-                     __builtin_popcountll(__ballot(k2)) + __builtin_popcountll(__ballot(k3));
-    if (lane == 0) { cnt[row] = kept; thr_lo[row] = lo; thr_key[row] = lo; }
-    return kept;
+    const u64 m0 = __ballot(k0), m1 = __ballot(k1), m2 = __ballot(k2), m3 = __ballot(k3);
+    const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int base = 0;
+    if (k0) list[base + __builtin_popcountll(m0 & below)] = v0;
+    base += __builtin_popcountll(m0);
+    if (k1) list[base + __builtin_popcountll(m1 & below)] = v1;
+    base += __builtin_popcountll(m1);
+    if (k2) list[base + __builtin_popcountll(m2 & below)] = v2;
+    base += __builtin_popcountll(m2);
+    if (k3) list[base + __builtin_popcountll(m3 & below)] = v3;
+    base += __builtin_popcountll(m3);
+    if (lane == 0) { cnt[row] = base; thr_lo[row] = lo; thr_key[row] = lo; }
+    return base;
 }
 
 // exact compaction: re-score every entry of the list with the fp32 chain, keep the exact top-kk
@@ -191,29 +208,34 @@ __device__ __forceinline__ void compact_exact(const ScanParamsH &p, u64 *__restr
     }
 }
 
-// shared post-tile maintenance for the rows of one wavefront
+// shared post-tile maintenance for the 32 query rows of one wavefront.  Lane r inspects row r; only
+// the rows that need work are visited (most tiles: none).
 __device__ __forceinline__ void maintain_rows(const ScanParamsH &p, u64 *__restrict__ cand_panel, int wave, int lane,
                                               int64_t q0, bool last, int *s_cnt, float *s_thr_lo, float *s_thr_key,
                                               const float *s_eps, const float *s_qn, u64 *sk, u64 *sb, bool bias_qn) {
-    for (int r = 0; r < 32; ++r) {
-        const int row = __builtin_amdgcn_readfirstlane(32 * wave + r);
-        const int c = s_cnt[row];
+    bool need = false;
+    if (lane < 32) {
+        const int c = s_cnt[32 * wave + lane];
+        need = last ? (c > 0) : (c > CAP - BX || (c >= p.b.kk && s_thr_key[32 * wave + lane] == -INFINITY));
+    }
+    u64 todo = __ballot(need);
+    while (todo) {
+        const int r = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int row = 32 * wave + r;                  // wave-uniform (todo is a ballot)
         u64 *list = cand_panel + (int64_t)row * CAP;
         const float eps = s_eps[row];
         if (last) {
-            if (c > 0) compact_exact(p, list, s_cnt, s_thr_lo, s_thr_key, row, q0 + row, eps, s_qn[row], lane, sk, sb);
+            compact_exact(p, list, s_cnt, s_thr_lo, s_thr_key, row, q0 + row, eps, s_qn[row], lane, sk, sb);
             continue;
         }
-        const bool warm = (s_thr_key[row] == -INFINITY) && (c >= p.b.kk);
-        if (c > CAP - BX || warm) {
-            const int kept = compact_light(list, s_cnt, s_thr_lo, s_thr_key, row, p.b.kk, eps, lane, sk);
-            if (kept > CAP - BX)      // the band itself does not fit: settle it exactly
-                compact_exact(p, list, s_cnt, s_thr_lo, s_thr_key, row, q0 + row, eps, s_qn[row], lane, sk, sb);
-            // Q-stationary L2 filter compares 2 s~ - |x|^2 = key + |q|^2
-            if (bias_qn && lane == 0 && s_thr_key[row] != -INFINITY) {
-                const float b = s_qn[row], lo = s_thr_key[row];
-                s_thr_lo[row] = (lo + b) - (fabsf(lo) + b) * 2.4e-7f - 1e-37f;
-            }
+        const int kept = compact_light(list, s_cnt, s_thr_lo, s_thr_key, row, p.b.kk, eps, lane);
+        if (kept > CAP - BX)          // the band itself does not fit: settle it exactly
+            compact_exact(p, list, s_cnt, s_thr_lo, s_thr_key, row, q0 + row, eps, s_qn[row], lane, sk, sb);
+        // Q-stationary L2 filter compares 2 s~ - |x|^2 = key + |q|^2
+        if (bias_qn && lane == 0 && s_thr_key[row] != -INFINITY) {
+            const float b = s_qn[row], lo = s_thr_key[row];
+            s_thr_lo[row] = (lo + b) - (fabsf(lo) + b) * 2.4e-7f - 1e-37f;
         }
     }
 }
@@ -446,11 +468,13 @@ __device__ __forceinline__ void mfma_qs(f32x16 &acc, bf16x8 a, const bf16x8 &bq)
     asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(bq));
 }
 
-template <int KT>
+template <int KT, bool PROF>
 __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
-    static_assert(KT % 4 == 0, "stage ring of 4 needs KT % 4 == 0");
+    unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ts = 0;
+#define PH_STAMP(acc) do { if (PROF) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - ts; ts = now_; } } while (0)
     constexpr int KS = 4 * KT;                 // 16-wide k steps
-    constexpr int NB = 4;                      // LDS stage ring; 3 stages of DMA in flight
+    constexpr int NB = 8;                      // LDS stage ring (128 KB); NB-1 stages of DMA in flight:
+    constexpr int LA = NB - 1;                 // HBM latency x bandwidth needs ~100 KB in flight per CU
     // ONE shared array (a second __shared__ object next to LDS-DMA staging makes hipcc drain vmcnt
     // before every k-step's first ds_read: guide 5, trap (a))
     __shared__ __attribute__((aligned(16))) float smem[NB * BX * BK + 5 * BQ + (NT / 64) * (512 + 128)];
@@ -471,10 +495,12 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
     const int panel = blockIdx.x / p.b.splits;
     const int split = blockIdx.x % p.b.splits;
     const int64_t q0 = (int64_t)panel * BQ;
-    const int t_begin = split * p.b.tiles_per_split;
+    int t_begin = split * p.b.tiles_per_split;
     int t_end = t_begin + p.b.tiles_per_split;
     if (t_end > p.b.n_tiles) t_end = p.b.n_tiles;
+    if (p.b.splits == 1) { t_begin = p.chunk_t0; t_end = p.chunk_t1; }
     const int ntile = t_end - t_begin;
+    const bool final_pass = (p.b.splits > 1) || p.last_chunk;
     const int dpad = p.dpad_h / 2;             // row pitch in 4-byte words
     const bool l2 = p.b.metric == LEMON_METRIC_L2;
 
@@ -483,9 +509,15 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
         const float qn = p.b.qnorm[q0 + tid];
         s_eps[tid] = band_eps(p, qn, p.qres2[q0 + tid], l2);
         s_qn[tid] = qn;
-        s_thr_lo[tid] = valid ? -INFINITY : INFINITY;
-        s_thr_key[tid] = valid ? -INFINITY : INFINITY;
-        s_cnt[tid] = 0;
+        float tk = valid ? -INFINITY : INFINITY;
+        int c0 = 0;
+        if (p.b.splits == 1 && !p.first_chunk) {        // resume this query's state from the last chunk
+            c0 = __float_as_int(p.state[2 * ((int64_t)blockIdx.x * BQ + tid)]);
+            tk = p.state[2 * ((int64_t)blockIdx.x * BQ + tid) + 1];
+        }
+        s_thr_key[tid] = tk;
+        s_thr_lo[tid] = (l2 && tk != -INFINITY && tk != INFINITY) ? (tk + qn) - (fabsf(tk) + qn) * 2.4e-7f - 1e-37f : tk;
+        s_cnt[tid] = c0;
     }
 
     // ---- stationary operand: this lane's query row, all k ----
@@ -501,29 +533,32 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
 
     const float *xbase = reinterpret_cast<const float *>(p.xh + (int64_t)t_begin * BX * p.dpad_h);
     const int total = ntile * KT;              // >= 4
-    // stage s -> ring slot s & 3.  Prologue: stages 0,1,2 in flight, wait for stage 0.
-    qs_dma_stage(xbase, dpad, s_x, wave, lane);
-    qs_dma_stage(xbase + BK, dpad, s_x + BX * BK, wave, lane);
-    qs_dma_stage(xbase + 2 * BK, dpad, s_x + 2 * BX * BK, wave, lane);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // stage s -> ring slot s & (NB-1).  Prologue: stages 0..LA-1 in flight, wait for stage 0.
+    // stage s of this launch covers k-slice (s % KT) of tile (s / KT)
+#pragma unroll
+    for (int s0 = 0; s0 < LA; ++s0)
+        if (s0 < total)
+            qs_dma_stage(xbase + (int64_t)(s0 / KT) * BX * dpad + (s0 % KT) * BK, dpad, s_x + s0 * BX * BK, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (prologue only)
     __syncthreads();
 
     u64 *cand_panel = p.b.cand + (int64_t)blockIdx.x * BQ * CAP;
     u64 *my_list = cand_panel + (int64_t)qrow_l * CAP;
     const float my_qn = l2 ? p.b.qnorm[q0 + qrow_l] : 0.0f;
 
+    if (PROF) ts = __builtin_amdgcn_s_memtime();
     for (int jl = 0; jl < ntile; ++jl) {
         const float *xt = xbase + (int64_t)jl * BX * dpad;
 #pragma clang loop unroll(full)
         for (int kt = 0; kt < KT; ++kt) {
             const int t = jl * KT + kt;
-            const bool more = t + 3 < total;
-            if (more) {   // stage t+3 into the slot stage t-1 was read from (everyone passed last barrier)
-                const float *src = (kt + 3 < KT) ? xt + (kt + 3) * BK
-                                                 : xt + (int64_t)BX * dpad + (kt + 3 - KT) * BK;
-                qs_dma_stage(src, dpad, s_x + ((kt + 3) & 3) * BX * BK, wave, lane);
+            const bool more = t + LA < total;
+            if (more) {   // stage t+LA into the slot stage t-1 was read from (everyone passed last barrier)
+                const int kn = kt + LA;       // k-slice index relative to this tile (may run into later tiles)
+                const float *src = xt + (int64_t)(kn / KT) * BX * dpad + (kn % KT) * BK;
+                qs_dma_stage(src, dpad, s_x + ((t + LA) & (NB - 1)) * BX * BK, wave, lane);
             }
-            const float *tx = s_x + (kt & 3) * BX * BK;
+            const float *tx = s_x + (t & (NB - 1)) * BX * BK;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const bf16x8 a0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(l31, 2 * u + h)]));
@@ -539,6 +574,7 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
                 }
             }
             if (kt == KT - 1) {
+                PH_STAMP(ph0);
                 // MFMA results are read by VALU next: hipcc pads nothing around asm, so wait out the
                 // 16-pass MFMA latency here (once per tile)
                 asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc0), "+a"(acc1), "+a"(acc2), "+a"(acc3));
@@ -549,6 +585,7 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
                 qs_filter_tile(acc1, th, jb + 32, l2, my_qn, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_list);
                 qs_filter_tile(acc2, th, jb + 64, l2, my_qn, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_list);
                 qs_filter_tile(acc3, th, jb + 96, l2, my_qn, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_list);
+                PH_STAMP(ph1);
             }
             // stage t+1 must have landed (all waves' parts) before anyone reads it: leave only the two
             // youngest stages (8 DMA instructions) in flight, then rendezvous
@@ -557,19 +594,33 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
             if (kt == KT - 1) {
                 __syncthreads();                         // full fence: vmcnt(0) + workgroup-scope ordering
             } else {
-                if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                // stage t+1 landed <=> at most the LA-1 youngest stages (4 DMA instructions each) in flight
+                if (more) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
                 else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's LDS reads retired
                 __builtin_amdgcn_s_barrier();
             }
             if (kt == KT - 1) {
-                maintain_rows(p, cand_panel, wave, lane, q0, jl + 1 == ntile, s_cnt, s_thr_lo, s_thr_key, s_eps, s_qn,
+                maintain_rows(p, cand_panel, wave, lane, q0, final_pass && (jl + 1 == ntile), s_cnt, s_thr_lo, s_thr_key, s_eps, s_qn,
                               s_keys + wave * 256, s_best + wave * 64, l2);
                 __syncthreads();
+                PH_STAMP(ph3);
             }
         }
     }
 
+    if (PROF && tid == 0) {
+        atomicAdd(&p.phase_dbg[0], ph0); atomicAdd(&p.phase_dbg[1], ph1);
+        atomicAdd(&p.phase_dbg[2], ph2); atomicAdd(&p.phase_dbg[3], ph3);
+    }
+#undef PH_STAMP
+    if (!final_pass) {      // park the per-query state for the next database chunk
+        if (tid < BQ) {
+            p.state[2 * ((int64_t)blockIdx.x * BQ + tid)] = __int_as_float(s_cnt[tid]);
+            p.state[2 * ((int64_t)blockIdx.x * BQ + tid) + 1] = s_thr_key[tid];
+        }
+        return;
+    }
     for (int r = 0; r < 32; ++r) {
         const int row = 32 * wave + r;
         const int64_t q = q0 + row;
@@ -667,16 +718,56 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
         p.b.n_tiles = n_tiles; p.b.tiles_per_split = tiles_per_split; p.b.splits = splits; p.b.nq_pad = nq_pad;
         p.qh = qh; p.xh = reinterpret_cast<const __bf16 *>(idx->xh);
         p.q = q_dev + c0 * d; p.x = idx->x; p.qres2 = qres2; p.qhn2 = qhn2; p.xstat = idx->xn2max_dev;
-        p.d = d; p.dpad_h = dpad_h;
+        p.d = d; p.dpad_h = dpad_h; p.phase_dbg = nullptr;
         const unsigned grid = (unsigned)(panels * splits);
-        {
-            const double flops = 2.0 * (double)cn * (double)idx->n * (double)d;
-            const double bytes = 2.0 * d * ((double)cn + (double)panels * (double)idx->n) + 12.0 * k * (double)cn;
+        const bool qs = dpad_h <= 768;
+        // database chunks sized for the Infinity Cache (the chunk is re-read by every query panel)
+        int chunk_tiles = n_tiles;
+        if (qs && splits == 1) {
+            const char *env = getenv("LEMON_CHUNK_MB");
+            const double mb = env ? atof(env) : 64.0;
+            if (mb > 0) {
+                chunk_tiles = (int)(mb * 1048576.0 / ((double)BX * dpad_h * 2));
+                if (chunk_tiles < 8) chunk_tiles = 8;
+            }
+            if (chunk_tiles > n_tiles) chunk_tiles = n_tiles;
+            if ((int64_t)grid * BQ * 2 > idx->ws_state_elems) {
+                LEMON_HIP_CHECK(hipStreamSynchronize(stream));
+                if (idx->ws_state) (void)hipFree(idx->ws_state);
+                idx->ws_state = nullptr; idx->ws_state_elems = 0;
+                if (hipMalloc(&idx->ws_state, (size_t)grid * BQ * 2 * sizeof(float)) != hipSuccess) {
+                    lemon_set_error("scan state allocation failed");
+                    return LEMON_E_NOMEM;
+                }
+                idx->ws_state_elems = (int64_t)grid * BQ * 2;
+            }
+        }
+        p.state = idx->ws_state;
+        for (int t0 = 0; t0 < n_tiles; t0 += chunk_tiles) {
+            const int t1 = (t0 + chunk_tiles < n_tiles) ? t0 + chunk_tiles : n_tiles;
+            p.chunk_t0 = t0; p.chunk_t1 = t1; p.first_chunk = (t0 == 0); p.last_chunk = (t1 == n_tiles);
+            const double rows = (double)(t1 - t0) * BX < (double)idx->n - (double)t0 * BX ? (double)(t1 - t0) * BX
+                                                                                            : (double)idx->n - (double)t0 * BX;
+            const double flops = 2.0 * (double)cn * rows * (double)d;
+            const double bytes = 2.0 * d * ((double)panels * rows) + (p.last_chunk ? 2.0 * d * cn + 12.0 * k * (double)cn : 0.0);
             LemonProfScope prof(idx, stream, flops, bytes);
-            switch (dpad_h <= 768 ? dpad_h / BKH : 0) {
-                case 4:  hipLaunchKernelGGL(k_scan_bf16_qs<4>, dim3(grid), dim3(NT), 0, stream, p); break;
-                case 8:  hipLaunchKernelGGL(k_scan_bf16_qs<8>, dim3(grid), dim3(NT), 0, stream, p); break;
-                case 12: hipLaunchKernelGGL(k_scan_bf16_qs<12>, dim3(grid), dim3(NT), 0, stream, p); break;
+            if (qs && dpad_h / BKH == 12 && getenv("LEMON_PHASE_PROF")) {   // diagnostic build: phase cycle sums
+                static unsigned long long *dbg = nullptr;
+                if (!dbg) { (void)hipMalloc(&dbg, 64); (void)hipMemset(dbg, 0, 64); }
+                p.phase_dbg = dbg;
+                hipLaunchKernelGGL((k_scan_bf16_qs<12, true>), dim3(grid), dim3(NT), 0, stream, p);
+                (void)hipStreamSynchronize(stream);
+                unsigned long long h[4]; (void)hipMemcpy(h, dbg, 32, hipMemcpyDeviceToHost);
+                const double tot = (double)(h[0] + h[1] + h[2] + h[3]);
+                fprintf(stderr, "[phase] grid=%u loop=%.1f%% epilogue=%.1f%% sync=%.1f%% maintain=%.1f%% total=%.3g cyc/WG=%.3g\n",
+                        grid, 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, tot, tot / grid);
+                (void)hipMemset(dbg, 0, 64);
+                continue;
+            }
+            switch (qs ? dpad_h / BKH : 0) {
+                case 4:  hipLaunchKernelGGL((k_scan_bf16_qs<4, false>), dim3(grid), dim3(NT), 0, stream, p); break;
+                case 8:  hipLaunchKernelGGL((k_scan_bf16_qs<8, false>), dim3(grid), dim3(NT), 0, stream, p); break;
+                case 12: hipLaunchKernelGGL((k_scan_bf16_qs<12, false>), dim3(grid), dim3(NT), 0, stream, p); break;
                 default: hipLaunchKernelGGL(k_scan_bf16, dim3(grid), dim3(NT), 0, stream, p); break;
             }
         }

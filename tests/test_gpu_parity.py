@@ -268,3 +268,21 @@ def test_neighbors_record_bf16_algo(hip, oracle):
     got = db.neighbors(cu(q_img), cu(q_txt), 10)
     for key in ("I_n", "I_m", "d_1", "D_n", "dists_n", "dists_tr_n", "D_m", "dists_m", "dists_tr_m"):
         assert np.array_equal(got[key].cpu().numpy(), ref[key]), key
+
+
+def test_bf16_filter_chunked_database_state_carry(hip, oracle, monkeypatch):
+    # >= 1024 query panels -> one launch per Infinity-Cache-sized database chunk with the per-query
+    # state carried between launches; force tiny chunks (8 tiles) so several launches happen
+    monkeypatch.setenv("LEMON_CHUNK_MB", "0.01")
+    g = torch.Generator(device="cuda").manual_seed(9)
+    X = hip.normalize_vectors(torch.randn(5000, 64, generator=g, device="cuda"))
+    Q = hip.normalize_vectors(torch.randn(131072 + 77, 64, generator=g, device="cuda"))
+    out = []
+    for algo in (1, BF16):
+        idx = hip.IndexFlatIP(64)
+        idx.set_algo(algo)
+        idx.add(X)
+        out.append(idx.search(Q, 51))
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][0], out[1][0])
+    Dr, Ir = oracle.knn("ip", X.cpu().numpy(), Q[:512].cpu().numpy(), 51)
+    assert np.array_equal(out[1][1][:512].cpu().numpy(), Ir)
