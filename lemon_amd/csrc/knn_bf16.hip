@@ -28,6 +28,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int BKH = 64;   // bf16 k-slice per LDS stage (128 B rows, like fp32 BK=32)
+constexpr int CAPH = 512; // candidate slots per query (approximate keys): 8 per lane in a light compaction
+constexpr int ABUF = 8;   // per-query LDS append buffer of the Q-stationary kernel (entries)
+constexpr int REFRESH = 64; // light-compact a list after this many new candidates: the admission bound then
+                            // tracks the running k-th best closely (appends ~ k ln(N/k) instead of 3-4x that)
 
 // f32 [n,d] -> bf16 [*, dpad_h] (RNE, zero padded columns), one wavefront per row, plus the row's
 // measured rounding residual ||x - xh||^2 and ||xh||^2 (float32 sums; consumers inflate them)
@@ -85,6 +89,7 @@ struct ScanParamsH {
     // HBM; per-query state (list length, admission bound) lives in `state` between launches
     int chunk_t0, chunk_t1, first_chunk, last_chunk;
     float *state;              // [grid*BQ][2]: {cnt as float bits, thr_key}
+    int ablate;                // diagnostics only (LEMON_ABLATE): 1 = skip the filter epilogue, 2 = skip maintenance
     unsigned long long *phase_dbg;   // diagnostic builds only: [grid][4] cycle sums (loop, epilogue, sync, maintain)
 };
 
@@ -123,6 +128,23 @@ __device__ __forceinline__ float exact_score(const float *__restrict__ q, const 
     return acc;
 }
 
+// LDS ops the compiler must not see as LDS writes (see the note on `smem` in k_scan_bf16_qs).  LDS
+// instructions of one wave execute in order, so later compiler-generated reads observe these writes.
+__device__ __forceinline__ unsigned lds_off(const void *p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
+}
+__device__ __forceinline__ int lds_inc_rtn(unsigned addr) {
+    int r;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr), "v"(1) : "memory");
+    return r;
+}
+__device__ __forceinline__ void lds_store_b64(unsigned addr, u64 v) {
+    asm volatile("ds_write_b64 %0, %1\n\ts_nop 1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_store_b32(unsigned addr, int v) {
+    asm volatile("ds_write_b32 %0, %1\n\ts_nop 1" ::"v"(addr), "v"(v) : "memory");
+}
+
 // admission bound from tau (k-th largest approximate score): rows with s~ <= tau - 2 eps are out
 __device__ __forceinline__ float bound_from_tau(float tau, float eps) {
     const float lo = tau - 2.0f * eps;
@@ -131,41 +153,46 @@ __device__ __forceinline__ float bound_from_tau(float tau, float eps) {
 
 // "light" compaction of one query's approximate-key list: no database access, no sort.
 //   1. tau = k-th largest approximate score, by a 32-step bisection on the order-preserving score bits
-//      (each step: 4 compares + 4 ballots per lane) -- O(32 n/64) instead of the O(n^2/64) rank-select;
+//      (each step: 9 compares + 9 ballots per lane) -- O(32 n/64) instead of the O(n^2/64) rank-select;
 //   2. every key that can still be in the exact top-k (s~ > tau - 2 eps) is stream-compacted to the
 //      front of the list (ballot prefix sums; order does not matter until the final exact pass);
 //   3. the admission bound is refreshed.  Returns the number of keys kept.
+// Input: n keys in the global list (<= CAPH = 8 per lane) + na keys in the LDS append buffer `abuf`
+// (this tile's appends, na <= ABUF; may be nullptr/0).
 __device__ __forceinline__ int compact_light(u64 *__restrict__ list, int *cnt, float *thr_lo, float *thr_key,
-                                             int row, int kk, float eps, int lane) {
+                                             int row, int kk, float eps, int lane, const u64 *abuf, int na) {
     const int n = __builtin_amdgcn_readfirstlane(cnt[row]);
-    if (n < kk) return n;                               // nothing can be dropped yet
-    const u64 v0 = (lane < n) ? list[lane] : 0;
-    const u64 v1 = (lane + 64 < n) ? list[lane + 64] : 0;
-    const u64 v2 = (lane + 128 < n) ? list[lane + 128] : 0;
-    const u64 v3 = (lane + 192 < n) ? list[lane + 192] : 0;
-    const u32 o0 = (u32)(v0 >> 32), o1 = (u32)(v1 >> 32), o2 = (u32)(v2 >> 32), o3 = (u32)(v3 >> 32);
+    u64 v[9];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (lane + 64 * i < n) ? list[lane + 64 * i] : 0;
+    v[8] = (lane < na) ? abuf[lane] : 0;
+    if (n + na < kk) {                                  // nothing can be dropped yet: just append the buffer
+        if (lane < na) list[n + lane] = v[8];
+        if (lane == 0) cnt[row] = n + na;
+        return n + na;
+    }
+    u32 o[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o[i] = (u32)(v[i] >> 32);
     u32 t = 0;                                          // largest t with #{ord >= t} >= kk  ==  kk-th largest ord
 #pragma unroll 1
     for (int bit = 31; bit >= 0; --bit) {
         const u32 cand = t | (1u << bit);
-        const int c = __builtin_popcountll(__ballot(o0 >= cand)) + __builtin_popcountll(__ballot(o1 >= cand)) +
-                      __builtin_popcountll(__ballot(o2 >= cand)) + __builtin_popcountll(__ballot(o3 >= cand));
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) c += __builtin_popcountll(__ballot(o[i] >= cand));
         if (c >= kk) t = cand;                          // wave-uniform
     }
     const float lo = bound_from_tau(lemon_ord2f(t), eps);
-    const bool k0 = v0 && lemon_key_score(v0) > lo, k1 = v1 && lemon_key_score(v1) > lo;
-    const bool k2 = v2 && lemon_key_score(v2) > lo, k3 = v3 && lemon_key_score(v3) > lo;
-    const u64 m0 = __ballot(k0), m1 = __ballot(k1), m2 = __ballot(k2), m3 = __ballot(k3);
     const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int base = 0;
-    if (k0) list[base + __builtin_popcountll(m0 & below)] = v0;
-    base += __builtin_popcountll(m0);
-    if (k1) list[base + __builtin_popcountll(m1 & below)] = v1;
-    base += __builtin_popcountll(m1);
-    if (k2) list[base + __builtin_popcountll(m2 & below)] = v2;
-    base += __builtin_popcountll(m2);
-    if (k3) list[base + __builtin_popcountll(m3 & below)] = v3;
-    base += __builtin_popcountll(m3);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const bool keep = v[i] && lemon_key_score(v[i]) > lo;
+        const u64 m = __ballot(keep);
+        if (keep) list[base + __builtin_popcountll(m & below)] = v[i];
+        base += __builtin_popcountll(m);
+    }
     if (lane == 0) { cnt[row] = base; thr_lo[row] = lo; thr_key[row] = lo; }
     return base;
 }
@@ -209,33 +236,64 @@ __device__ __forceinline__ void compact_exact(const ScanParamsH &p, u64 *__restr
 }
 
 // shared post-tile maintenance for the 32 query rows of one wavefront.  Lane r inspects row r; only
-// the rows that need work are visited (most tiles: none).
+// the rows that need work are visited (most tiles: none).  s_acnt/s_abuf: the Q-stationary kernel's
+// per-query LDS append buffers (nullptr for the streaming kernel, which appends to the list directly).
+// flush_all: end of a launch -- everything buffered must reach the global list.
 __device__ __forceinline__ void maintain_rows(const ScanParamsH &p, u64 *__restrict__ cand_panel, int wave, int lane,
-                                              int64_t q0, bool last, int *s_cnt, float *s_thr_lo, float *s_thr_key,
-                                              const float *s_eps, const float *s_qn, u64 *sk, u64 *sb, bool bias_qn) {
+                                              int64_t q0, bool last, bool flush_all, int *s_cnt, float *s_thr_lo,
+                                              float *s_thr_key, const float *s_eps, const float *s_qn, u64 *sk, u64 *sb,
+                                              bool bias_qn, int *s_acnt, u64 *s_abuf, int *s_last,
+                                              unsigned long long *dbg = nullptr) {
     bool need = false;
     if (lane < 32) {
-        const int c = s_cnt[32 * wave + lane];
-        need = last ? (c > 0) : (c > CAP - BX || (c >= p.b.kk && s_thr_key[32 * wave + lane] == -INFINITY));
+        const int row = 32 * wave + lane;
+        const int c = s_cnt[row];
+        const int a = s_acnt ? s_acnt[row] : 0;
+        const bool warm = (c + (a < ABUF ? a : ABUF) >= p.b.kk) && s_thr_key[row] == -INFINITY;
+        const bool stale = s_last && (c + a - s_last[row] >= REFRESH) && (c + a >= p.b.kk);
+        need = (last || flush_all) ? (c + a > 0) : (c + a > CAPH - BX - ABUF || warm || stale || a >= ABUF - 2);
     }
     u64 todo = __ballot(need);
+    if (todo == 0) return;
+    // a row whose buffer overflowed this tile appended straight to the global list: those stores (and,
+    // at the end of a launch, everything) must be visible to the lanes that compact it
+    bool ovf = false;
+    if (s_acnt && lane < 32) ovf = s_acnt[32 * wave + lane] > ABUF;
+    if (__ballot(ovf) || last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     while (todo) {
         const int r = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
         const int row = 32 * wave + r;                  // wave-uniform (todo is a ballot)
-        u64 *list = cand_panel + (int64_t)row * CAP;
+        u64 *list = cand_panel + (int64_t)row * CAPH;
         const float eps = s_eps[row];
-        if (last) {
-            compact_exact(p, list, s_cnt, s_thr_lo, s_thr_key, row, q0 + row, eps, s_qn[row], lane, sk, sb);
-            continue;
+        int a = s_acnt ? s_acnt[row] : 0;
+        if (a > ABUF) a = ABUF;                          // the overflow part is already in the list
+        const u64 *abuf = s_abuf ? s_abuf + row * ABUF : nullptr;
+        const int c = __builtin_amdgcn_readfirstlane(s_cnt[row]);
+        const bool warm = (c + a >= p.b.kk) && s_thr_key[row] == -INFINITY;
+        const bool stale = s_last && (c + a - s_last[row] >= REFRESH) && (c + a >= p.b.kk);
+        if (!last && (c + a > CAPH - BX - ABUF || warm || stale)) {
+            const int kept = compact_light(list, s_cnt, s_thr_lo, s_thr_key, row, p.b.kk, eps, lane, abuf, a);
+            if (s_last && lane == 0) s_last[row] = kept;
+            if (dbg && lane == 0) { atomicAdd(dbg + 4, 1ull); atomicAdd(dbg + 5, (unsigned long long)(c + a)); atomicAdd(dbg + 6, (unsigned long long)kept); }
+            if (kept > CAPH - BX - ABUF) {               // the band itself does not fit: settle it exactly
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                compact_exact(p, list, s_cnt, s_thr_lo, s_thr_key, row, q0 + row, eps, s_qn[row], lane, sk, sb);
+            }
+            // Q-stationary L2 filter compares 2 s~ - |x|^2 = key + |q|^2
+            if (bias_qn && lane == 0 && s_thr_key[row] != -INFINITY) {
+                const float b = s_qn[row], lo = s_thr_key[row];
+                s_thr_lo[row] = (lo + b) - (fabsf(lo) + b) * 2.4e-7f - 1e-37f;
+            }
+        } else {                                         // plain flush of the append buffer
+            if (lane < a) list[c + lane] = abuf[lane];
+            if (lane == 0) lds_store_b32(lds_off(&s_cnt[row]), c + a);
+            if (dbg && lane == 0) { atomicAdd(dbg + 7, 1ull); }
         }
-        const int kept = compact_light(list, s_cnt, s_thr_lo, s_thr_key, row, p.b.kk, eps, lane);
-        if (kept > CAP - BX)          // the band itself does not fit: settle it exactly
+        if (s_acnt && lane == 0) lds_store_b32(lds_off(&s_acnt[row]), 0);
+        if (last) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             compact_exact(p, list, s_cnt, s_thr_lo, s_thr_key, row, q0 + row, eps, s_qn[row], lane, sk, sb);
-        // Q-stationary L2 filter compares 2 s~ - |x|^2 = key + |q|^2
-        if (bias_qn && lane == 0 && s_thr_key[row] != -INFINITY) {
-            const float b = s_qn[row], lo = s_thr_key[row];
-            s_thr_lo[row] = (lo + b) - (fabsf(lo) + b) * 2.4e-7f - 1e-37f;
         }
     }
 }
@@ -267,7 +325,7 @@ __device__ __forceinline__ void epilogue_tile_h(f32x16 &acc, int rtile, u32 j, b
             if (jvalid && s > th[e]) {
                 const int row = rbase + e;
                 const int slot = atomicAdd(&s_cnt[row], 1);
-                cand_panel[(int64_t)row * CAP + slot] = lemon_make_key(s, j);
+                cand_panel[(int64_t)row * CAPH + slot] = lemon_make_key(s, j);
             }
         }
     }
@@ -325,7 +383,7 @@ __global__ __launch_bounds__(NT, 2) void k_scan_bf16(ScanParamsH p) {
     STAGE_COMMIT(s_tile[0][0], s_tile[0][1]);
     __syncthreads();
 
-    u64 *cand_panel = p.b.cand + (int64_t)blockIdx.x * BQ * CAP;
+    u64 *cand_panel = p.b.cand + (int64_t)blockIdx.x * BQ * CAPH;
     const int arow0 = 64 * wr + l31, arow1 = arow0 + 32;
     const int brow0 = 64 * wc + l31, brow1 = brow0 + 32;
 
@@ -377,8 +435,8 @@ __global__ __launch_bounds__(NT, 2) void k_scan_bf16(ScanParamsH p) {
         __syncthreads();
 
         if (tile_done) {
-            maintain_rows(p, cand_panel, wave, lane, q0, it + 1 == total, s_cnt, s_thr_lo, s_thr_key, s_eps, s_qn,
-                          s_keys[wave], s_best[wave], false);
+            maintain_rows(p, cand_panel, wave, lane, q0, it + 1 == total, false, s_cnt, s_thr_lo, s_thr_key, s_eps, s_qn,
+                          s_keys[wave], s_best[wave], false, nullptr, nullptr, nullptr);
             __syncthreads();
         }
         kt = kt_n; jl = jl_n;
@@ -389,7 +447,7 @@ __global__ __launch_bounds__(NT, 2) void k_scan_bf16(ScanParamsH p) {
         const int64_t q = q0 + row;
         if (q >= p.b.nq) continue;
         const int kept = s_cnt[row];
-        const u64 key = (lane < kept && lane < p.b.kk) ? cand_panel[(int64_t)row * CAP + lane] : 0;
+        const u64 key = (lane < kept && lane < p.b.kk) ? cand_panel[(int64_t)row * CAPH + lane] : 0;
         write_out_row(p.b, split, q, lane, key);
     }
 }
@@ -407,10 +465,13 @@ __global__ __launch_bounds__(NT, 2) void k_scan_bf16(ScanParamsH p) {
 // each lane (col = lane&31), so the admission threshold is a per-lane scalar: a 16-value v_max3
 // tree + one compare per accumulator tile instead of a compare+branch per element.
 // ======================================================================================
-// one 32x32 accumulator tile: a[e] = s~(db row jb + (e&3) + 8(e>>2), this lane's query)
-__device__ __forceinline__ void qs_filter_tile(f32x16 a, float th, int64_t jb, bool l2, float qn,
-                                               const float *__restrict__ xnorm, int64_t n, int *cnt,
-                                               u64 *__restrict__ list) {
+// one 32x32 accumulator tile: a[e] = s~(db row jb + (e&3) + 8(e>>2), this lane's query).
+// Survivors go to the query's LDS append buffer (no VMEM store in the steady state, so the DMA queue
+// never has to be drained for them); if the buffer is full they go straight to the global list.
+template <bool l2>
+__device__ __forceinline__ void qs_filter_tile(f32x16 a, float th, int64_t jb, float qn,
+                                               const float *__restrict__ xnorm, int64_t n, int *acnt, u64 *abuf,
+                                               int *cnt, u64 *__restrict__ list) {
     if (l2) {   // monotone proxy of the key -D: 2 s~ - |x|^2 = key + |q|^2 (th carries the same offset)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -431,10 +492,12 @@ __device__ __forceinline__ void qs_filter_tile(f32x16 a, float th, int64_t jb, b
         for (int e = 0; e < 16; ++e) {
             const int64_t j = jb + (e & 3) + 8 * (e >> 2);
             if (a[e] > th && j < n) {
-                const int slot = atomicAdd(cnt, 1);
                 // approximate key: for L2 the clamped -D~ = min(0, proxy - |q|^2)
                 const float s = l2 ? fminf(0.0f, a[e] - qn) : a[e];
-                list[slot] = lemon_make_key(s, (u32)j);
+                const u64 key = lemon_make_key(s, (u32)j);
+                const int slot = lds_inc_rtn(lds_off(acnt));
+                if (slot < ABUF) lds_store_b64(lds_off(abuf) + 8u * (unsigned)slot, key);
+                else list[atomicAdd(cnt, 1)] = key;      // (rare: warm-up / concentrated data)
             }
         }
     }
@@ -468,7 +531,9 @@ __device__ __forceinline__ void mfma_qs(f32x16 &acc, bf16x8 a, const bf16x8 &bq)
     asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(bq));
 }
 
-template <int KT, bool PROF>
+// (the metric is a template parameter: the L2 epilogue issues ordinary global loads (|x|^2), and hipcc
+// drains the whole LDS-DMA queue before any use of an ordinary load while DMAs are in flight)
+template <int KT, bool l2, bool PROF>
 __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
     unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ts = 0;
 #define PH_STAMP(acc) do { if (PROF) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - ts; ts = now_; } } while (0)
@@ -477,14 +542,23 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
     constexpr int LA = NB - 1;                 // HBM latency x bandwidth needs ~100 KB in flight per CU
     // ONE shared array (a second __shared__ object next to LDS-DMA staging makes hipcc drain vmcnt
     // before every k-step's first ds_read: guide 5, trap (a))
-    __shared__ __attribute__((aligned(16))) float smem[NB * BX * BK + 5 * BQ + (NT / 64) * (512 + 128)];
+    // ONE shared array.  Two hipcc behaviours shape this (ROCm 7.2):
+    //  * with the DMA ring as its own __shared__ object the compiler KNOWS every ds_read of it aliases
+    //    the in-flight LDS-DMA and emits s_waitcnt vmcnt(0) before each k-step (guide 5, trap (a));
+    //  * inside one array it instead orders every compiler-generated LDS WRITE/ATOMIC behind
+    //    vmcnt(0) (possible WAW with a DMA destination) -- which drained the 7-stage queue on every
+    //    candidate append.  The steady-state appends therefore use inline-asm DS ops (lds_* helpers).
+    __shared__ __attribute__((aligned(16))) float smem[NB * BX * BK + 7 * BQ + 2 * BQ * ABUF + (NT / 64) * (512 + 128)];
     float *s_x = smem;                                   // [NB][128*32]
     float *s_thr_lo = smem + NB * BX * BK;               // [128] bound the epilogue compares against
     float *s_qn = s_thr_lo + BQ;
     float *s_eps = s_qn + BQ;
     float *s_thr_key = s_eps + BQ;                       // [128] same bound in key units (L2: without |q|^2)
     int *s_cnt = reinterpret_cast<int *>(s_thr_key + BQ);
-    u64 *s_keys = reinterpret_cast<u64 *>(s_cnt + BQ);   // [4][256]
+    int *s_acnt = s_cnt + BQ;                            // [128] entries in the LDS append buffer (this tile)
+    int *s_last = s_acnt + BQ;                           // [128] list length right after the last light compaction
+    u64 *s_abuf = reinterpret_cast<u64 *>(s_last + BQ);  // [128][ABUF]
+    u64 *s_keys = s_abuf + BQ * ABUF;                    // [4][256]
     u64 *s_best = s_keys + (NT / 64) * 256;              // [4][64]
 
     const int tid = threadIdx.x;
@@ -502,7 +576,6 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
     const int ntile = t_end - t_begin;
     const bool final_pass = (p.b.splits > 1) || p.last_chunk;
     const int dpad = p.dpad_h / 2;             // row pitch in 4-byte words
-    const bool l2 = p.b.metric == LEMON_METRIC_L2;
 
     if (tid < BQ) {
         const bool valid = q0 + tid < p.b.nq;
@@ -518,6 +591,8 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
         s_thr_key[tid] = tk;
         s_thr_lo[tid] = (l2 && tk != -INFINITY && tk != INFINITY) ? (tk + qn) - (fabsf(tk) + qn) * 2.4e-7f - 1e-37f : tk;
         s_cnt[tid] = c0;
+        s_acnt[tid] = 0;
+        s_last[tid] = c0;
     }
 
     // ---- stationary operand: this lane's query row, all k ----
@@ -542,8 +617,9 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (prologue only)
     __syncthreads();
 
-    u64 *cand_panel = p.b.cand + (int64_t)blockIdx.x * BQ * CAP;
-    u64 *my_list = cand_panel + (int64_t)qrow_l * CAP;
+    u64 *cand_panel = p.b.cand + (int64_t)blockIdx.x * BQ * CAPH;
+    u64 *my_list = cand_panel + (int64_t)qrow_l * CAPH;
+    u64 *my_abuf = s_abuf + qrow_l * ABUF;
     const float my_qn = l2 ? p.b.qnorm[q0 + qrow_l] : 0.0f;
 
     if (PROF) ts = __builtin_amdgcn_s_memtime();
@@ -573,7 +649,7 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
                     mfma_qs(acc2, a2, qf[4 * kt + u]); mfma_qs(acc3, a3, qf[4 * kt + u]);
                 }
             }
-            if (kt == KT - 1) {
+            if (kt == KT - 1 && !(p.ablate & 1)) {
                 PH_STAMP(ph0);
                 // MFMA results are read by VALU next: hipcc pads nothing around asm, so wait out the
                 // 16-pass MFMA latency here (once per tile)
@@ -581,31 +657,26 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
                 // ---- epilogue: acc[ni][e] = s~(db row 32ni + (e&3) + 8(e>>2) + 4h, query lane&31) ----
                 const float th = s_thr_lo[qrow_l];
                 const int64_t jb = (int64_t)(t_begin + jl) * BX + 4 * h;
-                qs_filter_tile(acc0, th, jb, l2, my_qn, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_list);
-                qs_filter_tile(acc1, th, jb + 32, l2, my_qn, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_list);
-                qs_filter_tile(acc2, th, jb + 64, l2, my_qn, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_list);
-                qs_filter_tile(acc3, th, jb + 96, l2, my_qn, p.b.xnorm, p.b.n, &s_cnt[qrow_l], my_list);
+                qs_filter_tile<l2>(acc0, th, jb, my_qn, p.b.xnorm, p.b.n, &s_acnt[qrow_l], my_abuf, &s_cnt[qrow_l], my_list);
+                qs_filter_tile<l2>(acc1, th, jb + 32, my_qn, p.b.xnorm, p.b.n, &s_acnt[qrow_l], my_abuf, &s_cnt[qrow_l], my_list);
+                qs_filter_tile<l2>(acc2, th, jb + 64, my_qn, p.b.xnorm, p.b.n, &s_acnt[qrow_l], my_abuf, &s_cnt[qrow_l], my_list);
+                qs_filter_tile<l2>(acc3, th, jb + 96, my_qn, p.b.xnorm, p.b.n, &s_acnt[qrow_l], my_abuf, &s_cnt[qrow_l], my_list);
                 PH_STAMP(ph1);
             }
-            // stage t+1 must have landed (all waves' parts) before anyone reads it: leave only the two
-            // youngest stages (8 DMA instructions) in flight, then rendezvous
-            // (at a tile end the candidate stores of the epilogue must be visible to the compacting
-            // lanes too: stores share the vmcnt queue and are YOUNGER than the DMAs, so drain fully)
-            if (kt == KT - 1) {
-                __syncthreads();                         // full fence: vmcnt(0) + workgroup-scope ordering
-            } else {
-                // stage t+1 landed <=> at most the LA-1 youngest stages (4 DMA instructions each) in flight
-                if (more) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-                else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's LDS reads retired
-                __builtin_amdgcn_s_barrier();
-            }
-            if (kt == KT - 1) {
-                maintain_rows(p, cand_panel, wave, lane, q0, final_pass && (jl + 1 == ntile), s_cnt, s_thr_lo, s_thr_key, s_eps, s_qn,
-                              s_keys + wave * 256, s_best + wave * 64, l2);
-                __syncthreads();
+            if (kt == KT - 1 && !(p.ablate & 2)) {
+                // candidate state of a query is touched only by the wave that owns it: no rendezvous needed
+                const bool last_tile = (jl + 1 == ntile);
+                maintain_rows(p, cand_panel, wave, lane, q0, final_pass && last_tile, last_tile, s_cnt, s_thr_lo,
+                              s_thr_key, s_eps, s_qn, s_keys + wave * 256, s_best + wave * 64, l2, s_acnt, s_abuf, s_last, PROF ? p.phase_dbg : nullptr);
                 PH_STAMP(ph3);
             }
+            // stage t+1 must have landed (all waves' parts) before anyone reads it: at most the LA-1
+            // youngest stages (4 DMA instructions each) may still be in flight, then rendezvous
+            if (more) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS reads retired
+            __builtin_amdgcn_s_barrier();
+            if (kt == KT - 1) PH_STAMP(ph2);
         }
     }
 
@@ -626,7 +697,7 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
         const int64_t q = q0 + row;
         if (q >= p.b.nq) continue;
         const int kept = s_cnt[row];
-        const u64 key = (lane < kept && lane < p.b.kk) ? cand_panel[(int64_t)row * CAP + lane] : 0;
+        const u64 key = (lane < kept && lane < p.b.kk) ? cand_panel[(int64_t)row * CAPH + lane] : 0;
         write_out_row(p.b, split, q, lane, key);
     }
 }
@@ -698,7 +769,7 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
         const int panels = (int)(nq_pad / BQ);
         int splits, tiles_per_split;
         lemon_plan_splits(panels, n_tiles, &splits, &tiles_per_split);
-        rc = lemon_ensure_search_ws(idx, nq_pad, splits, dpad_h * 2, stream);
+        rc = lemon_ensure_search_ws(idx, nq_pad, splits, dpad_h * 2, CAPH, stream);
         if (rc) return rc;
         // bf16 query panel (pad rows zero), chain norms, measured rounding residuals
         __bf16 *qh = reinterpret_cast<__bf16 *>(idx->ws_qp);
@@ -719,6 +790,7 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
         p.qh = qh; p.xh = reinterpret_cast<const __bf16 *>(idx->xh);
         p.q = q_dev + c0 * d; p.x = idx->x; p.qres2 = qres2; p.qhn2 = qhn2; p.xstat = idx->xn2max_dev;
         p.d = d; p.dpad_h = dpad_h; p.phase_dbg = nullptr;
+        p.ablate = getenv("LEMON_ABLATE") ? atoi(getenv("LEMON_ABLATE")) : 0;
         const unsigned grid = (unsigned)(panels * splits);
         const bool qs = dpad_h <= 768;
         // database chunks sized for the Infinity Cache (the chunk is re-read by every query panel)
@@ -751,23 +823,35 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
             const double flops = 2.0 * (double)cn * rows * (double)d;
             const double bytes = 2.0 * d * ((double)panels * rows) + (p.last_chunk ? 2.0 * d * cn + 12.0 * k * (double)cn : 0.0);
             LemonProfScope prof(idx, stream, flops, bytes);
-            if (qs && dpad_h / BKH == 12 && getenv("LEMON_PHASE_PROF")) {   // diagnostic build: phase cycle sums
+            if (qs && dpad_h / BKH == 12 && idx->metric == LEMON_METRIC_IP && getenv("LEMON_PHASE_PROF")) {   // diagnostic build: phase cycle sums
                 static unsigned long long *dbg = nullptr;
                 if (!dbg) { (void)hipMalloc(&dbg, 64); (void)hipMemset(dbg, 0, 64); }
                 p.phase_dbg = dbg;
-                hipLaunchKernelGGL((k_scan_bf16_qs<12, true>), dim3(grid), dim3(NT), 0, stream, p);
+                hipLaunchKernelGGL((k_scan_bf16_qs<12, false, true>), dim3(grid), dim3(NT), 0, stream, p);
                 (void)hipStreamSynchronize(stream);
-                unsigned long long h[4]; (void)hipMemcpy(h, dbg, 32, hipMemcpyDeviceToHost);
+                unsigned long long h[8]; (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
+                fprintf(stderr, "[phase] per query: light compactions=%.1f (avg n=%.0f -> kept=%.0f), flushes=%.1f\n",
+                        (double)h[4] / cn, h[4] ? (double)h[5] / h[4] : 0.0, h[4] ? (double)h[6] / h[4] : 0.0, (double)h[7] / cn);
                 const double tot = (double)(h[0] + h[1] + h[2] + h[3]);
                 fprintf(stderr, "[phase] grid=%u loop=%.1f%% epilogue=%.1f%% sync=%.1f%% maintain=%.1f%% total=%.3g cyc/WG=%.3g\n",
                         grid, 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, tot, tot / grid);
                 (void)hipMemset(dbg, 0, 64);
                 continue;
             }
+            const bool l2m = idx->metric == LEMON_METRIC_L2;
             switch (qs ? dpad_h / BKH : 0) {
-                case 4:  hipLaunchKernelGGL((k_scan_bf16_qs<4, false>), dim3(grid), dim3(NT), 0, stream, p); break;
-                case 8:  hipLaunchKernelGGL((k_scan_bf16_qs<8, false>), dim3(grid), dim3(NT), 0, stream, p); break;
-                case 12: hipLaunchKernelGGL((k_scan_bf16_qs<12, false>), dim3(grid), dim3(NT), 0, stream, p); break;
+                case 4:
+                    if (l2m) hipLaunchKernelGGL((k_scan_bf16_qs<4, true, false>), dim3(grid), dim3(NT), 0, stream, p);
+                    else     hipLaunchKernelGGL((k_scan_bf16_qs<4, false, false>), dim3(grid), dim3(NT), 0, stream, p);
+                    break;
+                case 8:
+                    if (l2m) hipLaunchKernelGGL((k_scan_bf16_qs<8, true, false>), dim3(grid), dim3(NT), 0, stream, p);
+                    else     hipLaunchKernelGGL((k_scan_bf16_qs<8, false, false>), dim3(grid), dim3(NT), 0, stream, p);
+                    break;
+                case 12:
+                    if (l2m) hipLaunchKernelGGL((k_scan_bf16_qs<12, true, false>), dim3(grid), dim3(NT), 0, stream, p);
+                    else     hipLaunchKernelGGL((k_scan_bf16_qs<12, false, false>), dim3(grid), dim3(NT), 0, stream, p);
+                    break;
                 default: hipLaunchKernelGGL(k_scan_bf16, dim3(grid), dim3(NT), 0, stream, p); break;
             }
         }

@@ -110,4 +110,5 @@ int lemon_launch_merge(const u64 *part, int splits, int64_t nq_pad, int64_t nq, 
                        int64_t *I, hipStream_t stream);
 int lemon_fill_empty(float *D, int64_t *I, int64_t total, int metric, hipStream_t stream);
 void lemon_plan_splits(int panels, int n_tiles, int *splits, int *tiles_per_split);
-int lemon_ensure_search_ws(lemon_index_t *idx, int64_t nq_pad, int splits, int qp_cols_bytes, hipStream_t stream);
+int lemon_ensure_search_ws(lemon_index_t *idx, int64_t nq_pad, int splits, int qp_row_bytes, int cand_cap,
+                           hipStream_t stream);

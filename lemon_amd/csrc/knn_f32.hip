@@ -305,9 +305,10 @@ void lemon_plan_splits(int panels, int n_tiles, int *splits_out, int *tiles_per_
 }
 
 // qp_row_bytes: bytes of one staged query row (dpad*4 for the fp32 scan, dpad_h*2 for the bf16 one)
-int lemon_ensure_search_ws(lemon_index_t *idx, int64_t nq_pad, int splits, int qp_row_bytes, hipStream_t stream) {
+int lemon_ensure_search_ws(lemon_index_t *idx, int64_t nq_pad, int splits, int qp_row_bytes, int cand_cap,
+                           hipStream_t stream) {
     const int64_t part_elems = (splits > 1) ? (int64_t)splits * nq_pad * LEMON_MAX_K : 0;
-    const int64_t cand_rows = nq_pad * splits;
+    const int64_t cand_rows = nq_pad * splits * (cand_cap / CAP);   // in units of CAP-entry rows
     int64_t row_bytes = (int64_t)idx->dpad * 4 > qp_row_bytes ? (int64_t)idx->dpad * 4 : qp_row_bytes;
     if (row_bytes < idx->ws_qp_row_bytes) row_bytes = idx->ws_qp_row_bytes;
     if (nq_pad > idx->ws_q || row_bytes > idx->ws_qp_row_bytes) {
@@ -361,7 +362,7 @@ int lemon_search_f32(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, 
         int splits, tiles_per_split;
         lemon_plan_splits(panels, n_tiles, &splits, &tiles_per_split);
 
-        int rc = lemon_ensure_search_ws(idx, nq_pad, splits, dpad * 4, stream);
+        int rc = lemon_ensure_search_ws(idx, nq_pad, splits, dpad * 4, CAP, stream);
         if (rc) return rc;
         // permuted, zero-padded query panel (+ chain norms for L2)
         LEMON_HIP_CHECK(hipMemsetAsync(idx->ws_qp, 0, (size_t)nq_pad * dpad * sizeof(float), stream));
