@@ -88,7 +88,7 @@ struct ScanParamsH {
     // for every query panel, so that the chunk is re-read from the 256 MiB Infinity Cache instead of
     // HBM; per-query state (list length, admission bound) lives in `state` between launches
     int chunk_t0, chunk_t1, first_chunk, last_chunk;
-    float *state;              // [grid*BQ][2]: {cnt as float bits, thr_key}
+    float *state;              // [grid*256 lanes][4]: {half-list count, last compacted length, thr_key, -}
     int ablate;                // diagnostics only (LEMON_ABLATE): 1 = skip the filter epilogue, 2 = skip maintenance
     unsigned long long *phase_dbg;   // diagnostic builds only: [grid][4] cycle sums (loop, epilogue, sync, maintain)
 };
@@ -465,13 +465,16 @@ __global__ __launch_bounds__(NT, 2) void k_scan_bf16(ScanParamsH p) {
 // each lane (col = lane&31), so the admission threshold is a per-lane scalar: a 16-value v_max3
 // tree + one compare per accumulator tile instead of a compare+branch per element.
 // ======================================================================================
-// one 32x32 accumulator tile: a[e] = s~(db row jb + (e&3) + 8(e>>2), this lane's query).
-// Survivors go to the query's LDS append buffer (no VMEM store in the steady state, so the DMA queue
-// never has to be drained for them); if the buffer is full they go straight to the global list.
+// ---- Q-stationary candidate bookkeeping: everything lane-private --------------------------------
+// A query is owned by the lane pair (l, l+32) of one wavefront; each of the two lanes appends to its
+// OWN half of the query's list (256 entries each) with its count in a VGPR: an append is one
+// predicated global store, no atomic, no LDS, no wait.  Thresholds live in VGPRs too.
+
+// one 32x32 accumulator tile: a[e] = s~(db row jb + (e&3) + 8(e>>2), this lane's query)
 template <bool l2>
 __device__ __forceinline__ void qs_filter_tile(f32x16 a, float th, int64_t jb, float qn,
-                                               const float *__restrict__ xnorm, int64_t n, int *acnt, u64 *abuf,
-                                               int *cnt, u64 *__restrict__ list) {
+                                               const float *__restrict__ xnorm, int64_t n, int &ccnt,
+                                               u64 *__restrict__ mylist) {
     if (l2) {   // monotone proxy of the key -D: 2 s~ - |x|^2 = key + |q|^2 (th carries the same offset)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -494,13 +497,83 @@ __device__ __forceinline__ void qs_filter_tile(f32x16 a, float th, int64_t jb, f
             if (a[e] > th && j < n) {
                 // approximate key: for L2 the clamped -D~ = min(0, proxy - |q|^2)
                 const float s = l2 ? fminf(0.0f, a[e] - qn) : a[e];
-                const u64 key = lemon_make_key(s, (u32)j);
-                const int slot = lds_inc_rtn(lds_off(acnt));
-                if (slot < ABUF) lds_store_b64(lds_off(abuf) + 8u * (unsigned)slot, key);
-                else list[atomicAdd(cnt, 1)] = key;      // (rare: warm-up / concentrated data)
+                mylist[ccnt++] = lemon_make_key(s, (u32)j);
             }
         }
     }
+}
+
+// entry idx (0..511) of a query's pair of half-lists holding n0 / n1 keys
+__device__ __forceinline__ u64 qs_load_slot(const u64 *__restrict__ list, int idx, int n0, int n1) {
+    const bool ok = idx < CAPH / 2 ? idx < n0 : (idx - CAPH / 2) < n1;
+    return ok ? list[idx] : 0;
+}
+
+// light compaction of one query (both half-lists): bisection for the k-th largest approximate score,
+// keep what can still matter, packed at the front of half-list 0 (then half-list 1).  Returns kept.
+__device__ __forceinline__ int qs_compact_light(u64 *__restrict__ list, int n0, int n1, int kk, float eps, int lane,
+                                                float *lo_out) {
+    u64 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = qs_load_slot(list, lane + 64 * i, n0, n1);
+    u32 o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (u32)(v[i] >> 32);
+    u32 t = 0;
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; --bit) {
+        const u32 cand = t | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c += __builtin_popcountll(__ballot(o[i] >= cand));
+        if (c >= kk) t = cand;
+    }
+    const float lo = bound_from_tau(lemon_ord2f(t), eps);
+    const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool keep = v[i] && lemon_key_score(v[i]) > lo;
+        const u64 m = __ballot(keep);
+        if (keep) list[base + __builtin_popcountll(m & below)] = v[i];   // contiguous over both halves
+        base += __builtin_popcountll(m);
+    }
+    *lo_out = lo;
+    return base;
+}
+
+// exact compaction of one query: re-score every entry of both half-lists with the fp32 chain, leave the
+// exact top-kk (sorted, exact keys) at the front of half-list 0.  Returns how many exist (<= kk).
+__device__ __forceinline__ int qs_compact_exact(const ScanParamsH &p, u64 *__restrict__ list, int n0, int n1, int64_t q,
+                                                float qn, int lane, u64 *__restrict__ sk, u64 *__restrict__ sb,
+                                                u64 *kth_out) {
+    const int kk = p.b.kk;
+    const float *qrow = p.q + q * (int64_t)p.d;
+    const bool l2 = p.b.metric == LEMON_METRIC_L2;
+    u64 best = 0;
+#pragma unroll 1
+    for (int base = 0; base < CAPH; base += 64) {
+        if (base < CAPH / 2 ? base >= n0 : (base - CAPH / 2) >= n1) continue;     // wave-uniform skip
+        const u64 old = qs_load_slot(list, base + lane, n0, n1);
+        u64 key = 0;
+        if (old) {
+            const u32 j = lemon_key_index(old);
+            const float *xrow = p.x + (int64_t)j * p.d;
+            const float s = exact_score(qrow, xrow, p.d, l2, qn, l2 ? p.b.xnorm[j] : 0.0f);
+            key = (s == s) ? lemon_make_key(s, j) : 0;
+        }
+        const Ranked r = wave_rank_keys(best, key, 0, 0, 128, sk, lane);
+        sb[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (best && r.r0 < kk) sb[r.r0] = best;
+        if (key && r.r1 < kk) sb[r.r1] = key;
+        __builtin_amdgcn_wave_barrier();
+        best = sb[lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < kk) list[lane] = best;
+    *kth_out = __shfl(best, kk - 1);
+    return __builtin_popcountll(__ballot(best != 0));
 }
 
 // LDS-DMA of one 16 KB X stage (128 rows x 128 B): each wave moves its 32 rows with four 1-KiB
@@ -538,27 +611,15 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
     unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ts = 0;
 #define PH_STAMP(acc) do { if (PROF) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - ts; ts = now_; } } while (0)
     constexpr int KS = 4 * KT;                 // 16-wide k steps
-    constexpr int NB = 8;                      // LDS stage ring (128 KB); NB-1 stages of DMA in flight:
-    constexpr int LA = NB - 1;                 // HBM latency x bandwidth needs ~100 KB in flight per CU
-    // ONE shared array (a second __shared__ object next to LDS-DMA staging makes hipcc drain vmcnt
-    // before every k-step's first ds_read: guide 5, trap (a))
-    // ONE shared array.  Two hipcc behaviours shape this (ROCm 7.2):
-    //  * with the DMA ring as its own __shared__ object the compiler KNOWS every ds_read of it aliases
-    //    the in-flight LDS-DMA and emits s_waitcnt vmcnt(0) before each k-step (guide 5, trap (a));
-    //  * inside one array it instead orders every compiler-generated LDS WRITE/ATOMIC behind
-    //    vmcnt(0) (possible WAW with a DMA destination) -- which drained the 7-stage queue on every
-    //    candidate append.  The steady-state appends therefore use inline-asm DS ops (lds_* helpers).
-    __shared__ __attribute__((aligned(16))) float smem[NB * BX * BK + 7 * BQ + 2 * BQ * ABUF + (NT / 64) * (512 + 128)];
+    constexpr int NB = 8;                      // LDS stage ring (128 KB); NB-1 stages of DMA in flight
+    constexpr int LA = NB - 1;
+    // ONE shared array (with the DMA ring as its own object hipcc drains vmcnt before every k-step's
+    // first ds_read: guide 5, trap (a)).  Candidate state is NOT in LDS: see the note above qs_filter_tile.
+    __shared__ __attribute__((aligned(16))) float smem[NB * BX * BK + 2 * BQ + (NT / 64) * (512 + 128)];
     float *s_x = smem;                                   // [NB][128*32]
-    float *s_thr_lo = smem + NB * BX * BK;               // [128] bound the epilogue compares against
-    float *s_qn = s_thr_lo + BQ;
-    float *s_eps = s_qn + BQ;
-    float *s_thr_key = s_eps + BQ;                       // [128] same bound in key units (L2: without |q|^2)
-    int *s_cnt = reinterpret_cast<int *>(s_thr_key + BQ);
-    int *s_acnt = s_cnt + BQ;                            // [128] entries in the LDS append buffer (this tile)
-    int *s_last = s_acnt + BQ;                           // [128] list length right after the last light compaction
-    u64 *s_abuf = reinterpret_cast<u64 *>(s_last + BQ);  // [128][ABUF]
-    u64 *s_keys = s_abuf + BQ * ABUF;                    // [4][256]
+    float *s_qn = smem + NB * BX * BK;                   // [128]
+    float *s_eps = s_qn + BQ;                            // [128]
+    u64 *s_keys = reinterpret_cast<u64 *>(s_eps + BQ);   // [4][256] rank-select scratch
     u64 *s_best = s_keys + (NT / 64) * 256;              // [4][64]
 
     const int tid = threadIdx.x;
@@ -578,25 +639,30 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
     const int dpad = p.dpad_h / 2;             // row pitch in 4-byte words
 
     if (tid < BQ) {
-        const bool valid = q0 + tid < p.b.nq;
         const float qn = p.b.qnorm[q0 + tid];
         s_eps[tid] = band_eps(p, qn, p.qres2[q0 + tid], l2);
         s_qn[tid] = qn;
-        float tk = valid ? -INFINITY : INFINITY;
-        int c0 = 0;
-        if (p.b.splits == 1 && !p.first_chunk) {        // resume this query's state from the last chunk
-            c0 = __float_as_int(p.state[2 * ((int64_t)blockIdx.x * BQ + tid)]);
-            tk = p.state[2 * ((int64_t)blockIdx.x * BQ + tid) + 1];
-        }
-        s_thr_key[tid] = tk;
-        s_thr_lo[tid] = (l2 && tk != -INFINITY && tk != INFINITY) ? (tk + qn) - (fabsf(tk) + qn) * 2.4e-7f - 1e-37f : tk;
-        s_cnt[tid] = c0;
-        s_acnt[tid] = 0;
-        s_last[tid] = c0;
     }
 
-    // ---- stationary operand: this lane's query row, all k ----
+    // ---- lane-private candidate state: query = 32*wave + (lane&31), half-list h = lane>>5 ----
     const int qrow_l = 32 * wave + l31;
+    const bool qvalid = q0 + qrow_l < p.b.nq;
+    const float my_qn = p.b.qnorm[q0 + qrow_l];
+    u64 *cand_panel = p.b.cand + (int64_t)blockIdx.x * BQ * CAPH;
+    u64 *mylist = cand_panel + (int64_t)qrow_l * CAPH + h * (CAPH / 2);
+    int ccnt = 0, clast = 0;                   // entries in my half-list; pair length right after the last compaction
+    float thkey = qvalid ? -INFINITY : INFINITY;   // admission bound in key units (shared by the pair)
+    if (p.b.splits == 1 && !p.first_chunk) {   // resume from the previous database chunk
+        const float *st = p.state + 4 * ((int64_t)blockIdx.x * NT + tid);
+        ccnt = __float_as_int(st[0]); clast = __float_as_int(st[1]); thkey = st[2];
+    }
+    auto th_of = [&](float tk) -> float {      // what the epilogue compares against (L2: proxy carries +|q|^2)
+        if (!l2 || tk == -INFINITY || tk == INFINITY) return tk;
+        return (tk + my_qn) - (fabsf(tk) + my_qn) * 2.4e-7f - 1e-37f;
+    };
+    float th = th_of(thkey);
+
+    // ---- stationary operand: this lane's query row, all k ----
     bf16x8 qf[KS];
     {
         const __bf16 *qsrc = p.qh + (q0 + qrow_l) * (int64_t)p.dpad_h + 8 * h;
@@ -607,20 +673,14 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
     f32x16 acc0, acc1, acc2, acc3;
 
     const float *xbase = reinterpret_cast<const float *>(p.xh + (int64_t)t_begin * BX * p.dpad_h);
-    const int total = ntile * KT;              // >= 4
-    // stage s -> ring slot s & (NB-1).  Prologue: stages 0..LA-1 in flight, wait for stage 0.
-    // stage s of this launch covers k-slice (s % KT) of tile (s / KT)
+    const int total = ntile * KT;
+    // stage s -> ring slot s & (NB-1); stage s covers k-slice (s % KT) of tile (s / KT)
 #pragma unroll
     for (int s0 = 0; s0 < LA; ++s0)
         if (s0 < total)
             qs_dma_stage(xbase + (int64_t)(s0 / KT) * BX * dpad + (s0 % KT) * BK, dpad, s_x + s0 * BX * BK, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (prologue only)
     __syncthreads();
-
-    u64 *cand_panel = p.b.cand + (int64_t)blockIdx.x * BQ * CAPH;
-    u64 *my_list = cand_panel + (int64_t)qrow_l * CAPH;
-    u64 *my_abuf = s_abuf + qrow_l * ABUF;
-    const float my_qn = l2 ? p.b.qnorm[q0 + qrow_l] : 0.0f;
 
     if (PROF) ts = __builtin_amdgcn_s_memtime();
     for (int jl = 0; jl < ntile; ++jl) {
@@ -630,7 +690,7 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
             const int t = jl * KT + kt;
             const bool more = t + LA < total;
             if (more) {   // stage t+LA into the slot stage t-1 was read from (everyone passed last barrier)
-                const int kn = kt + LA;       // k-slice index relative to this tile (may run into later tiles)
+                const int kn = kt + LA;
                 const float *src = xt + (int64_t)(kn / KT) * BX * dpad + (kn % KT) * BK;
                 qs_dma_stage(src, dpad, s_x + ((t + LA) & (NB - 1)) * BX * BK, wave, lane);
             }
@@ -655,20 +715,47 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
                 // 16-pass MFMA latency here (once per tile)
                 asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc0), "+a"(acc1), "+a"(acc2), "+a"(acc3));
                 // ---- epilogue: acc[ni][e] = s~(db row 32ni + (e&3) + 8(e>>2) + 4h, query lane&31) ----
-                const float th = s_thr_lo[qrow_l];
                 const int64_t jb = (int64_t)(t_begin + jl) * BX + 4 * h;
-                qs_filter_tile<l2>(acc0, th, jb, my_qn, p.b.xnorm, p.b.n, &s_acnt[qrow_l], my_abuf, &s_cnt[qrow_l], my_list);
-                qs_filter_tile<l2>(acc1, th, jb + 32, my_qn, p.b.xnorm, p.b.n, &s_acnt[qrow_l], my_abuf, &s_cnt[qrow_l], my_list);
-                qs_filter_tile<l2>(acc2, th, jb + 64, my_qn, p.b.xnorm, p.b.n, &s_acnt[qrow_l], my_abuf, &s_cnt[qrow_l], my_list);
-                qs_filter_tile<l2>(acc3, th, jb + 96, my_qn, p.b.xnorm, p.b.n, &s_acnt[qrow_l], my_abuf, &s_cnt[qrow_l], my_list);
+                qs_filter_tile<l2>(acc0, th, jb, my_qn, p.b.xnorm, p.b.n, ccnt, mylist);
+                qs_filter_tile<l2>(acc1, th, jb + 32, my_qn, p.b.xnorm, p.b.n, ccnt, mylist);
+                qs_filter_tile<l2>(acc2, th, jb + 64, my_qn, p.b.xnorm, p.b.n, ccnt, mylist);
+                qs_filter_tile<l2>(acc3, th, jb + 96, my_qn, p.b.xnorm, p.b.n, ccnt, mylist);
                 PH_STAMP(ph1);
-            }
-            if (kt == KT - 1 && !(p.ablate & 2)) {
-                // candidate state of a query is touched only by the wave that owns it: no rendezvous needed
-                const bool last_tile = (jl + 1 == ntile);
-                maintain_rows(p, cand_panel, wave, lane, q0, final_pass && last_tile, last_tile, s_cnt, s_thr_lo,
-                              s_thr_key, s_eps, s_qn, s_keys + wave * 256, s_best + wave * 64, l2, s_acnt, s_abuf, s_last, PROF ? p.phase_dbg : nullptr);
-                PH_STAMP(ph3);
+
+                // ---- maintenance: which queries need a (light) compaction? ----
+                const int pair = ccnt + __shfl_xor(ccnt, 32);
+                const bool warm = thkey == -INFINITY && pair >= p.b.kk;
+                const bool stale = pair >= p.b.kk && pair - clast >= REFRESH;
+                const bool full = ccnt > CAPH / 2 - BX / 2;           // my half could overflow on the next tile
+                u64 todo = __ballot(qvalid && (warm || stale || full));
+                todo = (todo | (todo >> 32)) & 0xffffffffull;          // one bit per query of this wave
+                if (todo) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this tile's candidate stores must be visible
+                    do {
+                        const int r = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1;
+                        const int row = 32 * wave + r;
+                        u64 *list = cand_panel + (int64_t)row * CAPH;
+                        const int n0 = __builtin_amdgcn_readlane(ccnt, r), n1 = __builtin_amdgcn_readlane(ccnt, r + 32);
+                        float lo;
+                        int kept = qs_compact_light(list, n0, n1, p.b.kk, s_eps[row], lane, &lo);
+                        if (kept > CAPH / 2 - BX / 2) {    // the band itself does not fit: settle it exactly
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            const int k0 = kept < CAPH / 2 ? kept : CAPH / 2;
+                            u64 kth;
+                            kept = qs_compact_exact(p, list, k0, kept - k0, q0 + row, s_qn[row], lane,
+                                                    s_keys + wave * 256, s_best + wave * 64, &kth);
+                            if (kept == p.b.kk) lo = bound_from_tau(lemon_key_score(kth), s_eps[row]);
+                        }
+                        if (l31 == r) {                    // both lanes of the pair take the new state
+                            ccnt = h == 0 ? kept : 0;      // (kept <= CAPH/2 - BX/2 here: all in half-list 0)
+                            clast = kept;
+                            thkey = lo;
+                            th = th_of(lo);
+                        }
+                    } while (todo);
+                    PH_STAMP(ph3);
+                }
             }
             // stage t+1 must have landed (all waves' parts) before anyone reads it: at most the LA-1
             // youngest stages (4 DMA instructions each) may still be in flight, then rendezvous
@@ -685,19 +772,24 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
         atomicAdd(&p.phase_dbg[2], ph2); atomicAdd(&p.phase_dbg[3], ph3);
     }
 #undef PH_STAMP
-    if (!final_pass) {      // park the per-query state for the next database chunk
-        if (tid < BQ) {
-            p.state[2 * ((int64_t)blockIdx.x * BQ + tid)] = __int_as_float(s_cnt[tid]);
-            p.state[2 * ((int64_t)blockIdx.x * BQ + tid) + 1] = s_thr_key[tid];
-        }
+    if (!final_pass) {      // park the lane-private state for the next database chunk
+        float *st = p.state + 4 * ((int64_t)blockIdx.x * NT + tid);
+        st[0] = __int_as_float(ccnt); st[1] = __int_as_float(clast); st[2] = thkey;
         return;
     }
+    // ---- final pass: exact re-scoring + exact top-k of every query, then the result rows ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int r = 0; r < 32; ++r) {
         const int row = 32 * wave + r;
         const int64_t q = q0 + row;
-        if (q >= p.b.nq) continue;
-        const int kept = s_cnt[row];
-        const u64 key = (lane < kept && lane < p.b.kk) ? cand_panel[(int64_t)row * CAPH + lane] : 0;
+        if (q >= p.b.nq) break;
+        u64 *list = cand_panel + (int64_t)row * CAPH;
+        const int n0 = __builtin_amdgcn_readlane(ccnt, r), n1 = __builtin_amdgcn_readlane(ccnt, r + 32);
+        u64 kth;
+        const int have = qs_compact_exact(p, list, n0, n1, q, s_qn[row], lane, s_keys + wave * 256,
+                                          s_best + wave * 64, &kth);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const u64 key = (lane < have && lane < p.b.kk) ? list[lane] : 0;
         write_out_row(p.b, split, q, lane, key);
     }
 }
@@ -803,15 +895,15 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
                 if (chunk_tiles < 8) chunk_tiles = 8;
             }
             if (chunk_tiles > n_tiles) chunk_tiles = n_tiles;
-            if ((int64_t)grid * BQ * 2 > idx->ws_state_elems) {
+            if ((int64_t)grid * NT * 4 > idx->ws_state_elems) {
                 LEMON_HIP_CHECK(hipStreamSynchronize(stream));
                 if (idx->ws_state) (void)hipFree(idx->ws_state);
                 idx->ws_state = nullptr; idx->ws_state_elems = 0;
-                if (hipMalloc(&idx->ws_state, (size_t)grid * BQ * 2 * sizeof(float)) != hipSuccess) {
+                if (hipMalloc(&idx->ws_state, (size_t)grid * NT * 4 * sizeof(float)) != hipSuccess) {
                     lemon_set_error("scan state allocation failed");
                     return LEMON_E_NOMEM;
                 }
-                idx->ws_state_elems = (int64_t)grid * BQ * 2;
+                idx->ws_state_elems = (int64_t)grid * NT * 4;
             }
         }
         p.state = idx->ws_state;
@@ -830,8 +922,7 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
                 hipLaunchKernelGGL((k_scan_bf16_qs<12, false, true>), dim3(grid), dim3(NT), 0, stream, p);
                 (void)hipStreamSynchronize(stream);
                 unsigned long long h[8]; (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
-                fprintf(stderr, "[phase] per query: light compactions=%.1f (avg n=%.0f -> kept=%.0f), flushes=%.1f\n",
-                        (double)h[4] / cn, h[4] ? (double)h[5] / h[4] : 0.0, h[4] ? (double)h[6] / h[4] : 0.0, (double)h[7] / cn);
+
                 const double tot = (double)(h[0] + h[1] + h[2] + h[3]);
                 fprintf(stderr, "[phase] grid=%u loop=%.1f%% epilogue=%.1f%% sync=%.1f%% maintain=%.1f%% total=%.3g cyc/WG=%.3g\n",
                         grid, 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, tot, tot / grid);
