@@ -490,14 +490,20 @@ __device__ __forceinline__ void qs_filter_tile(f32x16 a, float th, int64_t jb, f
     const float m2 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11]));
     const float m3 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
     const float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-    if (m > th) {
+    if (m > th) {                                   // some lane of the wave has a survivor in this tile
+        const float mq[4] = {m0, m1, m2, m3};
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int64_t j = jb + (e & 3) + 8 * (e >> 2);
-            if (a[e] > th && j < n) {
-                // approximate key: for L2 the clamped -D~ = min(0, proxy - |q|^2)
-                const float s = l2 ? fminf(0.0f, a[e] - qn) : a[e];
-                mylist[ccnt++] = lemon_make_key(s, (u32)j);
+        for (int g = 0; g < 4; ++g) {
+            if (mq[g] > th) {                       // ... in this quad of rows
+#pragma unroll
+                for (int e = 4 * g; e < 4 * g + 4; ++e) {
+                    const int64_t j = jb + (e & 3) + 8 * (e >> 2);
+                    if (a[e] > th && j < n) {
+                        // approximate key: for L2 the clamped -D~ = min(0, proxy - |q|^2)
+                        const float s = l2 ? fminf(0.0f, a[e] - qn) : a[e];
+                        mylist[ccnt++] = lemon_make_key(s, (u32)j);
+                    }
+                }
             }
         }
     }
@@ -611,13 +617,16 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
     unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ts = 0;
 #define PH_STAMP(acc) do { if (PROF) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - ts; ts = now_; } } while (0)
     constexpr int KS = 4 * KT;                 // 16-wide k steps
-    constexpr int NB = 8;                      // LDS stage ring (128 KB); NB-1 stages of DMA in flight
+    constexpr int SUB = 2;                     // 64-wide k-slices per stage: 32 MFMAs per wave between barriers
+    constexpr int KT2 = KT / SUB;              // stages per database tile
+    constexpr int NB = 4;                      // LDS stage ring (4 x 32 KB); NB-1 stages of DMA in flight
     constexpr int LA = NB - 1;
+    constexpr int STG = SUB * BX * BK;         // floats per stage
     // ONE shared array (with the DMA ring as its own object hipcc drains vmcnt before every k-step's
     // first ds_read: guide 5, trap (a)).  Candidate state is NOT in LDS: see the note above qs_filter_tile.
-    __shared__ __attribute__((aligned(16))) float smem[NB * BX * BK + 2 * BQ + (NT / 64) * (512 + 128)];
-    float *s_x = smem;                                   // [NB][128*32]
-    float *s_qn = smem + NB * BX * BK;                   // [128]
+    __shared__ __attribute__((aligned(16))) float smem[NB * STG + 2 * BQ + (NT / 64) * (512 + 128)];
+    float *s_x = smem;                                   // [NB][SUB][128*32]
+    float *s_qn = smem + NB * STG;                       // [128]
     float *s_eps = s_qn + BQ;                            // [128]
     u64 *s_keys = reinterpret_cast<u64 *>(s_eps + BQ);   // [4][256] rank-select scratch
     u64 *s_best = s_keys + (NT / 64) * 256;              // [4][64]
@@ -673,12 +682,16 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
     f32x16 acc0, acc1, acc2, acc3;
 
     const float *xbase = reinterpret_cast<const float *>(p.xh + (int64_t)t_begin * BX * p.dpad_h);
-    const int total = ntile * KT;
-    // stage s -> ring slot s & (NB-1); stage s covers k-slice (s % KT) of tile (s / KT)
+    const int total = ntile * KT2;
+    // stage s -> ring slot s & (NB-1); stage s covers k-slices SUB*(s % KT2) .. +SUB-1 of tile (s / KT2)
+#define QS_ISSUE_STAGE(tile_base, kt2_, slot_)                                                         \
+    do {                                                                                                \
+        _Pragma("unroll") for (int sb_ = 0; sb_ < SUB; ++sb_)                                           \
+            qs_dma_stage((tile_base) + (SUB * (kt2_) + sb_) * BK, dpad, s_x + (slot_) * STG + sb_ * BX * BK, wave, lane); \
+    } while (0)
 #pragma unroll
     for (int s0 = 0; s0 < LA; ++s0)
-        if (s0 < total)
-            qs_dma_stage(xbase + (int64_t)(s0 / KT) * BX * dpad + (s0 % KT) * BK, dpad, s_x + s0 * BX * BK, wave, lane);
+        if (s0 < total) QS_ISSUE_STAGE(xbase + (int64_t)(s0 / KT2) * BX * dpad, s0 % KT2, s0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (prologue only)
     __syncthreads();
 
@@ -686,30 +699,34 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
     for (int jl = 0; jl < ntile; ++jl) {
         const float *xt = xbase + (int64_t)jl * BX * dpad;
 #pragma clang loop unroll(full)
-        for (int kt = 0; kt < KT; ++kt) {
-            const int t = jl * KT + kt;
+        for (int kt = 0; kt < KT2; ++kt) {
+            const int t = jl * KT2 + kt;
             const bool more = t + LA < total;
             if (more) {   // stage t+LA into the slot stage t-1 was read from (everyone passed last barrier)
                 const int kn = kt + LA;
-                const float *src = xt + (int64_t)(kn / KT) * BX * dpad + (kn % KT) * BK;
-                qs_dma_stage(src, dpad, s_x + ((t + LA) & (NB - 1)) * BX * BK, wave, lane);
+                QS_ISSUE_STAGE(xt + (int64_t)(kn / KT2) * BX * dpad, kn % KT2, (t + LA) & (NB - 1));
             }
-            const float *tx = s_x + (t & (NB - 1)) * BX * BK;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bf16x8 a0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(l31, 2 * u + h)]));
-                const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(32 + l31, 2 * u + h)]));
-                const bf16x8 a2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(64 + l31, 2 * u + h)]));
-                const bf16x8 a3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(96 + l31, 2 * u + h)]));
-                if (kt == 0 && u == 0) {
-                    mfma_qs_init(acc0, a0, qf[0]); mfma_qs_init(acc1, a1, qf[0]);
-                    mfma_qs_init(acc2, a2, qf[0]); mfma_qs_init(acc3, a3, qf[0]);
-                } else {
-                    mfma_qs(acc0, a0, qf[4 * kt + u]); mfma_qs(acc1, a1, qf[4 * kt + u]);
-                    mfma_qs(acc2, a2, qf[4 * kt + u]); mfma_qs(acc3, a3, qf[4 * kt + u]);
+            for (int sbk = 0; sbk < SUB; ++sbk) {
+                const float *tx = s_x + (t & (NB - 1)) * STG + sbk * BX * BK;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bf16x8 a0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(l31, 2 * u + h)]));
+                    const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(32 + l31, 2 * u + h)]));
+                    const bf16x8 a2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(64 + l31, 2 * u + h)]));
+                    const bf16x8 a3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(96 + l31, 2 * u + h)]));
+                    constexpr int dummy = 0; (void)dummy;
+                    const int ks = 4 * (SUB * kt + sbk) + u;      // compile-time after unrolling
+                    if (ks == 0) {
+                        mfma_qs_init(acc0, a0, qf[0]); mfma_qs_init(acc1, a1, qf[0]);
+                        mfma_qs_init(acc2, a2, qf[0]); mfma_qs_init(acc3, a3, qf[0]);
+                    } else {
+                        mfma_qs(acc0, a0, qf[ks]); mfma_qs(acc1, a1, qf[ks]);
+                        mfma_qs(acc2, a2, qf[ks]); mfma_qs(acc3, a3, qf[ks]);
+                    }
                 }
             }
-            if (kt == KT - 1 && !(p.ablate & 1)) {
+            if (kt == KT2 - 1 && !(p.ablate & 1)) {
                 PH_STAMP(ph0);
                 // MFMA results are read by VALU next: hipcc pads nothing around asm, so wait out the
                 // 16-pass MFMA latency here (once per tile)
@@ -759,11 +776,11 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
             }
             // stage t+1 must have landed (all waves' parts) before anyone reads it: at most the LA-1
             // youngest stages (4 DMA instructions each) may still be in flight, then rendezvous
-            if (more) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // (LA-1) stages x 2 slices x 4 DMAs
             else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS reads retired
             __builtin_amdgcn_s_barrier();
-            if (kt == KT - 1) PH_STAMP(ph2);
+            if (kt == KT2 - 1) PH_STAMP(ph2);
         }
     }
 
@@ -772,6 +789,7 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
         atomicAdd(&p.phase_dbg[2], ph2); atomicAdd(&p.phase_dbg[3], ph3);
     }
 #undef PH_STAMP
+#undef QS_ISSUE_STAGE
     if (!final_pass) {      // park the lane-private state for the next database chunk
         float *st = p.state + 4 * ((int64_t)blockIdx.x * NT + tid);
         st[0] = __int_as_float(ccnt); st[1] = __int_as_float(clast); st[2] = thkey;
