@@ -91,7 +91,9 @@ const float *lemon_index_data(const lemon_index_t *idx);
  * L2: ascending SQUARED distance max(0, |q|^2+|x|^2-2<q,x>)).  Slots beyond ntotal get
  * I=-1 and D=-FLT_MAX (IP) / +FLT_MAX (L2).  1 <= k <= LEMON_MAX_K.
  * Grows an internal workspace on first use of a larger (nq,k): that first call is not
- * graph-capturable; later calls with nq,k no larger only enqueue kernels. */
+ * graph-capturable; later calls with nq,k no larger only enqueue kernels.  With LEMON_ALGO_AUTO
+ * (default) the first LARGE search (ntotal >= 65536, nq*ntotal >= 8e9, d <= 768) after an add()
+ * runs a small probe search and synchronises the stream once to choose between the two scans. */
 int lemon_index_search(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
                        float *D_dev, int64_t *I_dev, void *stream);
 int lemon_index_set_algo(lemon_index_t *idx, int algo);

@@ -1,6 +1,7 @@
 // api.hip -- C ABI glue: index lifetime, search dispatch, multimodal-neighbour finalisation.
 #include "common.hpp"
 #include <stdlib.h>
+#include <math.h>
 
 static thread_local char g_err[512] = "";
 
@@ -158,6 +159,69 @@ extern "C" int lemon_index_add(lemon_index_t *idx, const float *x_dev, int64_t n
     return LEMON_OK;
 }
 
+// ---- LEMON_ALGO_AUTO ----------------------------------------------------------------------
+// The bf16 filter scan is ~5x faster than the fp32 scan on large, "spread out" data, but its work
+// grows with the number of database rows whose score lies within the rounding band of a query's
+// k-th best: exact duplicates (class prompts: SURVEY 0.9) or tightly concentrated embeddings put
+// hundreds of rows there and every one of them must be re-scored exactly.  AUTO therefore probes:
+// 64 strided queries against 2048 strided database rows with the exact fp32 scan; if the typical
+// probe query sees >= 4 sampled rows within the band of its best one (i.e. >= 4*n/2048 rows at full
+// scale), the data is band-crowded and the fp32 scan is used.  One small search + one host sync, done
+// once per index content (cached until the next add).
+static int lemon_auto_choose(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, hipStream_t stream) {
+    (void)k;
+    const int S = 2048, P = 64, KP = 16;
+    const int d = idx->d;
+    if (d > 768 || idx->n < 65536 || (double)nq * (double)idx->n < 8.0e9) return LEMON_ALGO_F32_MFMA;
+    if (idx->auto_n == idx->n && idx->auto_algo) return idx->auto_algo;
+    int choice = LEMON_ALGO_F32_MFMA;
+    float *xs = nullptr, *qs = nullptr, *Dp = nullptr, *qn = nullptr;
+    int64_t *Ip = nullptr;
+    lemon_index_t *probe = nullptr;
+    const int64_t xstride = idx->n / S, qstride = nq >= P ? nq / P : 1;
+    const int np = nq >= P ? P : (int)nq;
+    do {
+        if (hipMalloc(&xs, (size_t)S * d * 4) != hipSuccess || hipMalloc(&qs, (size_t)P * d * 4) != hipSuccess ||
+            hipMalloc(&Dp, (size_t)P * KP * 4) != hipSuccess || hipMalloc(&Ip, (size_t)P * KP * 8) != hipSuccess ||
+            hipMalloc(&qn, (size_t)P * 4) != hipSuccess) break;
+        if (hipMemcpy2DAsync(xs, (size_t)d * 4, idx->x, (size_t)xstride * d * 4, (size_t)d * 4, S,
+                             hipMemcpyDeviceToDevice, stream) != hipSuccess) break;
+        if (hipMemcpy2DAsync(qs, (size_t)d * 4, q_dev, (size_t)qstride * d * 4, (size_t)d * 4, np,
+                             hipMemcpyDeviceToDevice, stream) != hipSuccess) break;
+        if (lemon_index_create(idx->metric, d, &probe) != LEMON_OK) break;
+        probe->algo = LEMON_ALGO_F32_MFMA;
+        if (lemon_index_add(probe, xs, S, stream) != LEMON_OK) break;
+        if (lemon_search_internal(probe, qs, np, KP, Dp, Ip, stream) != LEMON_OK) break;
+        if (lemon_rowdot_chain(qs, qs, np, d, qn, stream) != LEMON_OK) break;
+        float hD[P * KP], hq[P], hx[S];
+        if (hipMemcpyAsync(hD, Dp, (size_t)np * KP * 4, hipMemcpyDeviceToHost, stream) != hipSuccess) break;
+        if (hipMemcpyAsync(hq, qn, (size_t)np * 4, hipMemcpyDeviceToHost, stream) != hipSuccess) break;
+        if (hipMemcpyAsync(hx, probe->xnorm, (size_t)S * 4, hipMemcpyDeviceToHost, stream) != hipSuccess) break;
+        if (hipStreamSynchronize(stream) != hipSuccess) break;
+        float xn2max = 0.0f;
+        for (int i = 0; i < S; ++i) xn2max = hx[i] > xn2max ? hx[i] : xn2max;
+        int crowded = 0;
+        for (int p = 0; p < np; ++p) {
+            const float eps = 0.004f * sqrtf(hq[p] > 0 ? hq[p] : 0.0f) * sqrtf(xn2max);
+            const float band = (idx->metric == LEMON_METRIC_L2) ? 4.0f * eps : 2.0f * eps;
+            int c = 0;
+            for (int j = 1; j < KP; ++j) {
+                const float gap = (idx->metric == LEMON_METRIC_L2) ? hD[p * KP + j] - hD[p * KP] : hD[p * KP] - hD[p * KP + j];
+                if (gap < band) ++c;
+            }
+            if (c >= 4) ++crowded;
+        }
+        choice = (2 * crowded >= np) ? LEMON_ALGO_F32_MFMA : LEMON_ALGO_BF16_FILTER;
+    } while (0);
+    if (probe) lemon_index_free(probe);
+    void *ptrs[] = {xs, qs, Dp, Ip, qn};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    idx->auto_algo = choice;
+    idx->auto_n = idx->n;
+    return choice;
+}
+
 int lemon_search_internal(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, float *D_dev,
                           int64_t *I_dev, hipStream_t stream) {
     LEMON_REQUIRE(idx != nullptr, "index handle");
@@ -166,7 +230,7 @@ int lemon_search_internal(lemon_index_t *idx, const float *q_dev, int64_t nq, in
     if (nq == 0) return LEMON_OK;
     LEMON_REQUIRE(q_dev && D_dev && I_dev, "null pointer");
     int algo = idx->algo;
-    if (algo == LEMON_ALGO_AUTO) algo = LEMON_ALGO_F32_MFMA;
+    if (algo == LEMON_ALGO_AUTO) algo = lemon_auto_choose(idx, q_dev, nq, k, stream);
     if (algo == LEMON_ALGO_BF16_FILTER) return lemon_search_bf16(idx, q_dev, nq, k, D_dev, I_dev, stream);
     return lemon_search_f32(idx, q_dev, nq, k, D_dev, I_dev, stream);
 }

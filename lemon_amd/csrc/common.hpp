@@ -70,6 +70,9 @@ struct lemon_index {
     float *ws_D;          // [ws_nb]
     int64_t *ws_I;        // [ws_nb]
     lemon_search_info_t last;
+    // LEMON_ALGO_AUTO decision cache (valid while auto_n == n)
+    int auto_algo;
+    int64_t auto_n;
     // optional scan-kernel timing (lemon_index_set_profiling)
     int profiling;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> *prof_events;

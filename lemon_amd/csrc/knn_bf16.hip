@@ -29,7 +29,6 @@ namespace {
 
 constexpr int BKH = 64;   // bf16 k-slice per LDS stage (128 B rows, like fp32 BK=32)
 constexpr int CAPH = 512; // candidate slots per query (approximate keys): 8 per lane in a light compaction
-constexpr int ABUF = 8;   // per-query LDS append buffer of the Q-stationary kernel (entries)
 constexpr int REFRESH = 64; // light-compact a list after this many new candidates: the admission bound then
                             // tracks the running k-th best closely (appends ~ k ln(N/k) instead of 3-4x that)
 
@@ -128,66 +127,42 @@ __device__ __forceinline__ float exact_score(const float *__restrict__ q, const 
     return acc;
 }
 
-// LDS ops the compiler must not see as LDS writes (see the note on `smem` in k_scan_bf16_qs).  LDS
-// instructions of one wave execute in order, so later compiler-generated reads observe these writes.
-__device__ __forceinline__ unsigned lds_off(const void *p) {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
-}
-__device__ __forceinline__ int lds_inc_rtn(unsigned addr) {
-    int r;
-    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr), "v"(1) : "memory");
-    return r;
-}
-__device__ __forceinline__ void lds_store_b64(unsigned addr, u64 v) {
-    asm volatile("ds_write_b64 %0, %1\n\ts_nop 1" ::"v"(addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ void lds_store_b32(unsigned addr, int v) {
-    asm volatile("ds_write_b32 %0, %1\n\ts_nop 1" ::"v"(addr), "v"(v) : "memory");
-}
-
 // admission bound from tau (k-th largest approximate score): rows with s~ <= tau - 2 eps are out
 __device__ __forceinline__ float bound_from_tau(float tau, float eps) {
     const float lo = tau - 2.0f * eps;
     return lo - fabsf(lo) * 2.4e-7f - 1e-37f;          // rounded DOWN
 }
 
-// "light" compaction of one query's approximate-key list: no database access, no sort.
+// "light" compaction of one query's approximate-key list (streaming kernel): no database access, no sort.
 //   1. tau = k-th largest approximate score, by a 32-step bisection on the order-preserving score bits
-//      (each step: 9 compares + 9 ballots per lane) -- O(32 n/64) instead of the O(n^2/64) rank-select;
+//      (each step: 8 compares + 8 ballots per lane) -- O(32 n/64) instead of the O(n^2/64) rank-select;
 //   2. every key that can still be in the exact top-k (s~ > tau - 2 eps) is stream-compacted to the
 //      front of the list (ballot prefix sums; order does not matter until the final exact pass);
 //   3. the admission bound is refreshed.  Returns the number of keys kept.
-// Input: n keys in the global list (<= CAPH = 8 per lane) + na keys in the LDS append buffer `abuf`
-// (this tile's appends, na <= ABUF; may be nullptr/0).
 __device__ __forceinline__ int compact_light(u64 *__restrict__ list, int *cnt, float *thr_lo, float *thr_key,
-                                             int row, int kk, float eps, int lane, const u64 *abuf, int na) {
+                                             int row, int kk, float eps, int lane) {
     const int n = __builtin_amdgcn_readfirstlane(cnt[row]);
-    u64 v[9];
+    if (n < kk) return n;
+    u64 v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (lane + 64 * i < n) ? list[lane + 64 * i] : 0;
-    v[8] = (lane < na) ? abuf[lane] : 0;
-    if (n + na < kk) {                                  // nothing can be dropped yet: just append the buffer
-        if (lane < na) list[n + lane] = v[8];
-        if (lane == 0) cnt[row] = n + na;
-        return n + na;
-    }
-    u32 o[9];
+    u32 o[8];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) o[i] = (u32)(v[i] >> 32);
+    for (int i = 0; i < 8; ++i) o[i] = (u32)(v[i] >> 32);
     u32 t = 0;                                          // largest t with #{ord >= t} >= kk  ==  kk-th largest ord
 #pragma unroll 1
     for (int bit = 31; bit >= 0; --bit) {
         const u32 cand = t | (1u << bit);
         int c = 0;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) c += __builtin_popcountll(__ballot(o[i] >= cand));
+        for (int i = 0; i < 8; ++i) c += __builtin_popcountll(__ballot(o[i] >= cand));
         if (c >= kk) t = cand;                          // wave-uniform
     }
     const float lo = bound_from_tau(lemon_ord2f(t), eps);
     const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int base = 0;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
+    for (int i = 0; i < 8; ++i) {
         const bool keep = v[i] && lemon_key_score(v[i]) > lo;
         const u64 m = __ballot(keep);
         if (keep) list[base + __builtin_popcountll(m & below)] = v[i];
@@ -235,64 +210,32 @@ __device__ __forceinline__ void compact_exact(const ScanParamsH &p, u64 *__restr
     }
 }
 
-// shared post-tile maintenance for the 32 query rows of one wavefront.  Lane r inspects row r; only
-// the rows that need work are visited (most tiles: none).  s_acnt/s_abuf: the Q-stationary kernel's
-// per-query LDS append buffers (nullptr for the streaming kernel, which appends to the list directly).
-// flush_all: end of a launch -- everything buffered must reach the global list.
+// post-tile maintenance of the streaming kernel for the 32 query rows of one wavefront.  Lane r inspects
+// row r; only the rows that need work are visited.
 __device__ __forceinline__ void maintain_rows(const ScanParamsH &p, u64 *__restrict__ cand_panel, int wave, int lane,
-                                              int64_t q0, bool last, bool flush_all, int *s_cnt, float *s_thr_lo,
-                                              float *s_thr_key, const float *s_eps, const float *s_qn, u64 *sk, u64 *sb,
-                                              bool bias_qn, int *s_acnt, u64 *s_abuf, int *s_last,
-                                              unsigned long long *dbg = nullptr) {
+                                              int64_t q0, bool last, int *s_cnt, int *s_last, float *s_thr_lo,
+                                              float *s_thr_key, const float *s_eps, const float *s_qn, u64 *sk, u64 *sb) {
     bool need = false;
     if (lane < 32) {
         const int row = 32 * wave + lane;
         const int c = s_cnt[row];
-        const int a = s_acnt ? s_acnt[row] : 0;
-        const bool warm = (c + (a < ABUF ? a : ABUF) >= p.b.kk) && s_thr_key[row] == -INFINITY;
-        const bool stale = s_last && (c + a - s_last[row] >= REFRESH) && (c + a >= p.b.kk);
-        need = (last || flush_all) ? (c + a > 0) : (c + a > CAPH - BX - ABUF || warm || stale || a >= ABUF - 2);
+        const bool warm = c >= p.b.kk && s_thr_key[row] == -INFINITY;
+        const bool stale = c >= p.b.kk && c - s_last[row] >= REFRESH;
+        need = last ? (c > 0) : (c > CAPH - BX || warm || stale);
     }
     u64 todo = __ballot(need);
-    if (todo == 0) return;
-    // a row whose buffer overflowed this tile appended straight to the global list: those stores (and,
-    // at the end of a launch, everything) must be visible to the lanes that compact it
-    bool ovf = false;
-    if (s_acnt && lane < 32) ovf = s_acnt[32 * wave + lane] > ABUF;
-    if (__ballot(ovf) || last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     while (todo) {
         const int r = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
         const int row = 32 * wave + r;                  // wave-uniform (todo is a ballot)
         u64 *list = cand_panel + (int64_t)row * CAPH;
         const float eps = s_eps[row];
-        int a = s_acnt ? s_acnt[row] : 0;
-        if (a > ABUF) a = ABUF;                          // the overflow part is already in the list
-        const u64 *abuf = s_abuf ? s_abuf + row * ABUF : nullptr;
-        const int c = __builtin_amdgcn_readfirstlane(s_cnt[row]);
-        const bool warm = (c + a >= p.b.kk) && s_thr_key[row] == -INFINITY;
-        const bool stale = s_last && (c + a - s_last[row] >= REFRESH) && (c + a >= p.b.kk);
-        if (!last && (c + a > CAPH - BX - ABUF || warm || stale)) {
-            const int kept = compact_light(list, s_cnt, s_thr_lo, s_thr_key, row, p.b.kk, eps, lane, abuf, a);
-            if (s_last && lane == 0) s_last[row] = kept;
-            if (dbg && lane == 0) { atomicAdd(dbg + 4, 1ull); atomicAdd(dbg + 5, (unsigned long long)(c + a)); atomicAdd(dbg + 6, (unsigned long long)kept); }
-            if (kept > CAPH - BX - ABUF) {               // the band itself does not fit: settle it exactly
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!last) {
+            const int kept = compact_light(list, s_cnt, s_thr_lo, s_thr_key, row, p.b.kk, eps, lane);
+            if (lane == 0) s_last[row] = kept;
+            if (kept > CAPH - BX)                        // the band itself does not fit: settle it exactly
                 compact_exact(p, list, s_cnt, s_thr_lo, s_thr_key, row, q0 + row, eps, s_qn[row], lane, sk, sb);
-            }
-            // Q-stationary L2 filter compares 2 s~ - |x|^2 = key + |q|^2
-            if (bias_qn && lane == 0 && s_thr_key[row] != -INFINITY) {
-                const float b = s_qn[row], lo = s_thr_key[row];
-                s_thr_lo[row] = (lo + b) - (fabsf(lo) + b) * 2.4e-7f - 1e-37f;
-            }
-        } else {                                         // plain flush of the append buffer
-            if (lane < a) list[c + lane] = abuf[lane];
-            if (lane == 0) lds_store_b32(lds_off(&s_cnt[row]), c + a);
-            if (dbg && lane == 0) { atomicAdd(dbg + 7, 1ull); }
-        }
-        if (s_acnt && lane == 0) lds_store_b32(lds_off(&s_acnt[row]), 0);
-        if (last) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
             compact_exact(p, list, s_cnt, s_thr_lo, s_thr_key, row, q0 + row, eps, s_qn[row], lane, sk, sb);
         }
     }
@@ -340,6 +283,7 @@ __global__ __launch_bounds__(NT, 2) void k_scan_bf16(ScanParamsH p) {
     __shared__ float s_thr_key[BQ];
     __shared__ float s_eps[BQ];
     __shared__ int s_cnt[BQ];
+    __shared__ int s_last[BQ];
     __shared__ __attribute__((aligned(16))) u64 s_keys[NT / 64][256];
     __shared__ __attribute__((aligned(16))) u64 s_best[NT / 64][64];
 
@@ -369,6 +313,7 @@ __global__ __launch_bounds__(NT, 2) void k_scan_bf16(ScanParamsH p) {
         s_thr_lo[tid] = valid ? -INFINITY : INFINITY;
         s_thr_key[tid] = valid ? -INFINITY : INFINITY;
         s_cnt[tid] = 0;
+        s_last[tid] = 0;
     }
 
     float4 rq0, rq1, rq2, rq3, rx0, rx1, rx2, rx3;
@@ -435,8 +380,8 @@ __global__ __launch_bounds__(NT, 2) void k_scan_bf16(ScanParamsH p) {
         __syncthreads();
 
         if (tile_done) {
-            maintain_rows(p, cand_panel, wave, lane, q0, it + 1 == total, false, s_cnt, s_thr_lo, s_thr_key, s_eps, s_qn,
-                          s_keys[wave], s_best[wave], false, nullptr, nullptr, nullptr);
+            maintain_rows(p, cand_panel, wave, lane, q0, it + 1 == total, s_cnt, s_last, s_thr_lo, s_thr_key, s_eps, s_qn,
+                          s_keys[wave], s_best[wave]);
             __syncthreads();
         }
         kt = kt_n; jl = jl_n;

@@ -286,3 +286,22 @@ def test_bf16_filter_chunked_database_state_carry(hip, oracle, monkeypatch):
     assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][0], out[1][0])
     Dr, Ir = oracle.knn("ip", X.cpu().numpy(), Q[:512].cpu().numpy(), 51)
     assert np.array_equal(out[1][1][:512].cpu().numpy(), Ir)
+
+
+def test_auto_picks_bf16_on_spread_data_and_f32_on_band_crowded_data(hip):
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n, nq, d = 65536, 131072, 64
+    spread = hip.normalize_vectors(torch.randn(n, d, generator=g, device="cuda"))
+    q = hip.normalize_vectors(torch.randn(nq, d, generator=g, device="cuda"))
+    proto = hip.normalize_vectors(torch.randn(10, d, generator=g, device="cuda"))
+    crowded = proto[torch.randint(0, 10, (n,), generator=g, device="cuda")]       # class-prompt style duplicates
+    for X, Q, expect in ((spread, q, 2), (crowded, crowded[:nq % n + n][:nq] if False else proto[torch.randint(0, 10, (nq,), generator=g, device="cuda")], 1)):
+        auto = hip.IndexFlatIP(d)
+        auto.add(X)
+        Da, Ia = auto.search(Q, 10)
+        assert auto.last_search_info()["algo"] == expect
+        ref = hip.IndexFlatIP(d)
+        ref.set_algo(1)
+        ref.add(X)
+        Dr, Ir = ref.search(Q, 10)
+        assert torch.equal(Ia, Ir) and torch.equal(Da, Dr)
