@@ -69,6 +69,11 @@ int lemon_d1_normalized(int metric, const float *q_img_dev, int64_t n, int d,
                         const float *cls_txt_dev, int C, const int32_t *noisy_label_dev,
                         float *d1_dev, void *stream);
 
+/* QuickGELU x*sigmoid(1.702x), in place, float32 (lib/models/chexzero_clip.py:186-188; HF CLIP's
+ * "quick_gelu"): the activation of encode_image / encode_text's MLP blocks, fused to one pass.
+ * x_dev must be 16-byte aligned. */
+int lemon_quick_gelu(float *x_dev, int64_t n, void *stream);
+
 /* ---- flat index (faiss.IndexFlatIP / IndexFlatL2 as used by run_lemon.py) ---------- */
 
 /* faiss.IndexFlatIP(d) / faiss.IndexFlatL2(d): run_lemon.py:167-168,171-172;

@@ -94,7 +94,11 @@ class Block(nn.Module):
         a = F.scaled_dot_product_attention(q, k, v, is_causal=causal)
         x = x + self.out(a.transpose(1, 2).reshape(B, L, W))
         h = self.fc1(self.ln2(x))
-        h = h * torch.sigmoid(1.702 * h)          # QuickGELU
+        if h.is_cuda and h.dtype == torch.float32 and not torch.is_grad_enabled():
+            from .ops import quick_gelu_           # fused HIP pass (3 elementwise kernels -> 1)
+            h = quick_gelu_(h)
+        else:
+            h = h * torch.sigmoid(1.702 * h)      # QuickGELU
         return x + self.fc2(h)
 
 

@@ -56,6 +56,15 @@ def normalize_vectors(vectors):
     return y
 
 
+def quick_gelu_(x):
+    """In-place QuickGELU on a contiguous float32 CUDA tensor (one fused HIP pass)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.lemon_quick_gelu(ptr(x), x.numel(), stream_ptr(x.device)), "lemon_quick_gelu")
+    return x
+
+
 def paired_distance(metric, a, b):
     a, b = dev_f32(a, "a"), dev_f32(b, "b")
     assert a.shape == b.shape and a.dim() == 2
