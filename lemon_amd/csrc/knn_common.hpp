@@ -80,6 +80,92 @@ __device__ __forceinline__ void stage_st(float *t, int tid, int i, float4 v) {
     } while (0)
 
 
+// ---- lane-private candidate lists ("pair lists") -------------------------------------------------
+// In the scans whose accumulator layout puts ONE query on each lane (A operand = database rows,
+// B operand = query rows: C[row = db][col = query = lane&31]), a query is owned by the lane pair
+// (l, l+32) of one wavefront.  Each of the two lanes appends to its OWN half of the query's list
+// (PAIR_CAP/2 entries) with the count in a VGPR: an append is one predicated global store -- no atomic,
+// no LDS, no wait.  Thresholds live in VGPRs too.  Entry idx of the pair list: idx < PAIR_CAP/2 -> half 0.
+constexpr int PAIR_CAP = 512;
+
+__device__ __forceinline__ u64 pair_load_slot(const u64 *__restrict__ list, int idx, int n0, int n1) {
+    const bool ok = idx < PAIR_CAP / 2 ? idx < n0 : (idx - PAIR_CAP / 2) < n1;
+    return ok ? list[idx] : 0;
+}
+
+// exact selection on exact keys: keep the kk largest keys (by the full 64-bit key: score, then lower
+// index), packed at the front of the pair list in arbitrary order: bisection on the key bits (8 compares
+// + 8 ballots per lane and step), then ballot-prefix stream compaction.  Needs n0 + n1 >= kk.
+// Returns the kk-th largest key.
+__device__ __forceinline__ u64 pair_select_exact(u64 *__restrict__ list, int n0, int n1, int kk, int lane) {
+    u64 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = pair_load_slot(list, lane + 64 * i, n0, n1);
+    // kk-th largest key = largest t with #{key >= t} >= kk.  High word (score) first: 32 steps; the
+    // low word (index order among equal scores) only matters when the kk-th score is tied.
+    u32 th_hi = 0;
+    int c_hi = 0;                                       // #{score-word >= th_hi} at the end (>= kk)
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; --bit) {
+        const u32 cand = th_hi | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c += __builtin_popcountll(__ballot((u32)(v[i] >> 32) >= cand));
+        if (c >= kk) { th_hi = cand; c_hi = c; }        // wave-uniform
+    }
+    u64 t = (u64)th_hi << 32;                           // all keys with a larger score word are in
+    if (th_hi == 0 || c_hi != kk) {                     // tie at the kk-th score (or c_hi never set): refine
+#pragma unroll 1
+        for (int bit = 31; bit >= 0; --bit) {
+            const u64 cand = t | (1ull << bit);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c += __builtin_popcountll(__ballot(v[i] >= cand));
+            if (c >= kk) t = cand;
+        }
+    } else {
+        // exactly kk keys have score word >= th_hi: the kk-th key is the smallest of them
+        u64 mn = ~0ull;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if ((u32)(v[i] >> 32) >= th_hi && v[i] < mn) mn = v[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(mn, off); mn = o < mn ? o : mn; }
+        t = mn;
+    }
+    const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool keep = v[i] >= t && v[i] != 0;
+        const u64 m = __ballot(keep);
+        if (keep) list[base + __builtin_popcountll(m & below)] = v[i];
+        base += __builtin_popcountll(m);
+    }
+    return t;
+}
+
+// sort the best kk keys of a pair list to the front of half-list 0 (best first) by 128-key rank
+// merges; returns how many exist (<= kk).  sk: 256-u64 scratch, sb: 64-u64 scratch (per wave, LDS).
+__device__ __forceinline__ int pair_sort_topk(u64 *__restrict__ list, int n0, int n1, int kk, int lane,
+                                              u64 *__restrict__ sk, u64 *__restrict__ sb) {
+    u64 best = 0;
+#pragma unroll 1
+    for (int base = 0; base < PAIR_CAP; base += 64) {
+        if (base < PAIR_CAP / 2 ? base >= n0 : (base - PAIR_CAP / 2) >= n1) continue;   // wave-uniform
+        const u64 key = pair_load_slot(list, base + lane, n0, n1);
+        const Ranked r = wave_rank_keys(best, key, 0, 0, 128, sk, lane);
+        sb[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (best && r.r0 < kk) sb[r.r0] = best;
+        if (key && r.r1 < kk) sb[r.r1] = key;
+        __builtin_amdgcn_wave_barrier();
+        best = sb[lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < kk) list[lane] = best;
+    return __builtin_popcountll(__ballot(best != 0));
+}
+
 // final write-out of a sorted per-row key list (lane < kk holds / reads entry `lane`)
 __device__ __forceinline__ void write_out_row(const ScanParams &p, int split, int64_t q, int lane, u64 key) {
     if (lane >= p.kk) return;

@@ -35,69 +35,57 @@ __global__ __launch_bounds__(256) void k_permute_rows(const float *__restrict__ 
     o[1] = make_float4(v[1], v[3], v[5], v[7]);
 }
 
-// compact one query row's candidate list to its best kk entries (sorted, best first)
-__device__ __forceinline__ void compact_row(u64 *__restrict__ list, int *cnt, float *thr, int row, int kk,
-                                            int lane, u64 *__restrict__ sk) {
-    const int n = __builtin_amdgcn_readfirstlane(cnt[row]);
-    const u64 v0 = (lane < n) ? list[lane] : 0;
-    const u64 v1 = (lane + 64 < n) ? list[lane + 64] : 0;
-    const u64 v2 = (lane + 128 < n) ? list[lane + 128] : 0;
-    const u64 v3 = (lane + 192 < n) ? list[lane + 192] : 0;
-    const Ranked r = wave_rank_keys(v0, v1, v2, v3, n, sk, lane);
-    const int kept = n < kk ? n : kk;
-    if (v0 && r.r0 < kk) list[r.r0] = v0;
-    if (v1 && r.r1 < kk) list[r.r1] = v1;
-    if (v2 && r.r2 < kk) list[r.r2] = v2;
-    if (v3 && r.r3 < kk) list[r.r3] = v3;
-    if (kept == kk) {   // the key of rank kk-1 is the new admission threshold
-        if (v0 && r.r0 == kk - 1) thr[row] = lemon_key_score(v0);
-        if (v1 && r.r1 == kk - 1) thr[row] = lemon_key_score(v1);
-        if (v2 && r.r2 == kk - 1) thr[row] = lemon_key_score(v2);
-        if (v3 && r.r3 == kk - 1) thr[row] = lemon_key_score(v3);
-    }
-    if (lane == 0) cnt[row] = kept;
-}
-
-// threshold filter + append for one 32x32 accumulator tile; zeroes the accumulator
-__device__ __forceinline__ void epilogue_tile(f32x16 &acc, int rtile, int64_t j, bool jvalid, float xn, int h,
-                                              int metric, const float *s_thr, const float *s_qn, int *s_cnt,
-                                              u64 *__restrict__ cand_panel) {
+// survivors of one 32x32 accumulator tile: a[e] = exact score of (db row jb + (e&3) + 8(e>>2), this
+// lane's query); strict '>' against the query's k-th best (rows arrive in ascending index, so an equal
+// score with a later index loses).  Appends go to this lane's private half-list.
+template <bool L2>
+__device__ __forceinline__ void f32_filter_tile(f32x16 a, float th, int64_t jb, float qn,
+                                                const float *__restrict__ xnorm, int64_t n, int &ccnt,
+                                                u64 *__restrict__ mylist) {
+    if (L2) {   // exact key of the numeric contract: -max(0, fma(-2, <q,x>, |q|^2 + |x|^2))
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int rbase = rtile + 8 * g + 4 * h;
-        const float4 t4 = *reinterpret_cast<const float4 *>(&s_thr[rbase]);
-        const float4 n4 = *reinterpret_cast<const float4 *>(&s_qn[rbase]);
-        const float th[4] = {t4.x, t4.y, t4.z, t4.w};
-        const float qn[4] = {n4.x, n4.y, n4.z, n4.w};
+        for (int g = 0; g < 4; ++g) {
+            const float4 xn4 = *reinterpret_cast<const float4 *>(&xnorm[jb + 8 * g]);
+            const float xn[4] = {xn4.x, xn4.y, xn4.z, xn4.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float s = acc[4 * g + e];
-            if (metric == LEMON_METRIC_L2) {
-                const float dd = __builtin_fmaf(-2.0f, s, qn[e] + xn);
-                s = -(dd > 0.0f ? dd : 0.0f);
-            }
-            if (jvalid && s > th[e]) {
-                const int row = rbase + e;
-                const int slot = atomicAdd(&s_cnt[row], 1);
-                cand_panel[(int64_t)row * CAP + slot] = lemon_make_key(s, (u32)j);
+            for (int e = 0; e < 4; ++e) {
+                const float dd = __builtin_fmaf(-2.0f, a[4 * g + e], qn + xn[e]);
+                a[4 * g + e] = -(dd > 0.0f ? dd : 0.0f);
             }
         }
     }
+    const float m0 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+    const float m1 = fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7]));
+    const float m2 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11]));
+    const float m3 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
+    const float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    if (m > th) {
+        const float mq[4] = {m0, m1, m2, m3};
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        for (int g = 0; g < 4; ++g) {
+            if (mq[g] > th) {
+#pragma unroll
+                for (int e = 4 * g; e < 4 * g + 4; ++e) {
+                    const int64_t j = jb + (e & 3) + 8 * (e >> 2);
+                    if (a[e] > th && j < n) mylist[ccnt++] = lemon_make_key(a[e], (u32)j);
+                }
+            }
+        }
+    }
 }
 
+// One workgroup = 128 queries x a range of 128-row database tiles.  Wave w owns queries 32w..32w+31
+// (B operand, one query per lane pair) against all 128 rows of the tile (A operand, 4 row tiles):
+// acc_i[e] = <x_(32i + (e&3) + 8(e>>2) + 4h), q_(32w + lane&31)> accumulated in ascending k.
+template <bool L2>
 __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
     __shared__ __attribute__((aligned(16))) float s_tile[2][2][BQ * BK];  // [buf][Q|X][row*32+..] 64 KiB
-    __shared__ __attribute__((aligned(16))) float s_thr[BQ];
-    __shared__ __attribute__((aligned(16))) float s_qn[BQ];
-    __shared__ int s_cnt[BQ];
-    __shared__ __attribute__((aligned(16))) u64 s_keys[NT / 64][256];   // rank-select scratch, one per wave
+    __shared__ __attribute__((aligned(16))) u64 s_keys[NT / 64][256];    // rank-merge scratch, one per wave
+    __shared__ __attribute__((aligned(16))) u64 s_best[NT / 64][64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
 
     const int panel = blockIdx.x / p.splits;
@@ -110,30 +98,27 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
     const int KT = p.dpad / BK;
     const int total = ntile * KT;
     const int dpad = p.dpad;
-    const int metric = p.metric;
 
-    if (tid < BQ) {
-        s_thr[tid] = (q0 + tid < p.nq) ? -INFINITY : INFINITY;  // pad queries never collect
-        s_cnt[tid] = 0;
-        s_qn[tid] = (metric == LEMON_METRIC_L2) ? p.qnorm[q0 + tid] : 0.0f;
-    }
+    // lane-private candidate state (see knn_common.hpp "pair lists")
+    const int qrow_l = 32 * wave + l31;
+    const bool qvalid = q0 + qrow_l < p.nq;
+    const float my_qn = L2 ? p.qnorm[q0 + qrow_l] : 0.0f;
+    u64 *cand_panel = p.cand + (int64_t)blockIdx.x * BQ * PAIR_CAP;
+    u64 *mylist = cand_panel + (int64_t)qrow_l * PAIR_CAP + h * (PAIR_CAP / 2);
+    int ccnt = 0, clast = 0;
+    float th = qvalid ? -INFINITY : INFINITY;    // exact score of the query's current k-th best
 
     float4 rq0, rq1, rq2, rq3, rx0, rx1, rx2, rx3;
     const float *qbase = p.qp + q0 * dpad;
     const float *xbase = p.xp + (int64_t)t_begin * BX * dpad;
 
-    f32x16 acc00, acc01, acc10, acc11;
+    f32x16 acc0, acc1, acc2, acc3;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { acc00[e] = 0.0f; acc01[e] = 0.0f; acc10[e] = 0.0f; acc11[e] = 0.0f; }
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.0f; acc1[e] = 0.0f; acc2[e] = 0.0f; acc3[e] = 0.0f; }
 
     STAGE_ISSUE(qbase, xbase);
     STAGE_COMMIT(s_tile[0][0], s_tile[0][1]);
     __syncthreads();
-
-    // one private candidate region per workgroup (panel x split)
-    u64 *cand_panel = p.cand + (int64_t)blockIdx.x * BQ * CAP;
-    const int arow0 = 64 * wr + l31, arow1 = arow0 + 32;
-    const int brow0 = 64 * wc + l31, brow1 = brow0 + 32;
 
     int kt = 0, jl = 0;  // position of iteration `it` = (tile jl of this split, k-slice kt)
     for (int it = 0; it < total; ++it) {
@@ -150,59 +135,73 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
         const float *tx = s_tile[cur][1];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(&tq[swz(arow0, 2 * u + h)]);
-            const float4 a1 = *reinterpret_cast<const float4 *>(&tq[swz(arow1, 2 * u + h)]);
-            const float4 b0 = *reinterpret_cast<const float4 *>(&tx[swz(brow0, 2 * u + h)]);
-            const float4 b1 = *reinterpret_cast<const float4 *>(&tx[swz(brow1, 2 * u + h)]);
+            const float4 b4 = *reinterpret_cast<const float4 *>(&tq[swz(qrow_l, 2 * u + h)]);
+            const float4 a0 = *reinterpret_cast<const float4 *>(&tx[swz(l31, 2 * u + h)]);
+            const float4 a1 = *reinterpret_cast<const float4 *>(&tx[swz(32 + l31, 2 * u + h)]);
+            const float4 a2 = *reinterpret_cast<const float4 *>(&tx[swz(64 + l31, 2 * u + h)]);
+            const float4 a3 = *reinterpret_cast<const float4 *>(&tx[swz(96 + l31, 2 * u + h)]);
+            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
             const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+            const float av2[4] = {a2.x, a2.y, a2.z, a2.w}, av3[4] = {a3.x, a3.y, a3.z, a3.w};
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[m], bv0[m], acc00, 0, 0, 0);
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[m], bv1[m], acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], bv0[m], acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], bv1[m], acc11, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[m], bv[m], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], bv[m], acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av2[m], bv[m], acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(av3[m], bv[m], acc3, 0, 0, 0);
             }
         }
 
-        const bool tile_done = (kt == KT - 1);
-        if (tile_done) {
-            const int64_t jb = (int64_t)(t_begin + jl) * BX + 64 * wc + l31;
-            const int64_t j0 = jb, j1 = jb + 32;
-            const bool v0 = j0 < p.n, v1 = j1 < p.n;
-            const float xn0 = (metric == LEMON_METRIC_L2) ? p.xnorm[j0] : 0.0f;
-            const float xn1 = (metric == LEMON_METRIC_L2) ? p.xnorm[j1] : 0.0f;
-            epilogue_tile(acc00, 64 * wr, j0, v0, xn0, h, metric, s_thr, s_qn, s_cnt, cand_panel);
-            epilogue_tile(acc01, 64 * wr, j1, v1, xn1, h, metric, s_thr, s_qn, s_cnt, cand_panel);
-            epilogue_tile(acc10, 64 * wr + 32, j0, v0, xn0, h, metric, s_thr, s_qn, s_cnt, cand_panel);
-            epilogue_tile(acc11, 64 * wr + 32, j1, v1, xn1, h, metric, s_thr, s_qn, s_cnt, cand_panel);
+        if (kt == KT - 1) {
+            // ---- epilogue: filter into the lane-private half-lists, then zero the accumulators ----
+            const int64_t jb = (int64_t)(t_begin + jl) * BX + 4 * h;
+            f32_filter_tile<L2>(acc0, th, jb, my_qn, p.xnorm, p.n, ccnt, mylist);
+            f32_filter_tile<L2>(acc1, th, jb + 32, my_qn, p.xnorm, p.n, ccnt, mylist);
+            f32_filter_tile<L2>(acc2, th, jb + 64, my_qn, p.xnorm, p.n, ccnt, mylist);
+            f32_filter_tile<L2>(acc3, th, jb + 96, my_qn, p.xnorm, p.n, ccnt, mylist);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc0[e] = 0.0f; acc1[e] = 0.0f; acc2[e] = 0.0f; acc3[e] = 0.0f; }
+
+            // ---- maintenance: select the exact top-kk of queries whose lists grew enough ----
+            const int pair = ccnt + __shfl_xor(ccnt, 32);
+            const bool warm = th == -INFINITY && pair >= p.kk;
+            const bool stale = pair >= p.kk && pair - clast >= 96;
+            const bool full = ccnt > PAIR_CAP / 2 - BX / 2;
+            u64 todo = __ballot(qvalid && (warm || stale || full));
+            todo = (todo | (todo >> 32)) & 0xffffffffull;          // one bit per query of this wave
+            if (todo) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's appends are visible
+                do {
+                    const int r = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    u64 *list = cand_panel + (int64_t)(32 * wave + r) * PAIR_CAP;
+                    const int n0 = __builtin_amdgcn_readlane(ccnt, r), n1 = __builtin_amdgcn_readlane(ccnt, r + 32);
+                    const u64 kth = pair_select_exact(list, n0, n1, p.kk, lane);
+                    if (l31 == r) {                    // both lanes of the pair take the new state
+                        ccnt = h == 0 ? p.kk : 0;
+                        clast = p.kk;
+                        th = lemon_key_score(kth);
+                    }
+                } while (todo);
+            }
         }
 
         if (it + 1 < total) STAGE_COMMIT(s_tile[cur ^ 1][0], s_tile[cur ^ 1][1]);
         __syncthreads();
-
-        if (tile_done) {
-            // rows whose list could overflow on the next tile are compacted (wave w owns rows 32w..)
-            const bool last = (it + 1 == total);
-            for (int r = 0; r < 32; ++r) {
-                const int row = 32 * wave + r;
-                const int c = s_cnt[row];
-                // also compact as soon as kk candidates exist while no threshold is set yet (warm-up)
-                if (last || c > CAP - BX || (c >= p.kk && s_thr[row] == -INFINITY))
-                    compact_row(cand_panel + (int64_t)row * CAP, s_cnt, s_thr, row, p.kk, lane, s_keys[wave]);
-            }
-            __syncthreads();
-        }
         kt = kt_n; jl = jl_n;
     }
 
-    // ---- write-out: lists are sorted (best first) after the final compaction --------------
+    // ---- final: sort every query's best kk, write the result rows ------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int r = 0; r < 32; ++r) {
         const int row = 32 * wave + r;
         const int64_t q = q0 + row;
-        if (q >= p.nq) continue;
-        const int kept = s_cnt[row];
-        const u64 key = (lane < kept && lane < p.kk) ? cand_panel[(int64_t)row * CAP + lane] : 0;
+        if (q >= p.nq) break;
+        u64 *list = cand_panel + (int64_t)row * PAIR_CAP;
+        const int n0 = __builtin_amdgcn_readlane(ccnt, r), n1 = __builtin_amdgcn_readlane(ccnt, r + 32);
+        const int have = pair_sort_topk(list, n0, n1, p.kk, lane, s_keys[wave], s_best[wave]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const u64 key = (lane < have && lane < p.kk) ? list[lane] : 0;
         write_out_row(p, split, q, lane, key);
     }
 }
@@ -290,11 +289,12 @@ int lemon_fill_empty(float *D, int64_t *I, int64_t total, int metric, hipStream_
     return LEMON_OK;
 }
 
-// enough workgroups to fill 256 CUs x 2 resident; every split keeps >= 8 tiles so the warm-up amortises
+// enough workgroups to fill 256 CUs x 2 resident 1.5 times; every split keeps >= 8 tiles so the
+// per-split warm-up (first-tile selection, final sort, merge) amortises
 void lemon_plan_splits(int panels, int n_tiles, int *splits_out, int *tiles_per_split_out) {
     int splits = 1;
-    if (panels < 1024) {
-        splits = (1024 + panels - 1) / panels;
+    if (panels < 768) {
+        splits = (768 + panels - 1) / panels;
         int max_splits = n_tiles / 8;
         if (max_splits < 1) max_splits = 1;
         if (splits > max_splits) splits = max_splits;
@@ -362,7 +362,7 @@ int lemon_search_f32(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, 
         int splits, tiles_per_split;
         lemon_plan_splits(panels, n_tiles, &splits, &tiles_per_split);
 
-        int rc = lemon_ensure_search_ws(idx, nq_pad, splits, dpad * 4, CAP, stream);
+        int rc = lemon_ensure_search_ws(idx, nq_pad, splits, dpad * 4, PAIR_CAP, stream);
         if (rc) return rc;
         // permuted, zero-padded query panel (+ chain norms for L2)
         LEMON_HIP_CHECK(hipMemsetAsync(idx->ws_qp, 0, (size_t)nq_pad * dpad * sizeof(float), stream));
@@ -384,7 +384,8 @@ int lemon_search_f32(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, 
             const double flops = 2.0 * (double)cn * (double)idx->n * (double)d;
             const double bytes = 4.0 * d * ((double)cn + (double)panels * (double)idx->n) + 12.0 * k * (double)cn;
             LemonProfScope prof(idx, stream, flops, bytes);
-            hipLaunchKernelGGL(k_scan_f32, dim3(grid), dim3(NT), 0, stream, p);
+            if (idx->metric == LEMON_METRIC_L2) hipLaunchKernelGGL(k_scan_f32<true>, dim3(grid), dim3(NT), 0, stream, p);
+            else hipLaunchKernelGGL(k_scan_f32<false>, dim3(grid), dim3(NT), 0, stream, p);
         }
         LEMON_HIP_CHECK(hipGetLastError());
         if (splits > 1) {
