@@ -74,14 +74,42 @@ class Embedder:
 
 def score_splits(db, splits, k, hparams=None, discrete=False):
     """splits: list of dicts {name, img, txt, drop_self, in_db, label_id}.  Returns per split the
-    record of device arrays (+ 'score' float64 when hparams is given)."""
-    out = {}
+    record of device arrays (+ 'score' float64 when hparams is given).
+
+    All splits go through ONE lemon_neighbors call (one scan launch per modality instead of one per
+    split and modality): the train split searches k+1 and drops result[0] where the sample is in the DB
+    else result[-1] (run_lemon.py:257-263); val/test search k.  With the per-query `in_db` flag the
+    second case is exactly "keep the first k of k+1", so val/test ride along with in_db = 0."""
+    splits = [s for s in splits if s["img"].shape[0] > 0]
+    if not splits:
+        return {}
+    any_train = any(s.get("drop_self", False) for s in splits)
+    dev = splits[0]["img"].device
+    img = torch.cat([s["img"] for s in splits])
+    txt = torch.cat([s["txt"] for s in splits])
+    in_db = None
+    if any_train:
+        parts = []
+        for s in splits:
+            n = s["img"].shape[0]
+            if s.get("drop_self", False):
+                m = s.get("in_db")
+                parts.append(torch.ones(n, dtype=torch.uint8, device=dev) if m is None
+                             else torch.as_tensor(m).to(device=dev, dtype=torch.uint8))
+            else:
+                parts.append(torch.zeros(n, dtype=torch.uint8, device=dev))
+        in_db = torch.cat(parts)
+    lab = None
+    if discrete:
+        lab = torch.cat([torch.as_tensor(s["label_id"]).to(device=dev, dtype=torch.int32) for s in splits])
+    rec = db.neighbors(img, txt, k, drop_self=any_train, in_db=in_db, discrete=discrete, q_label_id=lab)
+    if hparams is not None:
+        rec["score"] = ops.lemon_score(rec, hparams)
+    out, lo = {}, 0
     for s in splits:
-        rec = db.neighbors(s["img"], s["txt"], k, drop_self=s.get("drop_self", False), in_db=s.get("in_db"),
-                           discrete=discrete, q_label_id=s.get("label_id"))
-        if hparams is not None:
-            rec["score"] = ops.lemon_score(rec, hparams)
-        out[s["name"]] = rec
+        n = s["img"].shape[0]
+        out[s["name"]] = {key: v[lo:lo + n] for key, v in rec.items()}
+        lo += n
     return out
 
 

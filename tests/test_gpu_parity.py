@@ -322,3 +322,23 @@ def test_quick_gelu_and_encoder_gpu_vs_cpu(hip):
     mg = LemonCLIP(ClipConfig.named("tiny")).eval().cuda()
     gi, gt = mg.encode_image(px.cuda()).cpu(), mg.encode_text(ids.cuda()).cpu()
     assert (gi - ci).abs().max() < 1e-4 and (gt - ct).abs().max() < 1e-4
+
+
+def test_fused_split_scoring_equals_per_split_calls(hip, oracle):
+    # pipeline.score_splits sends train (k+1, self-exclusion) and val/test (k) through ONE neighbours call
+    from lemon_amd.pipeline import score_splits
+    s = planted(seed=2, n_tr=1500, n_q=200, d=64, C=16)
+    img_tr, txt_tr, _, noisy_tr = s["train"]
+    q_img, q_txt, _, noisy_q = s["query"]
+    in_db = np.ones(1500, np.uint8); in_db[::9] = 0
+    for discrete in (False, True):
+        db = hip.LemonDB(cu(img_tr), cu(txt_tr), "cosine", tr_label_id=noisy_tr)
+        recs = score_splits(db, [dict(name="train", img=cu(img_tr), txt=cu(txt_tr), drop_self=True, in_db=in_db, label_id=noisy_tr),
+                                 dict(name="val", img=cu(q_img), txt=cu(q_txt), label_id=noisy_q)], 5, discrete=discrete)
+        ref_tr = oracle.neighbors("cosine", img_tr, txt_tr, img_tr, txt_tr, 5, drop_self=True, in_db=in_db,
+                                  discrete=discrete, tr_label_id=noisy_tr, q_label_id=noisy_tr)
+        ref_va = oracle.neighbors("cosine", img_tr, txt_tr, q_img, q_txt, 5, discrete=discrete,
+                                  tr_label_id=noisy_tr, q_label_id=noisy_q)
+        for name, ref in (("train", ref_tr), ("val", ref_va)):
+            for key in ("I_n", "I_m", "d_1", "D_n", "dists_n", "dists_tr_n", "D_m", "dists_m", "dists_tr_m"):
+                assert np.array_equal(recs[name][key].cpu().numpy(), ref[key]), (name, key, discrete)
