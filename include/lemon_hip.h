@@ -63,6 +63,13 @@ int lemon_normalize_rows(const float *x_dev, int64_t n, int d, float *y_dev, voi
 int lemon_paired_distance(int metric, const float *a_dev, const float *b_dev, int64_t n, int d,
                           float *out_dev, void *stream);
 
+/* DistanceEvaluator.our_metric, lib/metrics/distance_metrics.py:48-73 (used by
+ * lib/baselines/run_clip_sim.py:235-248): paired distance of row i of a and row i of b WITHOUT
+ * assuming normalised inputs.  kind 0: cosine 1 - <a,b>/(|a||b|); 1: euclidean (NOT squared);
+ * 2: manhattan.  The reference takes the diagonal of the full n x n pairwise matrix. */
+int lemon_paired_metric(int kind, const float *a_dev, const float *b_dev, int64_t n, int d,
+                        float *out_dev, void *stream);
+
 /* --normalize_d1, run_lemon.py:244-248: d1[i] = softmax_c(dist(img_i, cls_txt_c))[noisy_label[i]].
  * cls_txt_dev [C,d] (run_lemon.py:180-190), noisy_label_dev [n] int32. */
 int lemon_d1_normalized(int metric, const float *q_img_dev, int64_t n, int d,
@@ -147,6 +154,15 @@ int lemon_neighbors(lemon_index_t *idx_img, lemon_index_t *idx_txt, const float 
                     float *d1_dev, float *D_n_dev, float *dists_n_dev, float *dists_tr_n_dev,
                     int64_t *I_n_dev, float *D_m_dev, float *dists_m_dev, float *dists_tr_m_dev,
                     int64_t *I_m_dev, void *stream);
+
+/* Discrepancy baselines, lib/baselines/discrepancy_baseline.py:164-242 (next-row scope).
+ * method 0 = dis_x / dis_y: mean cosine distance between the query's embedding qv_dev [nq,d] and the
+ * second-order neighbours (through the DB's own text kNN cache of k+1, self removed by index, :165-169)
+ * of its k (+1 on train, not dropped) text neighbours; method 1 = div_x / div_y: sum of pairwise cosine
+ * distances inside the neighbour set divided by k^2.  E_tr_dev [ntotal,d] are the DB embeddings of the
+ * scored modality (x: image, y: text); neighbours always come from idx_txt (:209).  out_dev [nq]. */
+int lemon_discrepancy(int method, lemon_index_t *idx_txt, const float *E_tr_dev, const float *qv_dev,
+                      const float *q_txt_dev, int64_t nq, int k, int is_train, float *out_dev, void *stream);
 
 /* lib/metrics/utils.py:47-82 calc_scores_given_hparams_vectorized (== loop twin :21-45):
  * score = d_1 + beta*mean_j[e^{-tau_1_n D_n} e^{-tau_2_n dists_tr_n} dists_n] + gamma*(same for m).

@@ -16,10 +16,10 @@ ALGO_AUTO, ALGO_F32_MFMA, ALGO_BF16_FILTER = 0, 1, 2
 # every symbol include/lemon_hip.h declares
 EXPORTS = [
     "lemon_last_error", "lemon_version", "lemon_normalize_rows", "lemon_paired_distance",
-    "lemon_d1_normalized", "lemon_quick_gelu", "lemon_index_create", "lemon_index_free", "lemon_index_add",
+    "lemon_d1_normalized", "lemon_paired_metric", "lemon_quick_gelu", "lemon_index_create", "lemon_index_free", "lemon_index_add",
     "lemon_index_ntotal", "lemon_index_dim", "lemon_index_data", "lemon_index_search",
     "lemon_index_set_algo", "lemon_index_last_search_info", "lemon_index_set_profiling",
-    "lemon_index_profile_read", "lemon_neighbors", "lemon_score",
+    "lemon_index_profile_read", "lemon_neighbors", "lemon_discrepancy", "lemon_score",
 ]
 
 
@@ -56,6 +56,7 @@ def load():
     lib.lemon_normalize_rows.argtypes = [vp, c_i64, c_int, vp, vp]
     lib.lemon_paired_distance.argtypes = [c_int, vp, vp, c_i64, c_int, vp, vp]
     lib.lemon_d1_normalized.argtypes = [c_int, vp, c_i64, c_int, vp, c_int, vp, vp, vp]
+    lib.lemon_paired_metric.argtypes = [c_int, vp, vp, c_i64, c_int, vp, vp]
     lib.lemon_quick_gelu.argtypes = [vp, c_i64, vp]
     lib.lemon_index_create.argtypes = [c_int, c_int, ctypes.POINTER(vp)]
     lib.lemon_index_free.argtypes = [vp]
@@ -71,6 +72,7 @@ def load():
     lib.lemon_index_set_profiling.argtypes = [vp, c_int]
     lib.lemon_index_profile_read.argtypes = [vp, ctypes.POINTER(c_i64)] + [ctypes.POINTER(ctypes.c_double)] * 3
     lib.lemon_neighbors.argtypes = [vp, vp, vp, vp, vp, c_i64, c_int, c_int, vp, c_int, vp, vp] + [vp] * 9 + [vp]
+    lib.lemon_discrepancy.argtypes = [c_int, vp, vp, vp, vp, c_i64, c_int, c_int, vp, vp]
     lib.lemon_score.argtypes = [vp] * 7 + [c_i64, c_int, ctypes.POINTER(ctypes.c_double), vp, vp, vp, vp]
     _lib = lib
     return lib

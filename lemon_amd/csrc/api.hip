@@ -378,3 +378,86 @@ extern "C" int lemon_neighbors(lemon_index_t *idx_img, lemon_index_t *idx_txt, c
     LEMON_HIP_CHECK(hipGetLastError());
     return LEMON_OK;
 }
+
+// ---- discrepancy baselines (lib/baselines/discrepancy_baseline.py:164-242) ------------------
+// One wavefront per query; lanes stride over the (neighbour, second-order neighbour) or
+// (neighbour, neighbour) pairs, each pair is a chain distance on gathered rows; float64 sums.
+struct DiscParams {
+    const float *E, *qv;
+    const int64_t *Im, *Ic;
+    float *out;
+    int64_t nq;
+    int d, k, kq, kc, method;
+};
+
+__global__ __launch_bounds__(256) void k_discrepancy(DiscParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= p.nq) return;
+    const int64_t *im = p.Im + i * p.kq;
+    double total = 0.0;
+    int count = 0;
+    const int pairs = p.method == 0 ? p.kq * p.kc : p.kq * p.kq;
+    for (int t = lane; t < pairs; t += 64) {
+        const int a = p.method == 0 ? t / p.kc : t / p.kq, b = p.method == 0 ? t % p.kc : t % p.kq;
+        const int64_t j = im[a];
+        if (j < 0) continue;
+        if (p.method == 0) {
+            const int64_t l = p.Ic[j * p.kc + b];
+            if (l < 0 || l == j) continue;
+            total += (double)chain_dist<false>(p.E + l * (int64_t)p.d, p.qv + i * (int64_t)p.d, p.d);
+            ++count;
+        } else {
+            const int64_t l = im[b];
+            if (l < 0) continue;
+            total += (double)chain_dist<false>(p.E + j * (int64_t)p.d, p.E + l * (int64_t)p.d, p.d);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { total += __shfl_xor(total, off); count += __shfl_xor(count, off); }
+    if (lane == 0)
+        p.out[i] = p.method == 0 ? (float)(count ? total / (double)count : (double)__builtin_nanf(""))
+                                 : (float)(total / ((double)p.k * (double)p.k));
+}
+
+extern "C" int lemon_discrepancy(int method, lemon_index_t *idx_txt, const float *E_tr_dev, const float *qv_dev,
+                                 const float *q_txt_dev, int64_t nq, int k, int is_train, float *out_dev,
+                                 void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LEMON_REQUIRE(method == 0 || method == 1, "method: 0 dis, 1 div");
+    LEMON_REQUIRE(idx_txt && idx_txt->metric == LEMON_METRIC_IP, "text index must be an IndexFlatIP");
+    LEMON_REQUIRE(nq >= 0 && k >= 1 && k + 1 <= LEMON_MAX_K, "nq >= 0, 1 <= k < LEMON_MAX_K");
+    if (nq == 0) return LEMON_OK;
+    LEMON_REQUIRE(E_tr_dev && q_txt_dev && out_dev && (method == 1 || qv_dev), "null pointer");
+    const int kc = k + 1, kq = k + (is_train ? 1 : 0);
+    const int64_t n = idx_txt->n;
+    // scratch: cache [n, kc] (dis only) + Im [nq, kq] (+ the D arrays the searches return)
+    const int64_t need = (method == 0 ? n * kc : 0) + nq * kq;
+    if (need > idx_txt->ws_nb) {
+        LEMON_HIP_CHECK(hipStreamSynchronize(stream));
+        if (idx_txt->ws_D) (void)hipFree(idx_txt->ws_D);
+        if (idx_txt->ws_I) (void)hipFree(idx_txt->ws_I);
+        idx_txt->ws_D = nullptr; idx_txt->ws_I = nullptr; idx_txt->ws_nb = 0;
+        if (hipMalloc(&idx_txt->ws_D, (size_t)need * sizeof(float)) != hipSuccess ||
+            hipMalloc(&idx_txt->ws_I, (size_t)need * sizeof(int64_t)) != hipSuccess) {
+            lemon_set_error("discrepancy workspace allocation failed");
+            return LEMON_E_NOMEM;
+        }
+        idx_txt->ws_nb = need;
+    }
+    int64_t *Ic = idx_txt->ws_I, *Im = idx_txt->ws_I + (method == 0 ? n * kc : 0);
+    float *Dc = idx_txt->ws_D, *Dm = idx_txt->ws_D + (method == 0 ? n * kc : 0);
+    int rc;
+    if (method == 0) {   // cache of the DB's own text neighbours, discrepancy_baseline.py:165-169
+        rc = lemon_search_internal(idx_txt, idx_txt->x, n, kc, Dc, Ic, stream);
+        if (rc) return rc;
+    }
+    rc = lemon_search_internal(idx_txt, q_txt_dev, nq, kq, Dm, Im, stream);   // :209
+    if (rc) return rc;
+    DiscParams p;
+    p.E = E_tr_dev; p.qv = qv_dev; p.Im = Im; p.Ic = Ic; p.out = out_dev; p.nq = nq;
+    p.d = idx_txt->d; p.k = k; p.kq = kq; p.kc = kc; p.method = method;
+    hipLaunchKernelGGL(k_discrepancy, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, p);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}

@@ -47,7 +47,9 @@ __global__ __launch_bounds__(256) void k_normalize_rows(const float *__restrict_
 // ---------------------------------------------------------------------------------
 // chain row-dot through an LDS transpose: a block stages a [64 rows x 64 cols] slab of a and b
 // with coalesced loads, then lane r walks row r in ascending k (the fmaf chain of the numeric
-// contract).  MODE 0: dot(a,b)  MODE 1: 1 - dot(a,b)  MODE 2: sum (a-b)^2
+// contract).  MODE 0: dot(a,b)  MODE 1: 1 - dot(a,b)  MODE 2: sum (a-b)^2  MODE 3: sqrt(sum (a-b)^2)
+// MODE 4: sum |a-b|  MODE 5: 1 - dot(a,b)/(|a||b|)   (3-5: DistanceEvaluator.our_metric,
+// lib/metrics/distance_metrics.py:48-73, which takes the diagonal of a full pairwise matrix)
 // ---------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(64) void k_rowchain(const float *__restrict__ a, const float *__restrict__ b,
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(64) void k_rowchain(const float *__restrict__ a, co
     __shared__ float sb[64][65];
     const int lane = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * 64;
-    float acc = 0.0f;
+    float acc = 0.0f, na = 0.0f, nb = 0.0f;
     for (int k0 = 0; k0 < d; k0 += 64) {
         // coalesced: for each of the 64 rows, 64 lanes read 64 consecutive floats
         for (int r = 0; r < 64; ++r) {
@@ -70,13 +72,21 @@ __global__ __launch_bounds__(64) void k_rowchain(const float *__restrict__ a, co
         const int kmax = (d - k0) < 64 ? (d - k0) : 64;
         for (int k = 0; k < kmax; ++k) {
             float va = sa[lane][k], vb = sb[lane][k];
-            if (MODE == 2) { float t = va - vb; acc = __builtin_fmaf(t, t, acc); }
+            if (MODE == 2 || MODE == 3) { float t = va - vb; acc = __builtin_fmaf(t, t, acc); }
+            else if (MODE == 4) acc += fabsf(va - vb);
             else acc = __builtin_fmaf(va, vb, acc);
+            if (MODE == 5) { na = __builtin_fmaf(va, va, na); nb = __builtin_fmaf(vb, vb, nb); }
         }
         __syncthreads();
     }
     int64_t row = row0 + lane;
-    if (row < n) out[row] = (MODE == 1) ? 1.0f - acc : acc;
+    if (row < n) {
+        float r = acc;
+        if (MODE == 1) r = 1.0f - acc;
+        if (MODE == 3) r = sqrtf(acc);
+        if (MODE == 5) r = 1.0f - acc / fmaxf(sqrtf(na) * sqrtf(nb), 1e-30f);
+        out[row] = r;
+    }
 }
 
 int lemon_rowdot_chain(const float *a, const float *b, int64_t n, int d, float *out, hipStream_t s) {
@@ -214,6 +224,20 @@ extern "C" int lemon_paired_distance(int metric, const float *a_dev, const float
         hipLaunchKernelGGL(k_rowchain<1>, grid, dim3(64), 0, (hipStream_t)stream, a_dev, b_dev, n, d, out_dev);
     else
         hipLaunchKernelGGL(k_rowchain<2>, grid, dim3(64), 0, (hipStream_t)stream, a_dev, b_dev, n, d, out_dev);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}
+
+extern "C" int lemon_paired_metric(int kind, const float *a_dev, const float *b_dev, int64_t n, int d,
+                                   float *out_dev, void *stream) {
+    LEMON_REQUIRE(kind >= 0 && kind <= 2, "kind: 0 cosine, 1 euclidean, 2 manhattan");
+    LEMON_REQUIRE(n >= 0 && d > 0, "n >= 0 and d > 0");
+    if (n == 0) return LEMON_OK;
+    LEMON_REQUIRE(a_dev && b_dev && out_dev, "null pointer");
+    dim3 grid((unsigned)((n + 63) / 64));
+    if (kind == 0) hipLaunchKernelGGL(k_rowchain<5>, grid, dim3(64), 0, (hipStream_t)stream, a_dev, b_dev, n, d, out_dev);
+    else if (kind == 1) hipLaunchKernelGGL(k_rowchain<3>, grid, dim3(64), 0, (hipStream_t)stream, a_dev, b_dev, n, d, out_dev);
+    else hipLaunchKernelGGL(k_rowchain<4>, grid, dim3(64), 0, (hipStream_t)stream, a_dev, b_dev, n, d, out_dev);
     LEMON_HIP_CHECK(hipGetLastError());
     return LEMON_OK;
 }

@@ -56,6 +56,23 @@ def normalize_vectors(vectors):
     return y
 
 
+def our_metric(first, second, dist="cosine"):
+    """DistanceEvaluator.our_metric (lib/metrics/distance_metrics.py:48-73): paired cosine /
+    euclidean (not squared) / manhattan distance of un-normalised embeddings, without the reference's
+    n x n detour.  Returns a CUDA float32 tensor [n]."""
+    kind = {"cosine": 0, "euclidean": 1, "manhattan": 2}.get(dist)
+    if kind is None:
+        raise NotImplementedError(dist)
+    a, b = dev_f32(first, "first"), dev_f32(second, "second")
+    assert a.shape == b.shape and a.dim() == 2
+    out = torch.empty(a.shape[0], dtype=torch.float32, device=a.device)
+    lib = _lib.load()
+    with torch.cuda.device(a.device):
+        _lib.check(lib.lemon_paired_metric(kind, ptr(a), ptr(b), a.shape[0], a.shape[1], ptr(out),
+                                           stream_ptr(a.device)), "lemon_paired_metric")
+    return out
+
+
 def quick_gelu_(x):
     """In-place QuickGELU on a contiguous float32 CUDA tensor (one fused HIP pass)."""
     assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()

@@ -301,6 +301,52 @@ void lo_score(const float *d1, const float *D_n, const float *dists_tr_n, const 
     }
 }
 
+/* ------------------------------------------------------------------ */
+/* discrepancy baselines, lib/baselines/discrepancy_baseline.py:164-242 */
+/* ------------------------------------------------------------------ */
+/*
+ * method 0 = dis_* (second-order neighbours through the DB self-kNN cache, :165-169,214-221),
+ * method 1 = div_* (mean pairwise distance inside the neighbour set, :222-229; divides by k^2 even
+ * when k+1 neighbours were searched on the train split).  E_tr / qv are the embeddings of the
+ * modality being scored (x: image, y: text); neighbours always come from the TEXT index (:209).
+ * The reference does NOT drop the query itself from I_m on the train split.
+ */
+void lo_discrepancy(int method, const float *E_tr, const float *txt_tr, int64_t n_tr, int d,
+                    const float *qv, const float *q_txt, int64_t nq, int k, int is_train, float *out) {
+    const int kc = k + 1, kq = k + (is_train ? 1 : 0);
+    float *Dc = (float *)malloc(sizeof(float) * (size_t)n_tr * kc);
+    int64_t *Ic = (int64_t *)malloc(sizeof(int64_t) * (size_t)n_tr * kc);
+    float *Dm = (float *)malloc(sizeof(float) * (size_t)nq * kq);
+    int64_t *Im = (int64_t *)malloc(sizeof(int64_t) * (size_t)nq * kq);
+    if (method == 0) lo_knn(LO_METRIC_IP, txt_tr, n_tr, d, txt_tr, n_tr, kc, Dc, Ic);   /* cache, :166 */
+    lo_knn(LO_METRIC_IP, txt_tr, n_tr, d, q_txt, nq, kq, Dm, Im);                       /* :209 */
+    #pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < nq; ++i) {
+        double total = 0.0;
+        int64_t count = 0;
+        for (int a = 0; a < kq; ++a) {
+            const int64_t j = Im[i * kq + a];
+            if (j < 0) continue;
+            if (method == 0) {
+                for (int c = 0; c < kc; ++c) {
+                    const int64_t l = Ic[j * kc + c];
+                    if (l < 0 || l == j) continue;                                      /* cache[i] without i, :168-169 */
+                    total += (double)(1.0f - lo_dot(E_tr + l * (int64_t)d, qv + i * (int64_t)d, d));
+                    ++count;
+                }
+            } else {
+                for (int b = 0; b < kq; ++b) {
+                    const int64_t l = Im[i * kq + b];
+                    if (l < 0) continue;
+                    total += (double)(1.0f - lo_dot(E_tr + j * (int64_t)d, E_tr + l * (int64_t)d, d));
+                }
+            }
+        }
+        out[i] = (method == 0) ? (float)(count ? total / (double)count : NAN) : (float)(total / ((double)k * (double)k));
+    }
+    free(Dc); free(Ic); free(Dm); free(Im);
+}
+
 int lo_has_simd(void) { return LO_SIMD; }
 
 #ifdef _OPENMP

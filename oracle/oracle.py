@@ -137,6 +137,16 @@ def d1_normalized(metric, q_img, cls_txt, noisy_label):
     return out
 
 
+def discrepancy(method, E_tr, txt_tr, qv, q_txt, k, is_train=False):
+    """lib/baselines/discrepancy_baseline.py:164-242.  method: 'dis' | 'div'."""
+    E_tr, txt_tr, qv, q_txt = _f32(E_tr), _f32(txt_tr), _f32(qv), _f32(q_txt)
+    out = np.empty(q_txt.shape[0], np.float32)
+    lib().lo_discrepancy(ctypes.c_int({"dis": 0, "div": 1}[method]), _p(E_tr), _p(txt_tr),
+                         ctypes.c_int64(E_tr.shape[0]), ctypes.c_int(E_tr.shape[1]), _p(qv), _p(q_txt),
+                         ctypes.c_int64(q_txt.shape[0]), ctypes.c_int(k), ctypes.c_int(int(is_train)), _p(out))
+    return out
+
+
 HP_ORDER = ("beta", "gamma", "tau_1_n", "tau_2_n", "tau_1_m", "tau_2_m")
 
 

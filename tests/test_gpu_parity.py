@@ -342,3 +342,48 @@ def test_fused_split_scoring_equals_per_split_calls(hip, oracle):
         for name, ref in (("train", ref_tr), ("val", ref_va)):
             for key in ("I_n", "I_m", "d_1", "D_n", "dists_n", "dists_tr_n", "D_m", "dists_m", "dists_tr_m"):
                 assert np.array_equal(recs[name][key].cpu().numpy(), ref[key]), (name, key, discrete)
+
+
+def test_our_metric_matches_sklearn_pairwise_diagonal(hip):
+    # lib/metrics/distance_metrics.py:48-73 takes np.diagonal of sklearn's full pairwise matrices
+    from sklearn.metrics.pairwise import cosine_similarity, euclidean_distances, manhattan_distances
+    from lemon_amd.ops import our_metric
+    rng = np.random.default_rng(0)
+    a = (rng.standard_normal((300, 96)) * 3).astype(np.float32)
+    b = (rng.standard_normal((300, 96)) * 0.5).astype(np.float32)
+    ref = {"cosine": 1 - np.diagonal(cosine_similarity(a, b)), "euclidean": np.diagonal(euclidean_distances(a, b)),
+           "manhattan": np.diagonal(manhattan_distances(a, b))}
+    for dist, r in ref.items():
+        got = our_metric(cu(a), cu(b), dist).cpu().numpy()
+        assert np.allclose(got, r, rtol=2e-5, atol=2e-5), dist
+
+
+@pytest.mark.parametrize("is_train", [False, True])
+def test_discrepancy_baselines_match_oracle(hip, oracle, is_train):
+    from lemon_amd.baselines import discrepancy_scores
+    s = planted(seed=6, n_tr=1200, n_q=150, d=48, C=12)
+    img_tr, txt_tr, _, _ = s["train"]
+    if is_train:
+        q_img, q_txt = img_tr[:200], txt_tr[:200]
+    else:
+        q_img, q_txt, _, _ = s["query"]
+    txt_j = (txt_tr + 0.05 * np.random.default_rng(0).standard_normal(txt_tr.shape)).astype(np.float32)
+    txt_j /= np.linalg.norm(txt_j, axis=1, keepdims=True)        # captions: no exact duplicates
+    for tr_txt in (txt_tr, txt_j):
+        db = hip.LemonDB(cu(img_tr), cu(tr_txt), "cosine")
+        for method in ("dis_x", "dis_y", "div_x", "div_y"):
+            got = discrepancy_scores(db, cu(q_img), cu(q_txt), 4, method, is_train=is_train).cpu().numpy()
+            E, qv = (img_tr, q_img) if method.endswith("_x") else (tr_txt, q_txt)
+            ref = oracle.discrepancy(method[:3], E, tr_txt, qv, q_txt, 4, is_train)
+            assert np.allclose(got, ref, rtol=1e-6, atol=1e-6, equal_nan=True), (method, np.abs(got - ref).max())
+
+
+def test_cos_distance_topk_matches_reference_golden(hip):
+    import os
+    from lemon_amd.baselines import cos_distance_topk, count_knn_distribution
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cosdistance_topk.npz"))
+    vals, idx = cos_distance_topk(cu(g["feat"]), 6)
+    assert np.array_equal(idx.cpu().numpy(), g["idx"])
+    assert np.abs(vals.cpu().numpy() - g["vals"]).max() < 5e-7
+    prob = count_knn_distribution(4, 0.0, cu(g["feat"]), np.arange(64) % 4, 6)
+    assert prob.shape == (64, 4) and torch.allclose(prob.norm(dim=1), torch.ones(64, device="cuda"), atol=1e-5)
