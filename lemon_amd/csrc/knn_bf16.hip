@@ -303,6 +303,7 @@ __global__ __launch_bounds__(NT, 2) void k_scan_bf16(ScanParamsH p) {
     const int KT = p.dpad_h / BKH;
     const int total = ntile * KT;
     const int dpad = p.dpad_h / 2;          // row pitch in 4-byte words (stage_ld counts floats)
+    const unsigned voff = (unsigned)(((threadIdx.x >> 3) * dpad + 4 * (threadIdx.x & 7)) * 4);
     const int metric = p.b.metric;
 
     if (tid < BQ) {
@@ -824,7 +825,7 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
         const int panels = (int)(nq_pad / BQ);
         int splits, tiles_per_split;
         lemon_plan_splits(panels, n_tiles, &splits, &tiles_per_split);
-        rc = lemon_ensure_search_ws(idx, nq_pad, splits, dpad_h * 2, CAPH, stream);
+        rc = lemon_ensure_search_ws(idx, nq_pad, splits, (int64_t)panels * splits, dpad_h * 2, CAPH, stream);
         if (rc) return rc;
         // bf16 query panel (pad rows zero), chain norms, measured rounding residuals
         __bf16 *qh = reinterpret_cast<__bf16 *>(idx->ws_qp);
@@ -911,7 +912,7 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
         }
         LEMON_HIP_CHECK(hipGetLastError());
         if (splits > 1) {
-            rc = lemon_launch_merge(idx->ws_part, splits, nq_pad, cn, k, idx->metric, p.b.D, p.b.I, stream);
+            rc = lemon_launch_merge(idx->ws_part, splits, 0, 0, nq_pad, cn, k, idx->metric, p.b.D, p.b.I, stream);
             if (rc) return rc;
         }
         idx->last.algo = LEMON_ALGO_BF16_FILTER;

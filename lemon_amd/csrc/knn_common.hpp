@@ -51,15 +51,21 @@ struct ScanParams {
     int dpad, kk, metric;
     int n_tiles, tiles_per_split, splits;
     int64_t nq_pad;
+    unsigned long long *phase_dbg;   // diagnostic instantiation only: 4 cycle sums
+    int ablate;           // diagnostic instantiation only: 1 = no operand loads, 2 = no barriers (results invalid)
+    int stale;            // new entries per query that trigger a re-selection (fp32 scan)
+    int units_per_wg;     // > 0: balanced decomposition (see lemon_plan_balanced); splits = max pieces per panel
 };
 
 __device__ __forceinline__ int swz(int r, int c) { return r * BK + 4 * (c ^ ((r >> 1) & 7)); }
 
 // global -> register staging of one k-slice: each thread moves 4 16-B chunks per operand.
 // (named registers, not arrays: hipcc keeps by-reference float4 arrays in scratch here)
-__device__ __forceinline__ float4 stage_ld(const float *__restrict__ src, int dpad, int tid, int i) {
-    const int id = tid + NT * i, r = id >> 3, c = id & 7;
-    return *reinterpret_cast<const float4 *>(src + (int64_t)r * dpad + 4 * c);
+// `src` is wave-uniform, `voff` = ((tid>>3)*dpad + 4*(tid&7))*4 the thread's byte offset inside a 32-row
+// block: the load becomes SGPR base + 32-bit VGPR offset (no per-lane 64-bit address arithmetic).
+__device__ __forceinline__ float4 stage_ld(const float *__restrict__ src, int dpad, unsigned voff, int i) {
+    const char *b = reinterpret_cast<const char *>(src + (int64_t)(NT / 8) * i * dpad);
+    return *reinterpret_cast<const float4 *>(b + voff);
 }
 __device__ __forceinline__ void stage_st(float *t, int tid, int i, float4 v) {
     const int id = tid + NT * i, r = id >> 3, c = id & 7;
@@ -67,10 +73,10 @@ __device__ __forceinline__ void stage_st(float *t, int tid, int i, float4 v) {
 }
 #define STAGE_ISSUE(qsrc, xsrc)                                                                     \
     do {                                                                                            \
-        rq0 = stage_ld(qsrc, dpad, tid, 0); rq1 = stage_ld(qsrc, dpad, tid, 1);                     \
-        rq2 = stage_ld(qsrc, dpad, tid, 2); rq3 = stage_ld(qsrc, dpad, tid, 3);                     \
-        rx0 = stage_ld(xsrc, dpad, tid, 0); rx1 = stage_ld(xsrc, dpad, tid, 1);                     \
-        rx2 = stage_ld(xsrc, dpad, tid, 2); rx3 = stage_ld(xsrc, dpad, tid, 3);                     \
+        rq0 = stage_ld(qsrc, dpad, voff, 0); rq1 = stage_ld(qsrc, dpad, voff, 1);                   \
+        rq2 = stage_ld(qsrc, dpad, voff, 2); rq3 = stage_ld(qsrc, dpad, voff, 3);                   \
+        rx0 = stage_ld(xsrc, dpad, voff, 0); rx1 = stage_ld(xsrc, dpad, voff, 1);                   \
+        rx2 = stage_ld(xsrc, dpad, voff, 2); rx3 = stage_ld(xsrc, dpad, voff, 3);                   \
     } while (0)
 #define STAGE_COMMIT(tq_, tx_)                                                                      \
     do {                                                                                            \
@@ -93,77 +99,118 @@ __device__ __forceinline__ u64 pair_load_slot(const u64 *__restrict__ list, int 
     return ok ? list[idx] : 0;
 }
 
-// exact selection on exact keys: keep the kk largest keys (by the full 64-bit key: score, then lower
-// index), packed at the front of the pair list in arbitrary order: bisection on the key bits (8 compares
-// + 8 ballots per lane and step), then ballot-prefix stream compaction.  Needs n0 + n1 >= kk.
-// Returns the kk-th largest key.
-__device__ __forceinline__ u64 pair_select_exact(u64 *__restrict__ list, int n0, int n1, int kk, int lane) {
-    u64 v[8];
+// Exact selection on exact keys.  The pair list is read into NS register slots (64 keys each; the
+// occupied 64-blocks of half 0 first, then those of half 1 -- typical lists fill 2-3 of the 8 possible
+// slots, and the bisection below costs one compare + ballot per slot and step, so NS is specialised).
+// kk-th largest key = largest t with #{key >= t} >= kk, found by bisection on the key bits: the high
+// word (score) first, 32 steps; the low word (index order among equal scores) only when the kk-th
+// score is tied.  Fewer than kk keys: t = 0 (everything survives).
+template <int NS>
+struct PairSlots {
+    u64 v[NS];
+    __device__ __forceinline__ void load(const u64 *__restrict__ list, int n0, int n1, int s0, int lane) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = pair_load_slot(list, lane + 64 * i, n0, n1);
-    // kk-th largest key = largest t with #{key >= t} >= kk.  High word (score) first: 32 steps; the
-    // low word (index order among equal scores) only matters when the kk-th score is tied.
-    u32 th_hi = 0;
-    int c_hi = 0;                                       // #{score-word >= th_hi} at the end (>= kk)
-#pragma unroll 1
-    for (int bit = 31; bit >= 0; --bit) {
-        const u32 cand = th_hi | (1u << bit);
-        int c = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) c += __builtin_popcountll(__ballot((u32)(v[i] >> 32) >= cand));
-        if (c >= kk) { th_hi = cand; c_hi = c; }        // wave-uniform
+        for (int j = 0; j < NS; ++j) {
+            const bool lo = j < s0;
+            const int pos = lane + 64 * (lo ? j : j - s0);
+            const bool ok = lo ? pos < n0 : pos < n1;
+            v[j] = ok ? list[lo ? pos : PAIR_CAP / 2 + pos] : 0;
+        }
     }
-    u64 t = (u64)th_hi << 32;                           // all keys with a larger score word are in
-    if (th_hi == 0 || c_hi != kk) {                     // tie at the kk-th score (or c_hi never set): refine
+    __device__ __forceinline__ u64 kth(int kk) const {
+        u32 th_hi = 0;
+        int c_hi = 0;                                   // #{score-word >= th_hi} at the end (>= kk)
 #pragma unroll 1
         for (int bit = 31; bit >= 0; --bit) {
-            const u64 cand = t | (1ull << bit);
+            const u32 cand = th_hi | (1u << bit);
             int c = 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) c += __builtin_popcountll(__ballot(v[i] >= cand));
-            if (c >= kk) t = cand;
+            for (int i = 0; i < NS; ++i) c += __builtin_popcountll(__ballot((u32)(v[i] >> 32) >= cand));
+            if (c >= kk) { th_hi = cand; c_hi = c; }    // wave-uniform
         }
-    } else {
-        // exactly kk keys have score word >= th_hi: the kk-th key is the smallest of them
-        u64 mn = ~0ull;
+        u64 t = (u64)th_hi << 32;                       // all keys with a larger score word are in
+        if (th_hi == 0 || c_hi != kk) {                 // tie at the kk-th score (or c_hi never set): refine
+#pragma unroll 1
+            for (int bit = 31; bit >= 0; --bit) {
+                const u64 cand = t | (1ull << bit);
+                int c = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) if ((u32)(v[i] >> 32) >= th_hi && v[i] < mn) mn = v[i];
+                for (int i = 0; i < NS; ++i) c += __builtin_popcountll(__ballot(v[i] >= cand));
+                if (c >= kk) t = cand;
+            }
+        } else {
+            // exactly kk keys have score word >= th_hi: the kk-th key is the smallest of them
+            u64 mn = ~0ull;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(mn, off); mn = o < mn ? o : mn; }
-        t = mn;
+            for (int i = 0; i < NS; ++i) if ((u32)(v[i] >> 32) >= th_hi && v[i] < mn) mn = v[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(mn, off); mn = o < mn ? o : mn; }
+            t = mn;
+        }
+        return t;
     }
-    const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    int base = 0;
+    // survivors (key >= t, non-empty) packed to dst[0..) in arbitrary order; returns their count
+    __device__ __forceinline__ int compact(u64 *__restrict__ dst, u64 t, int lane) const {
+        const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        int base = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const bool keep = v[i] >= t && v[i] != 0;
-        const u64 m = __ballot(keep);
-        if (keep) list[base + __builtin_popcountll(m & below)] = v[i];
-        base += __builtin_popcountll(m);
+        for (int i = 0; i < NS; ++i) {
+            const bool keep = v[i] >= t && v[i] != 0;
+            const u64 m = __ballot(keep);
+            if (keep) dst[base + __builtin_popcountll(m & below)] = v[i];
+            base += __builtin_popcountll(m);
+        }
+        return base;
     }
+};
+
+// maintenance: keep the kk largest keys packed at the front of half-list 0; returns the kk-th largest.
+// Needs n0 + n1 >= kk.
+template <int NS>
+__device__ __forceinline__ u64 pair_select_ns(u64 *__restrict__ list, int n0, int n1, int s0, int kk, int lane) {
+    PairSlots<NS> ps;
+    ps.load(list, n0, n1, s0, lane);
+    const u64 t = ps.kth(kk);
+    ps.compact(list, t, lane);                          // all loads above precede these stores
     return t;
 }
+__device__ __forceinline__ u64 pair_select_exact(u64 *__restrict__ list, int n0, int n1, int kk, int lane) {
+    const int s0 = (n0 + 63) >> 6, ns = s0 + ((n1 + 63) >> 6);   // wave-uniform
+    if (ns <= 2) return pair_select_ns<2>(list, n0, n1, s0, kk, lane);
+    if (ns == 3) return pair_select_ns<3>(list, n0, n1, s0, kk, lane);
+    if (ns == 4) return pair_select_ns<4>(list, n0, n1, s0, kk, lane);
+    return pair_select_ns<8>(list, n0, n1, s0, kk, lane);
+}
 
-// sort the best kk keys of a pair list to the front of half-list 0 (best first) by 128-key rank
-// merges; returns how many exist (<= kk).  sk: 256-u64 scratch, sb: 64-u64 scratch (per wave, LDS).
-__device__ __forceinline__ int pair_sort_topk(u64 *__restrict__ list, int n0, int n1, int kk, int lane,
-                                              u64 *__restrict__ sk, u64 *__restrict__ sb) {
-    u64 best = 0;
-#pragma unroll 1
-    for (int base = 0; base < PAIR_CAP; base += 64) {
-        if (base < PAIR_CAP / 2 ? base >= n0 : (base - PAIR_CAP / 2) >= n1) continue;   // wave-uniform
-        const u64 key = pair_load_slot(list, base + lane, n0, n1);
-        const Ranked r = wave_rank_keys(best, key, 0, 0, 128, sk, lane);
-        sb[lane] = 0;
-        __builtin_amdgcn_wave_barrier();
-        if (best && r.r0 < kk) sb[r.r0] = best;
-        if (key && r.r1 < kk) sb[r.r1] = key;
-        __builtin_amdgcn_wave_barrier();
-        best = sb[lane];
-        __builtin_amdgcn_wave_barrier();
+// final: the best kk keys of a pair list, sorted: lane's return value is one surviving key (0 = none)
+// and *pos its position in best-first order (keys are distinct, so ranks are a permutation); lanes
+// without a key get *pos = lane.  sk: >= 64-u64 per-wave LDS scratch.
+template <int NS>
+__device__ __forceinline__ u64 pair_final_ns(const u64 *__restrict__ list, int n0, int n1, int s0, int kk,
+                                             int lane, u64 *__restrict__ sk, int *pos) {
+    PairSlots<NS> ps;
+    ps.load(list, n0, n1, s0, lane);
+    const u64 t = ps.kth(kk);
+    __builtin_amdgcn_wave_barrier();
+    const int cnt = ps.compact(sk, t, lane);            // <= kk <= 64 survivors
+    __builtin_amdgcn_wave_barrier();
+    const u64 mine = lane < cnt ? sk[lane] : 0;
+    __builtin_amdgcn_wave_barrier();
+    int r = 0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        const u32 lo = __builtin_amdgcn_readlane((u32)mine, j), hi = __builtin_amdgcn_readlane((u32)(mine >> 32), j);
+        r += (((u64)hi << 32) | lo) > mine;
     }
-    if (lane < kk) list[lane] = best;
-    return __builtin_popcountll(__ballot(best != 0));
+    *pos = mine ? r : lane;
+    return mine;
+}
+__device__ __forceinline__ u64 pair_final_topk(const u64 *__restrict__ list, int n0, int n1, int kk, int lane,
+                                               u64 *__restrict__ sk, int *pos) {
+    const int s0 = (n0 + 63) >> 6, ns = s0 + ((n1 + 63) >> 6);
+    if (ns <= 2) return pair_final_ns<2>(list, n0, n1, s0, kk, lane, sk, pos);
+    if (ns <= 4) return pair_final_ns<4>(list, n0, n1, s0, kk, lane, sk, pos);
+    return pair_final_ns<8>(list, n0, n1, s0, kk, lane, sk, pos);
 }
 
 // final write-out of a sorted per-row key list (lane < kk holds / reads entry `lane`)
@@ -192,9 +239,10 @@ inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
 // host helpers implemented in knn_f32.hip
 int lemon_permute_rows(const float *src, int64_t n, int d, float *dst, int dpad, hipStream_t s);
-int lemon_launch_merge(const u64 *part, int splits, int64_t nq_pad, int64_t nq, int kk, int metric, float *D,
+int lemon_launch_merge(const u64 *part, int splits, int n_tiles, int units_per_wg, int64_t nq_pad, int64_t nq, int kk, int metric, float *D,
                        int64_t *I, hipStream_t stream);
 int lemon_fill_empty(float *D, int64_t *I, int64_t total, int metric, hipStream_t stream);
 void lemon_plan_splits(int panels, int n_tiles, int *splits, int *tiles_per_split);
-int lemon_ensure_search_ws(lemon_index_t *idx, int64_t nq_pad, int splits, int qp_row_bytes, int cand_cap,
+void lemon_plan_balanced(int panels, int n_tiles, unsigned *grid, int *units_per_wg, int *splits, int *tiles_per_split);
+int lemon_ensure_search_ws(lemon_index_t *idx, int64_t nq_pad, int splits, int64_t n_wg, int qp_row_bytes, int cand_cap,
                            hipStream_t stream);

@@ -77,34 +77,55 @@ __device__ __forceinline__ void f32_filter_tile(f32x16 a, float th, int64_t jb, 
 // One workgroup = 128 queries x a range of 128-row database tiles.  Wave w owns queries 32w..32w+31
 // (B operand, one query per lane pair) against all 128 rows of the tile (A operand, 4 row tiles):
 // acc_i[e] = <x_(32i + (e&3) + 8(e>>2) + 4h), q_(32w + lane&31)> accumulated in ascending k.
-template <bool L2>
+template <bool L2, bool PROF>
 __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
+    // diagnostic instantiation: per-phase cycle sums of wave 0 (loop incl. barriers, filter, maintenance, final)
+    unsigned long long ts = 0, ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0;
+#define PH_STAMP(acc) do { if (PROF) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - ts; ts = now_; } } while (0)
+    if (PROF) ts = __builtin_amdgcn_s_memtime();
     __shared__ __attribute__((aligned(16))) float s_tile[2][2][BQ * BK];  // [buf][Q|X][row*32+..] 64 KiB
     __shared__ __attribute__((aligned(16))) u64 s_keys[NT / 64][256];    // rank-merge scratch, one per wave
-    __shared__ __attribute__((aligned(16))) u64 s_best[NT / 64][64];
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
 
-    const int panel = blockIdx.x / p.splits;
-    const int split = blockIdx.x % p.splits;
-    const int64_t q0 = (int64_t)panel * BQ;
-    const int t_begin = split * p.tiles_per_split;
-    int t_end = t_begin + p.tiles_per_split;
+    // work range in flattened (panel, tile) units: legacy = one (panel, split) per workgroup; balanced =
+    // equal unit counts per workgroup, a range may cross panel boundaries (one segment per panel touched)
+    int64_t ub, ue;
+    if (p.units_per_wg > 0) {
+        ub = (int64_t)blockIdx.x * p.units_per_wg;
+        ue = ub + p.units_per_wg;
+        const int64_t units = (p.nq_pad / BQ) * p.n_tiles;
+        if (ue > units) ue = units;
+    } else {
+        const int pnl = blockIdx.x / p.splits, spl = blockIdx.x % p.splits;
+        ub = (int64_t)pnl * p.n_tiles + (int64_t)spl * p.tiles_per_split;
+        ue = ub + p.tiles_per_split;
+        if (ue > (int64_t)(pnl + 1) * p.n_tiles) ue = (int64_t)(pnl + 1) * p.n_tiles;
+    }
+    const int KT = p.dpad / BK;
+    const int dpad = p.dpad;
+    const unsigned voff = (unsigned)(((tid >> 3) * dpad + 4 * (tid & 7)) * 4);
+    u64 *cand_panel = p.cand + (int64_t)blockIdx.x * BQ * PAIR_CAP;
+    const int qrow_l = 32 * wave + l31;
+    u64 *mylist = cand_panel + (int64_t)qrow_l * PAIR_CAP + h * (PAIR_CAP / 2);
+
+    while (ub < ue) {                                   // workgroup-uniform
+    const int panel = (int)(ub / p.n_tiles);
+    const int t_begin = (int)(ub - (int64_t)panel * p.n_tiles);
+    int t_end = t_begin + (int)(ue - ub);
     if (t_end > p.n_tiles) t_end = p.n_tiles;
     const int ntile = t_end - t_begin;           // >= 1 by construction
-    const int KT = p.dpad / BK;
+    const int split = p.units_per_wg > 0 ? (int)(blockIdx.x - ((int64_t)panel * p.n_tiles) / p.units_per_wg)
+                                         : (int)(blockIdx.x % p.splits);
+    ub += ntile;
+    const int64_t q0 = (int64_t)panel * BQ;
     const int total = ntile * KT;
-    const int dpad = p.dpad;
 
     // lane-private candidate state (see knn_common.hpp "pair lists")
-    const int qrow_l = 32 * wave + l31;
     const bool qvalid = q0 + qrow_l < p.nq;
     const float my_qn = L2 ? p.qnorm[q0 + qrow_l] : 0.0f;
-    u64 *cand_panel = p.cand + (int64_t)blockIdx.x * BQ * PAIR_CAP;
-    u64 *mylist = cand_panel + (int64_t)qrow_l * PAIR_CAP + h * (PAIR_CAP / 2);
     int ccnt = 0, clast = 0;
     float th = qvalid ? -INFINITY : INFINITY;    // exact score of the query's current k-th best
 
@@ -125,7 +146,8 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
         const int cur = it & 1;
         int kt_n = kt + 1, jl_n = jl;
         if (kt_n == KT) { kt_n = 0; jl_n = jl + 1; }
-        if (it + 1 < total) {
+        const bool abl_ld = PROF && (p.ablate & 1), abl_bar = PROF && (p.ablate & 2);
+        if (it + 1 < total && !abl_ld) {
             const float *qs = qbase + kt_n * BK;
             const float *xs = xbase + (int64_t)jl_n * BX * dpad + kt_n * BK;
             STAGE_ISSUE(qs, xs);
@@ -152,8 +174,12 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
             }
         }
 
+        // commit the next stage BEFORE the epilogue: its vmcnt(0) must not also wait for this tile's appends
+        if (it + 1 < total && !abl_ld) STAGE_COMMIT(s_tile[cur ^ 1][0], s_tile[cur ^ 1][1]);
+
         if (kt == KT - 1) {
             // ---- epilogue: filter into the lane-private half-lists, then zero the accumulators ----
+            PH_STAMP(ph0);
             const int64_t jb = (int64_t)(t_begin + jl) * BX + 4 * h;
             f32_filter_tile<L2>(acc0, th, jb, my_qn, p.xnorm, p.n, ccnt, mylist);
             f32_filter_tile<L2>(acc1, th, jb + 32, my_qn, p.xnorm, p.n, ccnt, mylist);
@@ -163,9 +189,10 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
             for (int e = 0; e < 16; ++e) { acc0[e] = 0.0f; acc1[e] = 0.0f; acc2[e] = 0.0f; acc3[e] = 0.0f; }
 
             // ---- maintenance: select the exact top-kk of queries whose lists grew enough ----
+            PH_STAMP(ph1);
             const int pair = ccnt + __shfl_xor(ccnt, 32);
             const bool warm = th == -INFINITY && pair >= p.kk;
-            const bool stale = pair >= p.kk && pair - clast >= 96;
+            const bool stale = pair >= p.kk && pair - clast >= p.stale;
             const bool full = ccnt > PAIR_CAP / 2 - BX / 2;
             u64 todo = __ballot(qvalid && (warm || stale || full));
             todo = (todo | (todo >> 32)) & 0xffffffffull;          // one bit per query of this wave
@@ -184,14 +211,15 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
                     }
                 } while (todo);
             }
+            PH_STAMP(ph2);
         }
 
-        if (it + 1 < total) STAGE_COMMIT(s_tile[cur ^ 1][0], s_tile[cur ^ 1][1]);
-        __syncthreads();
+        if (!abl_bar) __syncthreads();
         kt = kt_n; jl = jl_n;
     }
 
     // ---- final: sort every query's best kk, write the result rows ------------------------------
+    PH_STAMP(ph0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int r = 0; r < 32; ++r) {
         const int row = 32 * wave + r;
@@ -199,23 +227,34 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
         if (q >= p.nq) break;
         u64 *list = cand_panel + (int64_t)row * PAIR_CAP;
         const int n0 = __builtin_amdgcn_readlane(ccnt, r), n1 = __builtin_amdgcn_readlane(ccnt, r + 32);
-        const int have = pair_sort_topk(list, n0, n1, p.kk, lane, s_keys[wave], s_best[wave]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const u64 key = (lane < have && lane < p.kk) ? list[lane] : 0;
-        write_out_row(p, split, q, lane, key);
+        int pos;
+        const u64 key = pair_final_topk(list, n0, n1, p.kk, lane, s_keys[wave], &pos);
+        write_out_row(p, split, q, pos, key);
     }
+    PH_STAMP(ph3);
+    __syncthreads();                                    // LDS tiles and lists are reused by the next segment
+    }
+    if (PROF && tid == 0) {
+        atomicAdd(&p.phase_dbg[0], ph0); atomicAdd(&p.phase_dbg[1], ph1);
+        atomicAdd(&p.phase_dbg[2], ph2); atomicAdd(&p.phase_dbg[3], ph3);
+    }
+#undef PH_STAMP
 }
 
 // merge the per-split sorted lists of one query (one wavefront per query)
-__global__ __launch_bounds__(256) void k_merge(const u64 *__restrict__ part, int splits, int64_t nq_pad,
-                                               int64_t nq, int kk, int metric, float *__restrict__ D,
-                                               int64_t *__restrict__ I) {
+__global__ __launch_bounds__(256) void k_merge(const u64 *__restrict__ part, int splits, int n_tiles,
+                                               int units_per_wg, int64_t nq_pad, int64_t nq, int kk, int metric,
+                                               float *__restrict__ D, int64_t *__restrict__ I) {
     __shared__ __attribute__((aligned(16))) u64 s_keys[4][256];
     __shared__ __attribute__((aligned(16))) u64 s_best[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * 4 + wave;
     if (q >= nq) return;
     u64 best = 0;  // lane i: i-th best so far
+    if (units_per_wg > 0) {   // balanced decomposition: pieces of this query's panel = workgroups touching it
+        const int64_t u0 = (q / BQ) * n_tiles;
+        splits = (int)((u0 + n_tiles - 1) / units_per_wg - u0 / units_per_wg) + 1;
+    }
     const int total = splits * kk;
     for (int base = 0; base < total; base += 192) {
         u64 v[3];
@@ -274,10 +313,10 @@ int lemon_permute_rows(const float *src, int64_t n, int d, float *dst, int dpad,
     return LEMON_OK;
 }
 
-int lemon_launch_merge(const u64 *part, int splits, int64_t nq_pad, int64_t nq, int kk, int metric, float *D,
-                       int64_t *I, hipStream_t stream) {
-    hipLaunchKernelGGL(k_merge, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, part, splits, nq_pad, nq, kk,
-                       metric, D, I);
+int lemon_launch_merge(const u64 *part, int splits, int n_tiles, int units_per_wg, int64_t nq_pad, int64_t nq,
+                       int kk, int metric, float *D, int64_t *I, hipStream_t stream) {
+    hipLaunchKernelGGL(k_merge, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, part, splits, n_tiles,
+                       units_per_wg, nq_pad, nq, kk, metric, D, I);
     LEMON_HIP_CHECK(hipGetLastError());
     return LEMON_OK;
 }
@@ -293,7 +332,11 @@ int lemon_fill_empty(float *D, int64_t *I, int64_t total, int metric, hipStream_
 // per-split warm-up (first-tile selection, final sort, merge) amortises
 void lemon_plan_splits(int panels, int n_tiles, int *splits_out, int *tiles_per_split_out) {
     int splits = 1;
-    if (panels < 768) {
+    static const int forced = [] { const char *e = getenv("LEMON_SPLITS"); return e ? atoi(e) : 0; }();   // tuning knob
+    if (forced > 0) {
+        splits = forced;
+        if (splits > n_tiles) splits = n_tiles;
+    } else if (panels < 768) {
         splits = (768 + panels - 1) / panels;
         int max_splits = n_tiles / 8;
         if (max_splits < 1) max_splits = 1;
@@ -304,11 +347,49 @@ void lemon_plan_splits(int panels, int n_tiles, int *splits_out, int *tiles_per_
     *tiles_per_split_out = tiles_per_split;
 }
 
+// Balanced ("stream-K") decomposition of the fp32 scan.  One workgroup alone on a CU reaches only about
+// half the MFMA rate of two co-resident ones, so a grid that is not a multiple of 2 x CUs pays a whole
+// extra round (391 panels ran as slowly as 512).  Instead the panels x tiles unit space is cut into equal
+// contiguous ranges, one per resident slot; a range that crosses a panel boundary yields one partial list
+// per panel touched and k_merge combines the pieces.  *splits_out = max pieces per panel.
+void lemon_plan_balanced(int panels, int n_tiles, unsigned *grid_out, int *units_per_wg_out, int *splits_out,
+                         int *tiles_per_split_out) {
+    static const int slots = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return 2 * (cus > 0 ? cus : 256);
+    }();
+    static const bool legacy = getenv("LEMON_SPLITS") != nullptr;
+    const int64_t units = (int64_t)panels * n_tiles;
+    if (legacy || units < 2) {
+        lemon_plan_splits(panels, n_tiles, splits_out, tiles_per_split_out);
+        *grid_out = (unsigned)(panels * *splits_out);
+        *units_per_wg_out = 0;
+        return;
+    }
+    int64_t g = units / 8;                               // every workgroup keeps >= 8 tiles
+    if (g < 1) g = 1;
+    static const int rounds = [] { const char *e = getenv("LEMON_ROUNDS"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
+    if (g > (int64_t)slots * rounds) g = (int64_t)slots * rounds;
+    const int64_t u = (units + g - 1) / g;
+    g = (units + u - 1) / u;
+    int pieces = 1;
+    for (int pnl = 0; pnl < panels; ++pnl) {
+        const int64_t u0 = (int64_t)pnl * n_tiles;
+        const int c = (int)((u0 + n_tiles - 1) / u - u0 / u) + 1;
+        if (c > pieces) pieces = c;
+    }
+    *grid_out = (unsigned)g;
+    *units_per_wg_out = (int)u;
+    *splits_out = pieces;
+    *tiles_per_split_out = n_tiles;
+}
+
 // qp_row_bytes: bytes of one staged query row (dpad*4 for the fp32 scan, dpad_h*2 for the bf16 one)
-int lemon_ensure_search_ws(lemon_index_t *idx, int64_t nq_pad, int splits, int qp_row_bytes, int cand_cap,
-                           hipStream_t stream) {
+int lemon_ensure_search_ws(lemon_index_t *idx, int64_t nq_pad, int splits, int64_t n_wg, int qp_row_bytes,
+                           int cand_cap, hipStream_t stream) {
     const int64_t part_elems = (splits > 1) ? (int64_t)splits * nq_pad * LEMON_MAX_K : 0;
-    const int64_t cand_rows = nq_pad * splits * (cand_cap / CAP);   // in units of CAP-entry rows
+    const int64_t cand_rows = n_wg * BQ * (cand_cap / CAP);         // in units of CAP-entry rows
     int64_t row_bytes = (int64_t)idx->dpad * 4 > qp_row_bytes ? (int64_t)idx->dpad * 4 : qp_row_bytes;
     if (row_bytes < idx->ws_qp_row_bytes) row_bytes = idx->ws_qp_row_bytes;
     if (nq_pad > idx->ws_q || row_bytes > idx->ws_qp_row_bytes) {
@@ -359,10 +440,11 @@ int lemon_search_f32(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, 
         const int64_t cn = (nq - c0) < QCHUNK ? (nq - c0) : QCHUNK;
         const int64_t nq_pad = round_up(cn, BQ);
         const int panels = (int)(nq_pad / BQ);
-        int splits, tiles_per_split;
-        lemon_plan_splits(panels, n_tiles, &splits, &tiles_per_split);
+        int splits, tiles_per_split, units_per_wg;
+        unsigned grid;
+        lemon_plan_balanced(panels, n_tiles, &grid, &units_per_wg, &splits, &tiles_per_split);
 
-        int rc = lemon_ensure_search_ws(idx, nq_pad, splits, dpad * 4, PAIR_CAP, stream);
+        int rc = lemon_ensure_search_ws(idx, nq_pad, splits, grid, dpad * 4, PAIR_CAP, stream);
         if (rc) return rc;
         // permuted, zero-padded query panel (+ chain norms for L2)
         LEMON_HIP_CHECK(hipMemsetAsync(idx->ws_qp, 0, (size_t)nq_pad * dpad * sizeof(float), stream));
@@ -379,17 +461,32 @@ int lemon_search_f32(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, 
         p.D = D_dev + c0 * k; p.I = I_dev + c0 * k;
         p.nq = cn; p.n = idx->n; p.dpad = dpad; p.kk = k; p.metric = idx->metric;
         p.n_tiles = n_tiles; p.tiles_per_split = tiles_per_split; p.splits = splits; p.nq_pad = nq_pad;
-        const unsigned grid = (unsigned)(panels * splits);
+        p.units_per_wg = units_per_wg; p.phase_dbg = nullptr;
+        p.ablate = getenv("LEMON_ABLATE") ? atoi(getenv("LEMON_ABLATE")) : 0;   // diagnostic instantiation only
+        static const int stale = [] { const char *e = getenv("LEMON_STALE"); return e && atoi(e) > 0 ? atoi(e) : 96; }();
+        p.stale = stale;
         {
             const double flops = 2.0 * (double)cn * (double)idx->n * (double)d;
             const double bytes = 4.0 * d * ((double)cn + (double)panels * (double)idx->n) + 12.0 * k * (double)cn;
             LemonProfScope prof(idx, stream, flops, bytes);
-            if (idx->metric == LEMON_METRIC_L2) hipLaunchKernelGGL(k_scan_f32<true>, dim3(grid), dim3(NT), 0, stream, p);
-            else hipLaunchKernelGGL(k_scan_f32<false>, dim3(grid), dim3(NT), 0, stream, p);
+            if (idx->metric == LEMON_METRIC_IP && getenv("LEMON_PHASE_PROF")) {   // diagnostic build: phase cycle sums
+                static unsigned long long *dbg = nullptr;
+                if (!dbg) { (void)hipMalloc(&dbg, 64); (void)hipMemset(dbg, 0, 64); }
+                p.phase_dbg = dbg;
+                hipLaunchKernelGGL((k_scan_f32<false, true>), dim3(grid), dim3(NT), 0, stream, p);
+                (void)hipStreamSynchronize(stream);
+                unsigned long long h[8]; (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
+                const double tot = (double)(h[0] + h[1] + h[2] + h[3]);
+                fprintf(stderr, "[phase f32] grid=%u loop=%.1f%% filter=%.1f%% maintain=%.1f%% final=%.1f%% cyc/WG=%.3g\n",
+                        grid, 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, tot / grid);
+                (void)hipMemset(dbg, 0, 64);
+            } else if (idx->metric == LEMON_METRIC_L2) hipLaunchKernelGGL((k_scan_f32<true, false>), dim3(grid), dim3(NT), 0, stream, p);
+            else hipLaunchKernelGGL((k_scan_f32<false, false>), dim3(grid), dim3(NT), 0, stream, p);
         }
         LEMON_HIP_CHECK(hipGetLastError());
         if (splits > 1) {
-            rc = lemon_launch_merge(idx->ws_part, splits, nq_pad, cn, k, idx->metric, p.D, p.I, stream);
+            rc = lemon_launch_merge(idx->ws_part, splits, n_tiles, units_per_wg, nq_pad, cn, k, idx->metric, p.D,
+                                    p.I, stream);
             if (rc) return rc;
         }
         idx->last.algo = LEMON_ALGO_F32_MFMA;

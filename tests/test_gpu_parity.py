@@ -64,6 +64,8 @@ def _assert_knn_equal(got, ref):
 @pytest.mark.parametrize("nq,n,d,k", [
     (1, 1, 8, 1), (5, 3, 16, 5), (130, 1000, 40, 10), (128, 128, 32, 64), (257, 1300, 64, 51),
     (64, 5000, 512, 50), (300, 2049, 768, 5), (1100, 3000, 100, 1), (33, 40000, 96, 51),
+    # balanced decomposition: workgroup ranges that cross panel boundaries, 1-3 pieces per panel
+    (700, 128 * 37, 64, 20), (900, 5000, 48, 33), (70000, 1500, 32, 10), (66000, 128 * 9, 40, 64),
 ])
 def test_flat_search_bit_exact(hip, oracle, metric, nq, n, d, k):
     rng = np.random.default_rng(nq * 7 + n * 3 + d + k)
