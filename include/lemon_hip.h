@@ -81,6 +81,15 @@ int lemon_d1_normalized(int metric, const float *q_img_dev, int64_t n, int d,
  * x_dev must be 16-byte aligned. */
 int lemon_quick_gelu(float *x_dev, int64_t n, void *stream);
 
+/* Multi-head self-attention of the CLIP towers, fused to one pass: the attention inside
+ * encode_image / encode_text (lib/models/downstream_models.py:37-41 -> HF CLIPAttention; in-tree twin
+ * lib/models/chexzero_clip.py:191-212 with the causal mask of :348-354 for text).
+ * qkv_dev [batch, seq_len, 3, heads, head_dim] float32 = the fused q/k/v projection output;
+ * out_dev [batch, seq_len, heads*head_dim] = softmax(q k^T / sqrt(head_dim) [+ causal]) v with heads
+ * concatenated, ready for the output projection.  head_dim must be 64, seq_len <= 288. */
+int lemon_attention_f32(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
+                        int causal, float *out_dev, void *stream);
+
 /* ---- flat index (faiss.IndexFlatIP / IndexFlatL2 as used by run_lemon.py) ---------- */
 
 /* faiss.IndexFlatIP(d) / faiss.IndexFlatL2(d): run_lemon.py:167-168,171-172;

@@ -90,11 +90,17 @@ class Block(nn.Module):
 
     def forward(self, x, causal):
         B, L, W = x.shape
-        q, k, v = self.qkv(self.ln1(x)).view(B, L, 3, self.heads, W // self.heads).permute(2, 0, 3, 1, 4)
-        a = F.scaled_dot_product_attention(q, k, v, is_causal=causal)
-        x = x + self.out(a.transpose(1, 2).reshape(B, L, W))
+        qkv = self.qkv(self.ln1(x))
+        fused = x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+        if fused and W == 64 * self.heads and L <= 288:
+            from .ops import attention              # one HIP pass: no [B,H,L,L] matrix, no permute copies
+            a = attention(qkv, self.heads, causal)
+        else:
+            q, k, v = qkv.view(B, L, 3, self.heads, W // self.heads).permute(2, 0, 3, 1, 4)
+            a = F.scaled_dot_product_attention(q, k, v, is_causal=causal).transpose(1, 2).reshape(B, L, W)
+        x = x + self.out(a)
         h = self.fc1(self.ln2(x))
-        if h.is_cuda and h.dtype == torch.float32 and not torch.is_grad_enabled():
+        if fused:
             from .ops import quick_gelu_           # fused HIP pass (3 elementwise kernels -> 1)
             h = quick_gelu_(h)
         else:

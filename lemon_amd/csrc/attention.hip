@@ -1,0 +1,160 @@
+// Fused multi-head self-attention for the CLIP towers of the embedding stage (gfx950 only).
+//
+// Replaces, inside encode_image / encode_text (lib/models/downstream_models.py:30-41 -> HF CLIPAttention;
+// in-tree twin lib/models/chexzero_clip.py:191-212 nn.MultiheadAttention), the chain
+//   view/permute(qkv) -> softmax(q k^T / sqrt(hd) [+ causal mask]) v -> transpose -> reshape
+// with ONE pass: reads the packed projection output qkv[B, L, 3, H, 64] (what the fused QKV GEMM
+// writes) and writes out[B, L, H*64] (what the output projection reads).  No [B,H,L,L] matrix, no
+// permute copies: algorithmic HBM traffic 16*H*64 B per token (3 reads + 1 write).
+//
+// One workgroup per (batch, head); wave t owns queries 32t..32t+31.  K and V of the head are staged in
+// LDS (row pitch 68 floats: 16-B aligned, conflict-free 128-bit reads).  Per 32-key tile:
+//   S^T = K Q^T      32 x v_mfma_f32_32x32x2_f32   A = K rows from LDS, B = the wave's Q rows (registers)
+//                    -> lane (i = lane&31, h) holds its OWN query's 16 scores: softmax statistics are
+//                       in-lane reductions plus one cross-half shuffle (flash-style running max / sum)
+//   O^T += V^T P^T   2 x 16 MFMAs: B = the score registers as they are, A = V columns from LDS
+// fp32 throughout (the reference runs the encoders in fp32).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int HD = 64;        // head dimension (every CLIP variant the reference loads: 768/12, 512/8, 1024/16)
+constexpr int PITCH = 68;     // LDS row pitch in floats
+
+__global__ __launch_bounds__(576) void k_attention_hd64(const float *__restrict__ qkv, int L, int H, int causal,
+                                                        float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int TJ = (L + 31) >> 5;                 // key tiles
+    float *sK = smem;                             // [32*TJ][PITCH]
+    float *sV = smem + (size_t)32 * TJ * PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int64_t b = blockIdx.x / H;
+    const int head = blockIdx.x % H;
+    const int64_t tok_stride = (int64_t)3 * H * HD;            // floats between consecutive tokens
+    const float *base = qkv + b * L * tok_stride + head * HD;  // q of token 0; k at +H*HD, v at +2*H*HD
+
+    // ---- stage K and V (zero rows beyond L: masked scores give p = 0 and 0 * 0 stays 0) ----
+    for (int id = tid; id < 32 * TJ * 16; id += blockDim.x) {
+        const int r = id >> 4, c = id & 15;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (r < L) {
+            const float *src = base + (int64_t)r * tok_stride + 4 * c;
+            kv = *reinterpret_cast<const float4 *>(src + H * HD);
+            vv = *reinterpret_cast<const float4 *>(src + 2 * H * HD);
+        }
+        *reinterpret_cast<float4 *>(&sK[r * PITCH + 4 * c]) = kv;
+        *reinterpret_cast<float4 *>(&sV[r * PITCH + 4 * c]) = vv;
+    }
+
+    // ---- this lane's query row, columns 32h..32h+31 (the k-index pairing of MFMA #1) ----
+    const int qi = 32 * wave + l31;
+    const int qrow = qi < L ? qi : L - 1;
+    float q[32];
+    {
+        const float *src = base + (int64_t)qrow * tok_stride + 32 * h;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 t = *reinterpret_cast<const float4 *>(src + 4 * u);
+            q[4 * u] = t.x; q[4 * u + 1] = t.y; q[4 * u + 2] = t.z; q[4 * u + 3] = t.w;
+        }
+    }
+    __syncthreads();
+
+    f32x16 o0, o1;                                 // O^T tiles: output columns 0..31 and 32..63 of query qi
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;          // running max (raw dot units) and sum of this query
+    const float c_exp = 0.125f * 1.44269504088896340736f;   // 1/sqrt(64) * log2(e)
+
+    const int tj_end = causal ? (wave + 1 < TJ ? wave + 1 : TJ) : TJ;   // causal: key tiles beyond the query tile are empty
+    for (int tj = 0; tj < tj_end; ++tj) {
+        // S^T tile = K[32tj.., :] Q^T : lane (i, h) gets scores of keys j = 32tj + (e&3) + 8(e>>2) + 4h
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        const float *krow = &sK[(32 * tj + l31) * PITCH + 32 * h];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 k4 = *reinterpret_cast<const float4 *>(krow + 4 * u);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, q[4 * u], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, q[4 * u + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, q[4 * u + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, q[4 * u + 3], s, 0, 0, 0);
+        }
+        // mask (padding keys, causal) and tile max
+        float mt = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int j = 32 * tj + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const bool ok = j < L && (!causal || j <= qi);
+            s[e] = ok ? s[e] : -INFINITY;
+            mt = fmaxf(mt, s[e]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);      // finite from the first tile on (key 0 is visible to every query)
+        const float alpha = exp2f((m_run - m_new) * c_exp);
+        float lt = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            s[e] = exp2f((s[e] - m_new) * c_exp);
+            lt += s[e];
+        }
+        lt += __shfl_xor(lt, 32);
+        l_run = l_run * alpha + lt;
+        m_run = m_new;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+        // O^T += V^T P^T : k-step m pairs keys (m&3) + 8(m>>2) + 4h of the tile, i.e. s[m] as it lies
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const float *vrow = &sV[(32 * tj + (m & 3) + 8 * (m >> 2) + 4 * h) * PITCH + l31];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], s[m], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], s[m], o1, 0, 0, 0);
+        }
+    }
+
+    if (qi < L) {
+        const float inv = 1.0f / l_run;
+        float *dst = out + ((b * L + qi) * H + head) * HD;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = 8 * g + 4 * h;
+            *reinterpret_cast<float4 *>(dst + c0) =
+                make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            *reinterpret_cast<float4 *>(dst + 32 + c0) =
+                make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int lemon_attention_f32(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
+                                   int causal, float *out_dev, void *stream) {
+    LEMON_REQUIRE(batch >= 0 && seq_len > 0 && heads > 0, "batch >= 0, seq_len > 0, heads > 0");
+    LEMON_REQUIRE(head_dim == HD, "head_dim must be 64");
+    LEMON_REQUIRE(seq_len <= 288, "seq_len <= 288 (K and V of one head are staged in LDS)");
+    if (batch == 0) return LEMON_OK;
+    LEMON_REQUIRE(qkv_dev && out_dev, "null pointer");
+    LEMON_REQUIRE((((uintptr_t)qkv_dev) & 15) == 0 && (((uintptr_t)out_dev) & 15) == 0, "16-byte alignment");
+    LEMON_REQUIRE(batch * heads < (int64_t)1 << 31, "batch * heads < 2^31");
+    const int tj = (seq_len + 31) / 32;
+    const size_t lds = (size_t)2 * 32 * tj * PITCH * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attention_hd64),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_attention_hd64, dim3((unsigned)(batch * heads)), dim3(64 * tj), lds, (hipStream_t)stream,
+                       qkv_dev, seq_len, heads, causal, out_dev);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}

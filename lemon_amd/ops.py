@@ -82,6 +82,24 @@ def quick_gelu_(x):
     return x
 
 
+ATTENTION_MAX_SEQ = 288
+
+
+def attention(qkv, heads, causal=False):
+    """Fused self-attention on the packed projection output qkv [B, L, 3*W] (float32, contiguous,
+    W = heads*64) -> [B, L, W]; the HIP kernel behind LemonCLIP's blocks."""
+    assert qkv.is_cuda and qkv.dtype == torch.float32 and qkv.is_contiguous() and qkv.dim() == 3
+    B, L, W3 = qkv.shape
+    W = W3 // 3
+    assert W3 == 3 * W and W == heads * 64 and L <= ATTENTION_MAX_SEQ
+    out = torch.empty((B, L, W), dtype=torch.float32, device=qkv.device)
+    lib = _lib.load()
+    with torch.cuda.device(qkv.device):
+        _lib.check(lib.lemon_attention_f32(ptr(qkv), B, L, heads, 64, int(bool(causal)), ptr(out),
+                                           stream_ptr(qkv.device)), "lemon_attention_f32")
+    return out
+
+
 def paired_distance(metric, a, b):
     a, b = dev_f32(a, "a"), dev_f32(b, "b")
     assert a.shape == b.shape and a.dim() == 2
