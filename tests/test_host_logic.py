@@ -132,3 +132,15 @@ def test_host_inputs_are_refused_without_gpu_fallback():
         ops.normalize_vectors(torch.zeros(3, 4))        # CPU tensor: no silent CPU path
     with pytest.raises(TypeError):
         ops.normalize_vectors(np.zeros((3, 4), np.float32))
+
+
+def test_gemm_tuning_results_file_is_well_formed():
+    # lemon_amd/tuning.py: recorded hipBLASLt solutions for the headline encoder shapes
+    from lemon_amd import tuning
+    lines = [l.strip().split(",") for l in open(tuning.RESULTS) if l.strip()]
+    validators = {l[1]: l[2] for l in lines if l[0] == "Validator"}
+    assert validators.get("GCN_ARCH_NAME", "").startswith("gfx950")
+    ops = [l for l in lines if l[0] != "Validator"]
+    assert ops and all(len(l) == 4 and l[0].startswith("Gemm") and float(l[3]) > 0 for l in ops)
+    keys = {l[1] for l in ops}
+    assert "tn_2304_50000_768_ld_768_768_2304" in keys      # ViT-B/32 QKV projection at encoder batch 1000
