@@ -90,6 +90,25 @@ int lemon_quick_gelu(float *x_dev, int64_t n, void *stream);
 int lemon_attention_f32(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
                         int causal, float *out_dev, void *stream);
 
+/* Linear layer of the CLIP towers with its element-wise tail fused into the GEMM:
+ *   y[m,n] = act(alpha x[m,k] W[n,k]^T + bias[n]) (+ residual[m,n])         float32, row-major
+ * (nn.Linear inside HF CLIPEncoderLayer / lib/models/chexzero_clip.py:191-212, driven by
+ * lib/models/downstream_models.py:30-41).  The GEMM runs on hipBLASLt; act = LEMON_ACT_SILU
+ * (u*sigmoid(u)) and the residual add ride in its epilogue.  QuickGELU z*sigmoid(1.702z)
+ * (chexzero_clip.py:186-188) is silu(1.702 z)/1.702: call with alpha = 1.702 and a bias scaled by 1.702,
+ * and give the consuming GEMM alpha = 1/1.702 (lemon_amd/clip.py does).  bias_dev / residual_dev may
+ * be NULL; residual_dev may alias y_dev; activation and residual cannot be combined.  The first call
+ * for a new (m,n,k,epilogue) benchmarks the library's solutions on the caller's stream (synchronises;
+ * bounded by LEMON_LINEAR_TUNE_MS, default 6000) unless lemon_linear_load_tuned() supplied the key. */
+#define LEMON_ACT_NONE 0
+#define LEMON_ACT_SILU 1
+int lemon_linear_f32(const float *x_dev, const float *w_dev, const float *bias_dev, const float *residual_dev,
+                     int64_t m, int n, int k, float alpha, int act, float *y_dev, void *stream);
+/* Recorded solution choices ("m,n,k,epilogue,residual,index,usec" lines): load returns the number of
+ * keys read, dump the number written (<0 on error). */
+int lemon_linear_load_tuned(const char *path);
+int lemon_linear_dump_tuned(const char *path);
+
 /* ---- flat index (faiss.IndexFlatIP / IndexFlatL2 as used by run_lemon.py) ---------- */
 
 /* faiss.IndexFlatIP(d) / faiss.IndexFlatL2(d): run_lemon.py:167-168,171-172;

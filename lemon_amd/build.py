@@ -9,7 +9,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "liblemon_hip.so")
-SOURCES = ["api.hip", "rowwise.hip", "knn_f32.hip", "knn_bf16.hip", "attention.hip"]
+SOURCES = ["api.hip", "rowwise.hip", "knn_f32.hip", "knn_bf16.hip", "attention.hip", "linear.hip"]
 HEADERS = ["common.hpp", os.path.join("..", "..", "include", "lemon_hip.h")]
 
 
@@ -32,7 +32,7 @@ def build_hip(force=False, verbose=False):
     if not force and not needs_build():
         return SO
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result", "-o", SO] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wno-unused-result", "-o", SO] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lhipblaslt"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

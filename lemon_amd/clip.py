@@ -90,22 +90,30 @@ class Block(nn.Module):
 
     def forward(self, x, causal):
         B, L, W = x.shape
-        qkv = self.qkv(self.ln1(x))
         fused = x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
-        if fused and W == 64 * self.heads and L <= 288:
-            from .ops import attention              # one HIP pass: no [B,H,L,L] matrix, no permute copies
-            a = attention(qkv, self.heads, causal)
-        else:
-            q, k, v = qkv.view(B, L, 3, self.heads, W // self.heads).permute(2, 0, 3, 1, 4)
-            a = F.scaled_dot_product_attention(q, k, v, is_causal=causal).transpose(1, 2).reshape(B, L, W)
+        if fused:
+            # inference on the GPU: every GEMM of the block goes through lemon_linear_f32 (bias, QuickGELU
+            # and the residual adds ride in the hipBLASLt epilogue), attention through lemon_attention_f32
+            from . import ops
+            qkv = ops.linear(self.ln1(x), self.qkv.weight, self.qkv.bias)
+            if W == 64 * self.heads and L <= ops.ATTENTION_MAX_SEQ:
+                a = ops.attention(qkv, self.heads, causal)
+            else:
+                a = self._sdpa(qkv, B, L, W, causal)
+            x = ops.linear(a, self.out.weight, self.out.bias, residual=x)
+            # QuickGELU(z) = silu(1.702 z) / 1.702: scale going in (alpha, bias), un-scale in fc2's alpha
+            s = ops.QUICK_GELU_SCALE
+            h = ops.linear(self.ln2(x), self.fc1.weight, self.fc1.bias * s, act="silu", alpha=s)
+            return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=x, alpha=1.0 / s)
+        a = self._sdpa(self.qkv(self.ln1(x)), B, L, W, causal)
         x = x + self.out(a)
         h = self.fc1(self.ln2(x))
-        if fused:
-            from .ops import quick_gelu_           # fused HIP pass (3 elementwise kernels -> 1)
-            h = quick_gelu_(h)
-        else:
-            h = h * torch.sigmoid(1.702 * h)      # QuickGELU
+        h = h * torch.sigmoid(1.702 * h)          # QuickGELU
         return x + self.fc2(h)
+
+    def _sdpa(self, qkv, B, L, W, causal):
+        q, k, v = qkv.view(B, L, 3, self.heads, W // self.heads).permute(2, 0, 3, 1, 4)
+        return F.scaled_dot_product_attention(q, k, v, is_causal=causal).transpose(1, 2).reshape(B, L, W)
 
 
 class VisionTower(nn.Module):

@@ -1,0 +1,276 @@
+// Linear layers of the CLIP towers with the element-wise work fused into the GEMM (gfx950 only).
+//
+//   y = act(alpha x W^T + bias) [+ residual]      x [m,k], W [n,k] (nn.Linear layout), y/residual [m,n], fp32
+//
+// The encoders' GEMMs (encode_image / encode_text, lib/models/downstream_models.py:30-41; MLP and
+// attention projections of HF CLIPEncoderLayer / lib/models/chexzero_clip.py:191-212) are plain library
+// GEMMs: they run on hipBLASLt.  What this file adds is (1) the epilogues PyTorch cannot express --
+// SiLU (hipBLASLt's Swish epilogue; QuickGELU z*sigmoid(1.702z), chexzero_clip.py:186-188, is
+// silu(1.702 z)/1.702: alpha = 1.702 here with a pre-scaled bias, alpha = 1/1.702 in the GEMM that
+// consumes it) and the residual add as the GEMM's beta*C term -- which removes one read+write pass
+// over the [m,3072] MLP activations and both residual-add passes per block, and (2) explicit solution selection: the
+// library's default heuristic is ~15 % off the best solution for the ViT-B/32 shapes, so every
+// (m,n,k,epilogue) key is benchmarked once over the solutions that support it (bounded by a time
+// budget) and the winner's index is cached, in process and in a results file.
+#include <hip/hip_runtime.h>
+#include <hipblaslt/hipblaslt.h>
+#include <hipblaslt/hipblaslt-ext.hpp>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+
+#define LT_CHECK(expr)                                                                              \
+    do {                                                                                            \
+        hipblasStatus_t st_ = (expr);                                                               \
+        if (st_ != HIPBLAS_STATUS_SUCCESS) {                                                        \
+            lemon_set_error("%s failed with hipblasStatus %d (%s:%d)", #expr, (int)st_, __FILE__, __LINE__); \
+            return LEMON_E_HIP;                                                                     \
+        }                                                                                           \
+    } while (0)
+
+typedef std::tuple<int64_t, int, int, int, int> LinKey;   // m, n, k, epilogue, has_residual
+
+struct LinState {
+    std::mutex mu;
+    hipblasLtHandle_t handle = nullptr;
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    std::map<LinKey, hipblasLtMatmulAlgo_t> algo;     // validated for the key in this process
+    std::map<LinKey, int> index;                      // solution index (from file or tuning)
+    std::map<LinKey, float> usec;
+    double tune_budget_ms = 6000.0;
+};
+LinState g_lin;
+
+struct Problem {
+    hipblasLtMatmulDesc_t desc = nullptr;
+    hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr;
+    ~Problem() {
+        if (la) (void)hipblasLtMatrixLayoutDestroy(la);
+        if (lb) (void)hipblasLtMatrixLayoutDestroy(lb);
+        if (lc) (void)hipblasLtMatrixLayoutDestroy(lc);
+        if (desc) (void)hipblasLtMatmulDescDestroy(desc);
+    }
+};
+
+// Row-major y[m,n] = x[m,k] W[n,k]^T is, in hipBLASLt's column-major terms, D[n,m] = op_T(A[k,n]) B[k,m]
+// with A = W (ld k), B = x (ld k), C/D = residual/y (ld n); the bias runs along D's rows (n).
+int make_problem(Problem &p, int64_t m, int n, int k, int epilogue, const float *bias) {
+    LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+    const hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
+    LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)));
+    LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb)));
+    const hipblasLtEpilogue_t epi = (hipblasLtEpilogue_t)epilogue;
+    LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)));
+    if (bias) LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
+    LT_CHECK(hipblasLtMatrixLayoutCreate(&p.la, HIP_R_32F, (uint64_t)k, (uint64_t)n, k));
+    LT_CHECK(hipblasLtMatrixLayoutCreate(&p.lb, HIP_R_32F, (uint64_t)k, (uint64_t)m, k));
+    LT_CHECK(hipblasLtMatrixLayoutCreate(&p.lc, HIP_R_32F, (uint64_t)n, (uint64_t)m, n));
+    return LEMON_OK;
+}
+
+int ensure_state(hipStream_t stream) {
+    if (!g_lin.handle) {
+        LT_CHECK(hipblasLtCreate(&g_lin.handle));
+        if (const char *e = getenv("LEMON_LINEAR_TUNE_MS")) g_lin.tune_budget_ms = atof(e);
+    }
+    if (!g_lin.ws) {
+        g_lin.ws_bytes = (size_t)64 << 20;
+        LEMON_HIP_CHECK(hipMalloc(&g_lin.ws, g_lin.ws_bytes));
+    }
+    (void)stream;
+    return LEMON_OK;
+}
+
+// time one candidate on the caller's stream (D = scratch so that an in-place residual is not accumulated)
+float time_algo(Problem &p, const hipblasLtMatmulAlgo_t &algo, const float *x, const float *w, const float *c,
+                float beta, float *d, int reps, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
+    const float alpha = 1.0f;                            // timing only: the scale does not change the kernel
+    if (hipblasLtMatmul(g_lin.handle, p.desc, &alpha, w, p.la, x, p.lb, &beta, c, p.lc, d, p.lc, &algo, g_lin.ws,
+                        g_lin.ws_bytes, stream) != HIPBLAS_STATUS_SUCCESS)
+        return -1.0f;
+    (void)hipEventRecord(e0, stream);
+    for (int r = 0; r < reps; ++r)
+        (void)hipblasLtMatmul(g_lin.handle, p.desc, &alpha, w, p.la, x, p.lb, &beta, c, p.lc, d, p.lc, &algo, g_lin.ws,
+                              g_lin.ws_bytes, stream);
+    (void)hipEventRecord(e1, stream);
+    if (hipEventSynchronize(e1) != hipSuccess) return -1.0f;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1e3f / reps;
+}
+
+bool supported(Problem &p, hipblasLtMatmulAlgo_t &algo, float beta) {
+    const float alpha = 1.0f;
+    size_t need = 0;
+    return hipblaslt_ext::matmulIsAlgoSupported(g_lin.handle, p.desc, &alpha, p.la, p.lb, &beta, p.lc, p.lc, algo, need) ==
+               HIPBLAS_STATUS_SUCCESS &&
+           need <= g_lin.ws_bytes;
+}
+
+// benchmark the solutions that support this problem; returns the winner (synchronises the stream)
+int tune(const LinKey &key, Problem &p, const float *x, const float *w, const float *residual, int64_t m, int n,
+         hipStream_t stream, hipblasLtMatmulAlgo_t *best_out) {
+    const float beta = residual ? 1.0f : 0.0f;
+    float *scratch = nullptr;
+    LEMON_HIP_CHECK(hipMalloc((void **)&scratch, (size_t)m * n * sizeof(float)));
+    const float *c = residual ? residual : scratch;
+    hipEvent_t e0, e1, t0, t1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventCreate(&t0); (void)hipEventCreate(&t1);
+    (void)hipEventRecord(t0, stream);
+
+    std::vector<hipblasLtMatmulHeuristicResult_t> cand;
+    {   // the library's own ranking first: a sane answer even if the budget runs out early
+        hipblasLtMatmulPreference_t pref = nullptr;
+        if (hipblasLtMatmulPreferenceCreate(&pref) == HIPBLAS_STATUS_SUCCESS) {
+            (void)hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &g_lin.ws_bytes,
+                                                        sizeof(g_lin.ws_bytes));
+            hipblasLtMatmulHeuristicResult_t top[8];
+            int got = 0;
+            if (hipblasLtMatmulAlgoGetHeuristic(g_lin.handle, p.desc, p.la, p.lb, p.lc, p.lc, pref, 8, top, &got) ==
+                HIPBLAS_STATUS_SUCCESS)
+                for (int i = 0; i < got; ++i) cand.push_back(top[i]);
+            (void)hipblasLtMatmulPreferenceDestroy(pref);
+        }
+    }
+    const size_t n_heur = cand.size();
+    {
+        std::vector<hipblasLtMatmulHeuristicResult_t> all;
+        if (hipblaslt_ext::getAllAlgos(g_lin.handle, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, HIPBLAS_OP_T, HIPBLAS_OP_N,
+                                       HIP_R_32F, HIP_R_32F, HIP_R_32F, HIP_R_32F, HIPBLAS_COMPUTE_32F,
+                                       all) == HIPBLAS_STATUS_SUCCESS)
+            cand.insert(cand.end(), all.begin(), all.end());
+    }
+    std::vector<std::pair<float, size_t>> timed;        // (usec, candidate)
+    for (size_t i = 0; i < cand.size(); ++i) {
+        if (!supported(p, cand[i].algo, beta)) continue;
+        const float us = time_algo(p, cand[i].algo, x, w, c, beta, scratch, 1, stream, e0, e1);
+        if (us > 0.f) timed.push_back({us, i});
+        if (i >= n_heur) {                               // budget applies to the exhaustive part only
+            (void)hipEventRecord(t1, stream); (void)hipEventSynchronize(t1);
+            float ms = 0.f; (void)hipEventElapsedTime(&ms, t0, t1);
+            if (ms > g_lin.tune_budget_ms) break;
+        }
+    }
+    int rc = LEMON_OK;
+    if (timed.empty()) {
+        lemon_set_error("lemon_linear_f32: no hipBLASLt solution supports m=%lld n=%d k=%d epilogue=%d", (long long)m, n,
+                        std::get<2>(key), std::get<3>(key));
+        rc = LEMON_E_INVALID;
+    } else {
+        std::sort(timed.begin(), timed.end());
+        const size_t finals = std::min<size_t>(timed.size(), 6);
+        float best_us = 1e30f; size_t best = timed[0].second;
+        for (size_t j = 0; j < finals; ++j) {            // re-time the front runners properly
+            const float us = time_algo(p, cand[timed[j].second].algo, x, w, c, beta, scratch, 5, stream, e0, e1);
+            if (us > 0.f && us < best_us) { best_us = us; best = timed[j].second; }
+        }
+        *best_out = cand[best].algo;
+        g_lin.index[key] = hipblaslt_ext::getIndexFromAlgo(cand[best].algo);
+        g_lin.usec[key] = best_us;
+        if (getenv("LEMON_LINEAR_VERBOSE"))
+            fprintf(stderr, "[lemon_linear] m=%lld n=%d k=%d epi=%d res=%d: %zu of %zu solutions timed, best index %d %.1f us\n",
+                    (long long)m, n, std::get<2>(key), std::get<3>(key), std::get<4>(key), timed.size(), cand.size(),
+                    g_lin.index[key], best_us);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    (void)hipFree(scratch);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int lemon_linear_f32(const float *x_dev, const float *w_dev, const float *bias_dev, const float *residual_dev,
+                                int64_t m, int n, int k, float alpha, int act, float *y_dev, void *stream_) {
+    LEMON_REQUIRE(m >= 0 && n > 0 && k > 0, "m >= 0, n > 0, k > 0");
+    LEMON_REQUIRE(act == LEMON_ACT_NONE || act == LEMON_ACT_SILU, "act must be LEMON_ACT_NONE or LEMON_ACT_SILU");
+    LEMON_REQUIRE(!(act != LEMON_ACT_NONE && residual_dev), "activation and residual cannot be combined");
+    if (m == 0) return LEMON_OK;
+    LEMON_REQUIRE(x_dev && w_dev && y_dev, "null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    std::lock_guard<std::mutex> lock(g_lin.mu);
+    int rc = ensure_state(stream);
+    if (rc) return rc;
+    int epilogue = HIPBLASLT_EPILOGUE_DEFAULT;
+    if (act == LEMON_ACT_SILU) epilogue = bias_dev ? HIPBLASLT_EPILOGUE_SWISH_BIAS_EXT : HIPBLASLT_EPILOGUE_SWISH_EXT;
+    else if (bias_dev) epilogue = HIPBLASLT_EPILOGUE_BIAS;
+    const LinKey key(m, n, k, epilogue, residual_dev ? 1 : 0);
+    const float beta = residual_dev ? 1.0f : 0.0f;
+    Problem p;
+    rc = make_problem(p, m, n, k, epilogue, bias_dev);
+    if (rc) return rc;
+
+    hipblasLtMatmulAlgo_t algo;
+    auto it = g_lin.algo.find(key);
+    bool have = false;
+    if (it != g_lin.algo.end()) {
+        algo = it->second;
+        have = supported(p, algo, beta);                 // also binds the problem to the algo struct
+    } else {
+        auto ix = g_lin.index.find(key);
+        if (ix != g_lin.index.end()) {                   // recorded index (results file)
+            std::vector<int> idx{ix->second};
+            std::vector<hipblasLtMatmulHeuristicResult_t> res;
+            if (hipblaslt_ext::getAlgosFromIndex(g_lin.handle, idx, res) == HIPBLAS_STATUS_SUCCESS && !res.empty()) {
+                algo = res[0].algo;
+                have = supported(p, algo, beta);
+            }
+        }
+    }
+    if (!have) {
+        rc = tune(key, p, x_dev, w_dev, residual_dev, m, n, stream, &algo);
+        if (rc) return rc;
+        if (!supported(p, algo, beta)) { lemon_set_error("lemon_linear_f32: tuned solution rejected"); return LEMON_E_HIP; }
+    }
+    g_lin.algo[key] = algo;
+    const float *c = residual_dev ? residual_dev : y_dev;
+    LT_CHECK(hipblasLtMatmul(g_lin.handle, p.desc, &alpha, w_dev, p.la, x_dev, p.lb, &beta, c, p.lc, y_dev, p.lc, &algo,
+                             g_lin.ws, g_lin.ws_bytes, stream));
+    return LEMON_OK;
+}
+
+extern "C" int lemon_linear_load_tuned(const char *path) {
+    LEMON_REQUIRE(path != nullptr, "path");
+    FILE *f = fopen(path, "r");
+    if (!f) { lemon_set_error("cannot open %s", path); return LEMON_E_INVALID; }
+    std::lock_guard<std::mutex> lock(g_lin.mu);
+    char line[512];
+    int loaded = 0;
+    while (fgets(line, sizeof line, f)) {
+        long long m; int n, k, epi, res, index; float us;
+        if (sscanf(line, "%lld,%d,%d,%d,%d,%d,%f", &m, &n, &k, &epi, &res, &index, &us) == 7) {
+            const LinKey key((int64_t)m, n, k, epi, res);
+            if (!g_lin.algo.count(key)) { g_lin.index[key] = index; g_lin.usec[key] = us; ++loaded; }
+        }
+    }
+    fclose(f);
+    return loaded;
+}
+
+extern "C" int lemon_linear_dump_tuned(const char *path) {
+    LEMON_REQUIRE(path != nullptr, "path");
+    FILE *f = fopen(path, "w");
+    if (!f) { lemon_set_error("cannot write %s", path); return LEMON_E_INVALID; }
+    std::lock_guard<std::mutex> lock(g_lin.mu);
+    fprintf(f, "# m,n,k,epilogue,residual,hipblaslt_solution_index,usec   (fp32, y = act(x W^T + b) [+ residual]; gfx950)\n");
+    int rows = 0;
+    for (const auto &kv : g_lin.index) {
+        const LinKey &key = kv.first;
+        fprintf(f, "%lld,%d,%d,%d,%d,%d,%.2f\n", (long long)std::get<0>(key), std::get<1>(key), std::get<2>(key),
+                std::get<3>(key), std::get<4>(key), kv.second, g_lin.usec.count(key) ? g_lin.usec[key] : 0.0f);
+        ++rows;
+    }
+    fclose(f);
+    return rows;
+}

@@ -83,6 +83,54 @@ def quick_gelu_(x):
 
 
 ATTENTION_MAX_SEQ = 288
+ACT_NONE, ACT_SILU = 0, 1
+QUICK_GELU_SCALE = 1.702
+_linear_tuned_loaded = False
+
+
+def _ensure_linear_tuned(lib):
+    """Hand the recorded hipBLASLt solution choices (lemon_amd/data/linear_gfx950.csv, or
+    $LEMON_LINEAR_TUNED) to the library once per process; keys not in the file are tuned on first use."""
+    global _linear_tuned_loaded
+    if _linear_tuned_loaded:
+        return
+    _linear_tuned_loaded = True
+    import os
+    path = os.environ.get("LEMON_LINEAR_TUNED",
+                          os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "linear_gfx950.csv"))
+    if path and os.path.exists(path):
+        lib.lemon_linear_load_tuned(path.encode())
+
+
+def linear(x, weight, bias=None, residual=None, act=None, alpha=1.0):
+    """y = act(alpha * x @ weight.T + bias) (+ residual) in ONE hipBLASLt GEMM (SiLU / residual add ride
+    in the epilogue).  x [..., k] float32 CUDA, weight [n, k]; act in (None, 'silu')."""
+    assert x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
+    x = x.contiguous()
+    weight = weight.contiguous()
+    k = x.shape[-1]
+    n = weight.shape[0]
+    assert weight.shape[1] == k
+    m = x.numel() // k
+    y = torch.empty(x.shape[:-1] + (n,), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        assert residual.shape == y.shape and residual.dtype == torch.float32
+        residual = residual.contiguous()
+    if bias is not None:
+        bias = bias.contiguous()
+    lib = _lib.load()
+    _ensure_linear_tuned(lib)
+    code = {None: ACT_NONE, "silu": ACT_SILU}[act]
+    with torch.cuda.device(x.device):
+        _lib.check(lib.lemon_linear_f32(ptr(x), ptr(weight), ptr(bias) if bias is not None else None,
+                                        ptr(residual) if residual is not None else None, m, n, k, float(alpha), code, ptr(y),
+                                        stream_ptr(x.device)), "lemon_linear_f32")
+    return y
+
+
+def linear_dump_tuned(path):
+    """Write the solution choices made so far in this process (tools/tune_gemms.py)."""
+    return _lib.load().lemon_linear_dump_tuned(str(path).encode())
 
 
 def attention(qkv, heads, causal=False):

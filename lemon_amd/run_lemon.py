@@ -62,6 +62,8 @@ def build_parser():
     p.add_argument("--data_root", default="./data", help="local dataset root, or synthetic:N")
     p.add_argument("--algo", default="auto", choices=["auto", "f32", "bf16"], help="kNN scan algorithm")
     p.add_argument("--encoder_batch", default=512, type=int, help="encoder micro-batch on the GPU")
+    p.add_argument("--gemm_tuning", action="store_true",
+                   help="let TunableOp pick the hipBLASLt solution per encoder GEMM shape (lemon_amd/tuning.py)")
     p.add_argument("--hparam_grid", default="full", choices=["full", "small"],
                    help="'small' = 3x3x2x2 grid for smoke runs (reference grid is 21x21x4x4)")
     return p
@@ -141,6 +143,9 @@ def main(argv=None):
         rng = np.random.default_rng(args.data_seed)
         val_set = val_set.subset(rng.choice(np.arange(len(val_set)), min(args.subset_val_set, len(val_set)), replace=False))
 
+    if args.gemm_tuning:
+        from .tuning import enable_gemm_tuning
+        enable_gemm_tuning()
     embedder = Embedder(model, device, batch_size=args.encoder_batch)
     prefix = "A photo of a " if args.custom_cifar_prompt is None else args.custom_cifar_prompt
     prompt_fn = lambda x: prefix + x

@@ -347,6 +347,31 @@ def test_fused_attention_matches_float64_reference(hip, B, L, H, causal):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("m,n,k", [(100, 64, 48), (7, 512, 512), (3000, 2304, 768), (2500, 768, 3072), (1, 32, 40)])
+@pytest.mark.parametrize("mode", ["plain", "bias", "bias_gelu", "gelu", "bias_residual", "residual"])
+def test_fused_linear_matches_float64_reference(hip, m, n, k, mode):
+    # lemon_linear_f32: y = act(alpha x W^T + b) (+ residual) in one hipBLASLt GEMM (SiLU epilogue)
+    from lemon_amd.ops import linear
+    g = torch.Generator().manual_seed(m * 7 + n * 3 + k)
+    x, w = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g) if "bias" in mode else None
+    r = torch.randn(m, n, generator=g) if "residual" in mode else None
+    ref = x.double() @ w.double().T
+    if b is not None:
+        ref = ref + b.double()
+    if "gelu" in mode:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    if r is not None:
+        ref = ref + r.double()
+    if "gelu" in mode:      # QuickGELU(z) = silu(1.702 z) / 1.702 (how lemon_amd/clip.py composes it)
+        got = linear(x.cuda(), w.cuda(), None if b is None else 1.702 * b.cuda(), None, "silu", alpha=1.702).cpu().double() / 1.702
+    else:
+        got = linear(x.cuda(), w.cuda(), None if b is None else b.cuda(), None if r is None else r.cuda()).cpu().double()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max() < 2e-5 * max(1.0, k ** 0.5 / 8), (got - ref).abs().max()
+
+
+@pytest.mark.gpu
 def test_encoder_vit_b32_block_fused_attention_vs_sdpa(hip):
     # one full-size transformer block (width 768, 12 heads, L=50): fused HIP attention vs torch SDPA path
     from lemon_amd.clip import Block, TowerConfig
