@@ -36,7 +36,7 @@ extern "C" int lemon_index_create(int metric, int d, lemon_index_t **out) {
     if (!idx) { lemon_set_error("host allocation failed"); return LEMON_E_NOMEM; }
     idx->metric = metric;
     idx->d = d;
-    idx->dpad = (int)round_up64(d, 32);
+    idx->dpad = (int)round_up64(d, 64);   // even number of 32-wide k-slices (fp32 scan's two-set prefetch)
     idx->algo = LEMON_ALGO_AUTO;
     idx->prof_events = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
     if (hipGetDevice(&idx->device) != hipSuccess) {

@@ -36,7 +36,7 @@ void lemon_set_error(const char *fmt, ...);
 // ---- index object ---------------------------------------------------------------
 // Data layout in HBM (DESIGN.md "Data layout"):
 //   x     [cap, d]        row-major copy of what the caller added (gathers, exact re-rank)
-//   xp    [cap_pad, dpad] same rows, zero padded to dpad = ceil32(d) columns and with every
+//   xp    [cap_pad, dpad] same rows, zero padded to dpad = ceil64(d) columns and with every
 //                         group of 8 consecutive k stored as [k0 k2 k4 k6 | k1 k3 k5 k7] so
 //                         that one 16-B LDS read feeds four v_mfma_f32_32x32x2_f32 steps in
 //                         ascending-k order (cap_pad = ceil128(cap), pad rows are zero)

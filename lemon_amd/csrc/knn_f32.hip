@@ -129,55 +129,85 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
     int ccnt = 0, clast = 0;
     float th = qvalid ? -INFINITY : INFINITY;    // exact score of the query's current k-th best
 
-    float4 rq0, rq1, rq2, rq3, rx0, rx1, rx2, rx3;
+    // Operand staging global -> registers -> LDS with TWO register sets: set (s & 1) carries stage s.
+    // At step s the stage s+1 is committed to the other LDS buffer and the freed set is re-issued for
+    // stage s+3, so every load has two full k-steps (128 MFMAs per wave) to land.  (With one set the
+    // distance was one step and the wait for it cost ~18 % of the launch under the fabric load of 512
+    // workgroups re-streaming their query panels.)  KT is even (dpad is a multiple of 64), so tiles
+    // start on even stages and the register sets have static names.
+    float4 ra_q0, ra_q1, ra_q2, ra_q3, ra_x0, ra_x1, ra_x2, ra_x3;
+    float4 rb_q0, rb_q1, rb_q2, rb_q3, rb_x0, rb_x1, rb_x2, rb_x3;
     const float *qbase = p.qp + q0 * dpad;
     const float *xbase = p.xp + (int64_t)t_begin * BX * dpad;
+    int lk = 0, lj = 0, ls = 0;                  // load cursor: next stage to issue = ls = lj * KT + lk
+#define F32_ISSUE(S)                                                                                   \
+    do {                                                                                               \
+        if (ls < total) {                                                                              \
+            const float *qs_ = qbase + lk * BK;                                                        \
+            const float *xs_ = xbase + (int64_t)lj * BX * dpad + lk * BK;                              \
+            r##S##_q0 = stage_ld(qs_, dpad, voff, 0); r##S##_q1 = stage_ld(qs_, dpad, voff, 1);        \
+            r##S##_q2 = stage_ld(qs_, dpad, voff, 2); r##S##_q3 = stage_ld(qs_, dpad, voff, 3);        \
+            r##S##_x0 = stage_ld(xs_, dpad, voff, 0); r##S##_x1 = stage_ld(xs_, dpad, voff, 1);        \
+            r##S##_x2 = stage_ld(xs_, dpad, voff, 2); r##S##_x3 = stage_ld(xs_, dpad, voff, 3);        \
+        }                                                                                              \
+        ++ls; if (++lk == KT) { lk = 0; ++lj; }                                                        \
+    } while (0)
+#define F32_COMMIT(S, BUF)                                                                             \
+    do {                                                                                               \
+        stage_st(s_tile[BUF][0], tid, 0, r##S##_q0); stage_st(s_tile[BUF][0], tid, 1, r##S##_q1);      \
+        stage_st(s_tile[BUF][0], tid, 2, r##S##_q2); stage_st(s_tile[BUF][0], tid, 3, r##S##_q3);      \
+        stage_st(s_tile[BUF][1], tid, 0, r##S##_x0); stage_st(s_tile[BUF][1], tid, 1, r##S##_x1);      \
+        stage_st(s_tile[BUF][1], tid, 2, r##S##_x2); stage_st(s_tile[BUF][1], tid, 3, r##S##_x3);      \
+    } while (0)
+#define F32_MFMA_U(BUF, U)                                                                             \
+    do {                                                                                               \
+        const float *tq_ = s_tile[BUF][0];                                                             \
+        const float *tx_ = s_tile[BUF][1];                                                             \
+        const float4 b4 = *reinterpret_cast<const float4 *>(&tq_[swz(qrow_l, 2 * (U) + h)]);           \
+        const float4 a0 = *reinterpret_cast<const float4 *>(&tx_[swz(l31, 2 * (U) + h)]);              \
+        const float4 a1 = *reinterpret_cast<const float4 *>(&tx_[swz(32 + l31, 2 * (U) + h)]);         \
+        const float4 a2 = *reinterpret_cast<const float4 *>(&tx_[swz(64 + l31, 2 * (U) + h)]);         \
+        const float4 a3 = *reinterpret_cast<const float4 *>(&tx_[swz(96 + l31, 2 * (U) + h)]);         \
+        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};                                                  \
+        const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};              \
+        const float av2[4] = {a2.x, a2.y, a2.z, a2.w}, av3[4] = {a3.x, a3.y, a3.z, a3.w};              \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[m], bv[m], acc0, 0, 0, 0);                 \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], bv[m], acc1, 0, 0, 0);                 \
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av2[m], bv[m], acc2, 0, 0, 0);                 \
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(av3[m], bv[m], acc3, 0, 0, 0);                 \
+        }                                                                                              \
+    } while (0)
+    // one k-step on LDS buffer BUF (stage `it_`); SET = the register set that holds stage it_+1
+#define F32_STEP(BUF, SET, it_)                                                                        \
+    do {                                                                                               \
+        F32_MFMA_U(BUF, 0); F32_MFMA_U(BUF, 1);                                                        \
+        if (!abl_ld) {                                                                                 \
+            if ((it_) + 1 < total) F32_COMMIT(SET, (BUF) ^ 1);                                         \
+            F32_ISSUE(SET);                                                                            \
+        }                                                                                              \
+        F32_MFMA_U(BUF, 2); F32_MFMA_U(BUF, 3);                                                        \
+    } while (0)
 
     f32x16 acc0, acc1, acc2, acc3;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc0[e] = 0.0f; acc1[e] = 0.0f; acc2[e] = 0.0f; acc3[e] = 0.0f; }
 
-    STAGE_ISSUE(qbase, xbase);
-    STAGE_COMMIT(s_tile[0][0], s_tile[0][1]);
+    const bool abl_ld = PROF && (p.ablate & 1), abl_bar = PROF && (p.ablate & 2);
+    F32_ISSUE(a);                                // stage 0
+    F32_ISSUE(b);                                // stage 1
+    F32_COMMIT(a, 0);
+    F32_ISSUE(a);                                // stage 2
     __syncthreads();
 
-    int kt = 0, jl = 0;  // position of iteration `it` = (tile jl of this split, k-slice kt)
-    for (int it = 0; it < total; ++it) {
-        const int cur = it & 1;
-        int kt_n = kt + 1, jl_n = jl;
-        if (kt_n == KT) { kt_n = 0; jl_n = jl + 1; }
-        const bool abl_ld = PROF && (p.ablate & 1), abl_bar = PROF && (p.ablate & 2);
-        if (it + 1 < total && !abl_ld) {
-            const float *qs = qbase + kt_n * BK;
-            const float *xs = xbase + (int64_t)jl_n * BX * dpad + kt_n * BK;
-            STAGE_ISSUE(qs, xs);
-        }
+    int jl = 0;                                  // tile of the stage pair being computed
+    for (int it = 0; it < total; it += 2) {
+        F32_STEP(0, b, it);                      // even stage: LDS buffer 0; set b holds stage it+1
+        if (!abl_bar) __syncthreads();
+        F32_STEP(1, a, it + 1);                  // odd stage: LDS buffer 1; set a holds stage it+2
+        const bool tile_done = ((it + 2) % KT) == 0;
 
-        const float *tq = s_tile[cur][0];
-        const float *tx = s_tile[cur][1];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float4 b4 = *reinterpret_cast<const float4 *>(&tq[swz(qrow_l, 2 * u + h)]);
-            const float4 a0 = *reinterpret_cast<const float4 *>(&tx[swz(l31, 2 * u + h)]);
-            const float4 a1 = *reinterpret_cast<const float4 *>(&tx[swz(32 + l31, 2 * u + h)]);
-            const float4 a2 = *reinterpret_cast<const float4 *>(&tx[swz(64 + l31, 2 * u + h)]);
-            const float4 a3 = *reinterpret_cast<const float4 *>(&tx[swz(96 + l31, 2 * u + h)]);
-            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float av2[4] = {a2.x, a2.y, a2.z, a2.w}, av3[4] = {a3.x, a3.y, a3.z, a3.w};
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[m], bv[m], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], bv[m], acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av2[m], bv[m], acc2, 0, 0, 0);
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(av3[m], bv[m], acc3, 0, 0, 0);
-            }
-        }
-
-        // commit the next stage BEFORE the epilogue: its vmcnt(0) must not also wait for this tile's appends
-        if (it + 1 < total && !abl_ld) STAGE_COMMIT(s_tile[cur ^ 1][0], s_tile[cur ^ 1][1]);
-
-        if (kt == KT - 1) {
+        if (tile_done) {
             // ---- epilogue: filter into the lane-private half-lists, then zero the accumulators ----
             PH_STAMP(ph0);
             const int64_t jb = (int64_t)(t_begin + jl) * BX + 4 * h;
@@ -187,6 +217,7 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
             f32_filter_tile<L2>(acc3, th, jb + 96, my_qn, p.xnorm, p.n, ccnt, mylist);
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc0[e] = 0.0f; acc1[e] = 0.0f; acc2[e] = 0.0f; acc3[e] = 0.0f; }
+            ++jl;
 
             // ---- maintenance: select the exact top-kk of queries whose lists grew enough ----
             PH_STAMP(ph1);
@@ -215,8 +246,11 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
         }
 
         if (!abl_bar) __syncthreads();
-        kt = kt_n; jl = jl_n;
     }
+#undef F32_STEP
+#undef F32_MFMA_U
+#undef F32_COMMIT
+#undef F32_ISSUE
 
     // ---- final: sort every query's best kk, write the result rows ------------------------------
     PH_STAMP(ph0);
