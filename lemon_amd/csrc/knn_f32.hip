@@ -209,12 +209,17 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
 
         if (tile_done) {
             // ---- epilogue: filter into the lane-private half-lists, then zero the accumulators ----
+            // (raised issue priority: the other three waves of the workgroup wait at the barrier for this
+            // one, while the co-resident workgroup's waves keep the MFMA pipe busy either way)
             PH_STAMP(ph0);
+            __builtin_amdgcn_s_setprio(3);
             const int64_t jb = (int64_t)(t_begin + jl) * BX + 4 * h;
+            if (!(PROF && (p.ablate & 4) && jl > 4)) {     // diagnostic: bit 2 = skip the filter after 5 tiles
             f32_filter_tile<L2>(acc0, th, jb, my_qn, p.xnorm, p.n, ccnt, mylist);
             f32_filter_tile<L2>(acc1, th, jb + 32, my_qn, p.xnorm, p.n, ccnt, mylist);
             f32_filter_tile<L2>(acc2, th, jb + 64, my_qn, p.xnorm, p.n, ccnt, mylist);
             f32_filter_tile<L2>(acc3, th, jb + 96, my_qn, p.xnorm, p.n, ccnt, mylist);
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc0[e] = 0.0f; acc1[e] = 0.0f; acc2[e] = 0.0f; acc3[e] = 0.0f; }
             ++jl;
@@ -242,6 +247,7 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
                     }
                 } while (todo);
             }
+            __builtin_amdgcn_s_setprio(0);
             PH_STAMP(ph2);
         }
 
