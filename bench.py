@@ -40,7 +40,7 @@ def pmc_traffic(kernel_substr, path=os.path.join(ROOT, "profiles", "r1", "bench_
         return None
     acc = {"FETCH_SIZE": [], "WRITE_SIZE": []}
     for r in csv.DictReader(open(path)):
-        if kernel_substr in r["kernel"] and r["counter"] in acc and int(r["grid"]) > 512 * 256:
+        if kernel_substr in r["kernel"] and r["counter"] in acc and int(r["grid"]) >= 256 * 256:
             acc[r["counter"]].append(float(r["value_KB"]))
     if not acc["FETCH_SIZE"] or not acc["WRITE_SIZE"]:
         return None

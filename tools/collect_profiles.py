@@ -1,0 +1,40 @@
+"""Copy the judged summaries of a tools/gpu_profile.sh run from gpurun_out/ into profiles/<tag>/.
+python tools/collect_profiles.py [tag]"""
+import csv, glob, json, os, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles", tag)
+os.makedirs(P, exist_ok=True)
+
+def one(pattern):
+    hits = glob.glob(os.path.join(G, pattern), recursive=True)
+    return max(hits, key=os.path.getmtime) if hits else None
+
+def pmc_rows(dirs):
+    rows = []
+    for d in dirs:
+        f = one(f"{d}/**/*counter_collection.csv")
+        if not f:
+            continue
+        for r in csv.DictReader(open(f)):
+            rows.append(dict(kernel=r["Kernel_Name"][:70], counter=r["Counter_Name"], value_KB=float(r["Counter_Value"]),
+                             dur_ms=(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, grid=r["Grid_Size"],
+                             wg=r["Workgroup_Size"], vgpr=r["VGPR_Count"], agpr=r["Accum_VGPR_Count"], lds=r["LDS_Block_Size"]))
+    return rows
+
+def write_pmc(name, dirs):
+    rows = pmc_rows(dirs)
+    if rows:
+        with open(os.path.join(P, name), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
+        print(name, len(rows), "rows")
+
+for src, dst in ((f"bench_{tag}.json", "bench_default.json"), (f"prof_knn_{tag}.json", "knn_262144x768.json")):
+    if os.path.exists(os.path.join(G, src)):
+        shutil.copyfile(os.path.join(G, src), os.path.join(P, dst)); print(dst)
+for d, dst in ((f"prof_bench_{tag}", "bench_default_kernel_stats.csv"), (f"prof_knn_{tag}", "knn_262144x768_kernel_stats.csv")):
+    f = one(f"{d}/**/*kernel_stats.csv")
+    if f:
+        shutil.copyfile(f, os.path.join(P, dst)); print(dst)
+write_pmc("bench_default_pmc.csv", [f"pmc_bench_fetch_{tag}", f"pmc_bench_write_{tag}"])
+write_pmc("knn_262144x768_pmc.csv", [f"pmc_fetch_{tag}", f"pmc_write_{tag}"])
