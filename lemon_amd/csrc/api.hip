@@ -285,9 +285,87 @@ __device__ __forceinline__ float chain_dist(const float *__restrict__ a, const f
     return L2 ? acc : 1.0f - acc;
 }
 
-__global__ __launch_bounds__(256) void k_neighbors_finalize(NbParams p) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= p.nq * p.k) return;
+// Wave-cooperative chained distance.  Lane l owns the row pair (a_l, b_l) and must walk it in ascending
+// k with ONE fmaf chain (the numeric contract), but 64 lanes reading 64 different rows 16 B at a time
+// touch 64 cache lines per instruction and thrash the 32 KB L1.  So rows are fetched 128 B (one line) at
+// a time with full-line loads -- lane (r8, c) fetches chunk c of rows r8, r8+8, ... of the wave -- and
+// transposed through LDS (row pitch 36 floats: conflict-free 128-bit reads); the next 128 B are in
+// flight while the current ones are consumed.  Needs d % 4 == 0 and 16-byte aligned rows.
+constexpr int NB_PITCH = 36;
+template <bool L2>
+__device__ __forceinline__ float chain_dist_wave(const float *a_row, const float *b_row, int d,
+                                                 float *__restrict__ lds /* [2][64][NB_PITCH] */, int lane) {
+    const int r8 = lane >> 3, c = lane & 7;
+    // named registers, not arrays (hipcc keeps arrays that are filled under a condition in scratch)
+#define NB_PTR(i) \
+    const float *pa##i = reinterpret_cast<const float *>(__shfl((unsigned long long)(uintptr_t)a_row, r8 + 8 * i)) + 4 * c; \
+    const float *pb##i = reinterpret_cast<const float *>(__shfl((unsigned long long)(uintptr_t)b_row, r8 + 8 * i)) + 4 * c;
+    NB_PTR(0) NB_PTR(1) NB_PTR(2) NB_PTR(3) NB_PTR(4) NB_PTR(5) NB_PTR(6) NB_PTR(7)
+#undef NB_PTR
+    float4 va0, va1, va2, va3, va4, va5, va6, va7, vb0, vb1, vb2, vb3, vb4, vb5, vb6, vb7;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#define NB_LOAD(i, koff) \
+    va##i = *reinterpret_cast<const float4 *>(pa##i + (koff)); vb##i = *reinterpret_cast<const float4 *>(pb##i + (koff));
+#define NB_ZERO(i) va##i = zero; vb##i = zero;
+#define NB_FETCH(koff)                                                                              \
+    do {                                                                                            \
+        if ((koff) + 4 * c < d) {                                                                   \
+            NB_LOAD(0, koff) NB_LOAD(1, koff) NB_LOAD(2, koff) NB_LOAD(3, koff)                     \
+            NB_LOAD(4, koff) NB_LOAD(5, koff) NB_LOAD(6, koff) NB_LOAD(7, koff)                     \
+        } else {                                                                                    \
+            NB_ZERO(0) NB_ZERO(1) NB_ZERO(2) NB_ZERO(3) NB_ZERO(4) NB_ZERO(5) NB_ZERO(6) NB_ZERO(7) \
+        }                                                                                           \
+    } while (0)
+#define NB_STORE(i)                                                                    \
+    *reinterpret_cast<float4 *>(&la[(r8 + 8 * i) * NB_PITCH + 4 * c]) = va##i;         \
+    *reinterpret_cast<float4 *>(&lb[(r8 + 8 * i) * NB_PITCH + 4 * c]) = vb##i;
+    NB_FETCH(0);
+    float acc = 0.0f;
+    float *la = lds, *lb = lds + 64 * NB_PITCH;
+    for (int k0 = 0; k0 < d; k0 += 32) {
+        NB_STORE(0) NB_STORE(1) NB_STORE(2) NB_STORE(3) NB_STORE(4) NB_STORE(5) NB_STORE(6) NB_STORE(7)
+        const int kn = k0 + 32;
+        if (kn < d) NB_FETCH(kn);                        // wave-uniform: next 128 B of every row
+        __builtin_amdgcn_wave_barrier();
+        const int lim = d - k0 < 32 ? d - k0 : 32;       // wave-uniform; multiple of 4
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (4 * u < lim) {
+                const float4 x = *reinterpret_cast<const float4 *>(&la[lane * NB_PITCH + 4 * u]);
+                const float4 y = *reinterpret_cast<const float4 *>(&lb[lane * NB_PITCH + 4 * u]);
+                if (L2) {
+                    float t;
+                    t = x.x - y.x; acc = __builtin_fmaf(t, t, acc);
+                    t = x.y - y.y; acc = __builtin_fmaf(t, t, acc);
+                    t = x.z - y.z; acc = __builtin_fmaf(t, t, acc);
+                    t = x.w - y.w; acc = __builtin_fmaf(t, t, acc);
+                } else {
+                    acc = __builtin_fmaf(x.x, y.x, acc);
+                    acc = __builtin_fmaf(x.y, y.y, acc);
+                    acc = __builtin_fmaf(x.z, y.z, acc);
+                    acc = __builtin_fmaf(x.w, y.w, acc);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef NB_STORE
+#undef NB_FETCH
+#undef NB_ZERO
+#undef NB_LOAD
+    return L2 ? acc : 1.0f - acc;
+}
+
+// STAGED: wave-cooperative row fetches (d % 4 == 0); otherwise every lane walks its rows from global.
+template <bool L2, bool STAGED>
+__global__ __launch_bounds__(128) void k_neighbors_finalize(NbParams p) {
+    __shared__ __attribute__((aligned(16))) float s_rows[STAGED ? 2 : 1][STAGED ? 2 * 64 * NB_PITCH : 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t total = p.nq * p.k;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = t0 < total;
+    if (!STAGED && !valid) return;
+    const int64_t t = valid ? t0 : total - 1;            // staged: idle lanes shadow the last pair
     const int64_t i = t / p.k;
     const int j = (int)(t % p.k);
     const int off = (p.drop_self && (p.in_db == nullptr || p.in_db[i])) ? 1 : 0;
@@ -297,28 +375,33 @@ __global__ __launch_bounds__(256) void k_neighbors_finalize(NbParams p) {
     const float *vi = p.q_img + i * (int64_t)p.d;
     const float *ti = p.q_txt + i * (int64_t)p.d;
     const float qnan = __builtin_nanf("");
+    float dist_n = qnan, dist_m = qnan;
+    if (!p.discrete) {                                   // uniform
+        const float *yn = jn >= 0 ? p.txt_tr + jn * (int64_t)p.d : ti;
+        dist_n = STAGED ? chain_dist_wave<L2>(ti, yn, p.d, s_rows[wave], lane) : chain_dist<L2>(ti, yn, p.d);
+    }
+    {
+        const float *xm = jm >= 0 ? p.img_tr + jm * (int64_t)p.d : vi;
+        dist_m = STAGED ? chain_dist_wave<L2>(vi, xm, p.d, s_rows[wave], lane) : chain_dist<L2>(vi, xm, p.d);
+    }
+    if (!valid) return;
     if (p.I_n) p.I_n[t] = jn;
     if (p.I_m) p.I_m[t] = jm;
     if (jn < 0) { p.D_n[t] = dn; p.dists_n[t] = qnan; p.dists_tr_n[t] = qnan; }
     else {
-        const float *yn = p.txt_tr + jn * (int64_t)p.d;
         if (p.discrete) {
             p.D_n[t] = dn;
             p.dists_n[t] = 1.0f - (float)(p.tr_lab[jn] == p.q_lab[i]);
-        } else if (p.metric == LEMON_METRIC_IP) {
-            p.D_n[t] = -dn;
-            p.dists_n[t] = chain_dist<false>(ti, yn, p.d);
         } else {
-            p.D_n[t] = dn;
-            p.dists_n[t] = chain_dist<true>(ti, yn, p.d);
+            p.D_n[t] = L2 ? dn : -dn;
+            p.dists_n[t] = dist_n;
         }
         p.dists_tr_n[t] = p.dists_tr[jn];
     }
     if (jm < 0) { p.D_m[t] = dm; p.dists_m[t] = qnan; p.dists_tr_m[t] = qnan; }
     else {
-        const float *xm = p.img_tr + jm * (int64_t)p.d;
-        if (p.metric == LEMON_METRIC_IP) { p.D_m[t] = -dm; p.dists_m[t] = chain_dist<false>(vi, xm, p.d); }
-        else                             { p.D_m[t] = dm;  p.dists_m[t] = chain_dist<true>(vi, xm, p.d); }
+        p.D_m[t] = L2 ? dm : -dm;
+        p.dists_m[t] = dist_m;
         p.dists_tr_m[t] = p.dists_tr[jm];
     }
 }
@@ -374,7 +457,19 @@ extern "C" int lemon_neighbors(lemon_index_t *idx_img, lemon_index_t *idx_txt, c
     p.nq = nq; p.d = idx_img->d; p.k = k; p.ks = ks; p.metric = idx_img->metric;
     p.drop_self = drop_self; p.discrete = discrete;
     const int64_t total = nq * k;
-    hipLaunchKernelGGL(k_neighbors_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+    {
+        const bool staged = (p.d & 3) == 0 &&
+                            ((((uintptr_t)p.img_tr) | ((uintptr_t)p.txt_tr) | ((uintptr_t)p.q_img) | ((uintptr_t)p.q_txt)) & 15) == 0;
+        const dim3 grid((unsigned)((total + 127) / 128)), block(128);
+        const bool l2m = p.metric == LEMON_METRIC_L2;
+        if (staged) {
+            if (l2m) hipLaunchKernelGGL((k_neighbors_finalize<true, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((k_neighbors_finalize<false, true>), grid, block, 0, stream, p);
+        } else {
+            if (l2m) hipLaunchKernelGGL((k_neighbors_finalize<true, false>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((k_neighbors_finalize<false, false>), grid, block, 0, stream, p);
+        }
+    }
     LEMON_HIP_CHECK(hipGetLastError());
     return LEMON_OK;
 }
