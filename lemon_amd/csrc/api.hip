@@ -485,28 +485,37 @@ struct DiscParams {
     int d, k, kq, kc, method;
 };
 
-__global__ __launch_bounds__(256) void k_discrepancy(DiscParams p) {
-    const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= p.nq) return;
+template <bool STAGED>
+__global__ __launch_bounds__(128) void k_discrepancy(DiscParams p) {
+    __shared__ __attribute__((aligned(16))) float s_rows[STAGED ? 2 : 1][STAGED ? 2 * 64 * NB_PITCH : 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 2 + wave;
+    if (i >= p.nq) return;                               // wave-uniform
     const int64_t *im = p.Im + i * p.kq;
     double total = 0.0;
     int count = 0;
     const int pairs = p.method == 0 ? p.kq * p.kc : p.kq * p.kq;
-    for (int t = lane; t < pairs; t += 64) {
-        const int a = p.method == 0 ? t / p.kc : t / p.kq, b = p.method == 0 ? t % p.kc : t % p.kq;
-        const int64_t j = im[a];
-        if (j < 0) continue;
-        if (p.method == 0) {
-            const int64_t l = p.Ic[j * p.kc + b];
-            if (l < 0 || l == j) continue;
-            total += (double)chain_dist<false>(p.E + l * (int64_t)p.d, p.qv + i * (int64_t)p.d, p.d);
-            ++count;
-        } else {
-            const int64_t l = im[b];
-            if (l < 0) continue;
-            total += (double)chain_dist<false>(p.E + j * (int64_t)p.d, p.E + l * (int64_t)p.d, p.d);
+    for (int tb = 0; tb < pairs; tb += 64) {
+        const int t = tb + lane;
+        bool active = t < pairs;
+        const float *ra = p.E, *rb = p.E;                // idle lanes read row 0 (always present: n >= 1)
+        if (active) {
+            const int a = p.method == 0 ? t / p.kc : t / p.kq, b = p.method == 0 ? t % p.kc : t % p.kq;
+            const int64_t j = im[a];
+            if (j < 0) active = false;
+            else if (p.method == 0) {
+                const int64_t l = p.Ic[j * p.kc + b];
+                if (l < 0 || l == j) active = false;
+                else { ra = p.E + l * (int64_t)p.d; rb = p.qv + i * (int64_t)p.d; }
+            } else {
+                const int64_t l = im[b];
+                if (l < 0) active = false;
+                else { ra = p.E + j * (int64_t)p.d; rb = p.E + l * (int64_t)p.d; }
+            }
         }
+        const float dist = STAGED ? chain_dist_wave<false>(ra, rb, p.d, s_rows[wave], lane)
+                                  : (active ? chain_dist<false>(ra, rb, p.d) : 0.0f);
+        if (active) { total += (double)dist; if (p.method == 0) ++count; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { total += __shfl_xor(total, off); count += __shfl_xor(count, off); }
@@ -552,7 +561,12 @@ extern "C" int lemon_discrepancy(int method, lemon_index_t *idx_txt, const float
     DiscParams p;
     p.E = E_tr_dev; p.qv = qv_dev; p.Im = Im; p.Ic = Ic; p.out = out_dev; p.nq = nq;
     p.d = idx_txt->d; p.k = k; p.kq = kq; p.kc = kc; p.method = method;
-    hipLaunchKernelGGL(k_discrepancy, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, p);
+    {
+        const bool staged = (p.d & 3) == 0 && ((((uintptr_t)p.E) | ((uintptr_t)p.qv)) & 15) == 0;
+        const dim3 grid((unsigned)((nq + 1) / 2)), block(128);
+        if (staged) hipLaunchKernelGGL(k_discrepancy<true>, grid, block, 0, stream, p);
+        else hipLaunchKernelGGL(k_discrepancy<false>, grid, block, 0, stream, p);
+    }
     LEMON_HIP_CHECK(hipGetLastError());
     return LEMON_OK;
 }

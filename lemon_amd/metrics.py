@@ -194,7 +194,10 @@ def maximize_metric(score_fn, y, grid, x0s, obj_func=optimize_f1_efficient, obj_
 
     def objective(x):
         hp = unpack_vector(x, force_zero, force_one)
-        return -obj_func(y, score_fn(hp), **obj_func_args)
+        score = score_fn(hp)
+        if not np.all(np.isfinite(score)):       # overflowing hyper-parameters: worst objective, not a crash
+            return 0.0
+        return -obj_func(y, score, **obj_func_args)
 
     best_x, best_val = None, -1
     for x0 in x0s:
@@ -208,6 +211,10 @@ def maximize_metric(score_fn, y, grid, x0s, obj_func=optimize_f1_efficient, obj_
                  for k, v in rec_for_lbfgs.items()}
         for x0 in x0s:
             cand = _torch_lbfgs(rec_t, y, x0, force_zero, force_one)
+            if not np.all(np.isfinite(cand)):
+                # LBFGS on the SoftMargin proxy can diverge to NaN (seen on tiny synthetic sets); the reference
+                # would die in fminbound with "bounds must be finite" (utils.py:170-174) -- skip the candidate
+                continue
             val = -objective(cand)
             if val > best_val:
                 best_val, best_x = val, cand

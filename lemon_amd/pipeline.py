@@ -6,6 +6,7 @@ Python (:238-307).  Here embeddings never leave HBM: encoder output -> K1 normal
 world_size > 1 every rank embeds its shard of each split, the DB shards are all-gathered over RCCL
 (torch.distributed, backend "nccl") and each rank scores its own query shard.
 """
+import os
 import time
 
 import numpy as np
@@ -103,6 +104,11 @@ def score_splits(db, splits, k, hparams=None, discrete=False):
     if discrete:
         lab = torch.cat([torch.as_tensor(s["label_id"]).to(device=dev, dtype=torch.int32) for s in splits])
     rec = db.neighbors(img, txt, k, drop_self=any_train, in_db=in_db, discrete=discrete, q_label_id=lab)
+    if os.environ.get("LEMON_DEBUG_FINITE"):       # diagnostic: name the first non-finite array (host sync)
+        for key, v in (("emb_img", img), ("emb_txt", txt)) + tuple(rec.items()):
+            if v.is_floating_point() and not bool(torch.isfinite(v).all()):
+                bad = (~torch.isfinite(v)).nonzero()[:5].tolist()
+                raise FloatingPointError(f"non-finite values in {key} at {bad} (k={k}, ntotal={db.index_img.ntotal})")
     if hparams is not None:
         rec["score"] = ops.lemon_score(rec, hparams)
     out, lo = {}, 0
