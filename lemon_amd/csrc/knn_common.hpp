@@ -94,11 +94,6 @@ __device__ __forceinline__ void stage_st(float *t, int tid, int i, float4 v) {
 // no LDS, no wait.  Thresholds live in VGPRs too.  Entry idx of the pair list: idx < PAIR_CAP/2 -> half 0.
 constexpr int PAIR_CAP = 512;
 
-__device__ __forceinline__ u64 pair_load_slot(const u64 *__restrict__ list, int idx, int n0, int n1) {
-    const bool ok = idx < PAIR_CAP / 2 ? idx < n0 : (idx - PAIR_CAP / 2) < n1;
-    return ok ? list[idx] : 0;
-}
-
 // Exact selection on exact keys.  The pair list is read into NS register slots (64 keys each; the
 // occupied 64-blocks of half 0 first, then those of half 1 -- typical lists fill 2-3 of the 8 possible
 // slots, and the bisection below costs one compare + ballot per slot and step, so NS is specialised).
