@@ -17,11 +17,12 @@ for spec in (sys.argv[1:] or ["vit-b-32:1000"]):
     model = LemonCLIP(cfg).eval().to(dev)
     tok = SyntheticTokenizer(cfg.vocab_size, cfg.context_length, cfg.eos_token_id)
     prompts = (["A photo of a " + l for l in ds.cifar100_labels] * (bs // 100 + 1))[:bs]
+    prompts = prompts * 4                                   # text micro-batch = 4 x image micro-batch (pipeline.Embedder)
     ids = torch.tensor(tok(prompts, padding="max_length", truncation=True)["input_ids"]).to(dev)
     px = torch.randn(bs, 3, cfg.image_size, cfg.image_size, device=dev)
     t0 = time.perf_counter()
     with torch.no_grad():
-        model.encode_image(px); model.encode_text(ids)
+        model.encode_image(px); model.encode_text(ids); model.encode_text(ids[:bs])
     torch.cuda.synchronize()
     print(spec, "tuned in", round(time.perf_counter() - t0, 1), "s", flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
