@@ -1,5 +1,7 @@
-"""CLIP dual encoder for the embedding stage of the hot path (PyTorch-ROCm: hipBLASLt GEMMs + SDPA
-run on the MFMA pipes; this file is plumbing around them, not a kernel).
+"""CLIP dual encoder for the embedding stage of the hot path.  On the GPU inference path every block
+runs on the HIP library: tower GEMMs through lemon_linear_f32 (hipBLASLt with bias / SiLU / residual
+epilogues), attention through lemon_attention_f32; PyTorch supplies LayerNorm, the patch convolution and
+the tensors.  The CPU / autograd path (parity oracle for the encoder) is plain PyTorch.
 
 Mirrors the model surface run_lemon.py uses:
   algorithm_class_from_scratch(name, text_base_name, img_base, return_tokenizer)   lib/models/utils.py:64-105
@@ -11,8 +13,8 @@ ids (:363-376), bias-free projections.  Weights load from a LOCAL HF checkpoint 
 (config.json + model.safetensors | pytorch_model.bin); there is no network in this environment,
 so loading by hub name is refused with a clear message.
 
-MI355X-first choices: fused QKV projection (one [3W,W] GEMM instead of three), SDPA instead of a
-materialised attention matrix, text batches truncated to the longest prompt (exact, because the mask
+MI355X-first choices: fused QKV projection (one [3W,W] GEMM instead of three), a fused attention kernel
+instead of a materialised attention matrix, text batches truncated to the longest prompt (exact, because the mask
 is causal and pooling reads the EOT position: SURVEY 3.2), distinct prompts embedded once and
 gathered (classification datasets have C distinct prompts for N samples).
 """
