@@ -297,7 +297,8 @@ def test_auto_picks_bf16_on_spread_data_and_f32_on_band_crowded_data(hip):
     q = hip.normalize_vectors(torch.randn(nq, d, generator=g, device="cuda"))
     proto = hip.normalize_vectors(torch.randn(10, d, generator=g, device="cuda"))
     crowded = proto[torch.randint(0, 10, (n,), generator=g, device="cuda")]       # class-prompt style duplicates
-    for X, Q, expect in ((spread, q, 2), (crowded, crowded[:nq % n + n][:nq] if False else proto[torch.randint(0, 10, (nq,), generator=g, device="cuda")], 1)):
+    crowded_q = proto[torch.randint(0, 10, (nq,), generator=g, device="cuda")]
+    for X, Q, expect in ((spread, q, 2), (crowded, crowded_q, 1)):   # expect: LEMON_ALGO_BF16_FILTER / LEMON_ALGO_F32_MFMA
         auto = hip.IndexFlatIP(d)
         auto.add(X)
         Da, Ia = auto.search(Q, 10)
