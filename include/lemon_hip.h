@@ -81,6 +81,19 @@ int lemon_d1_normalized(int metric, const float *q_img_dev, int64_t n, int d,
  * x_dev must be 16-byte aligned. */
 int lemon_quick_gelu(float *x_dev, int64_t n, void *stream);
 
+/* generic_transform (lib/datasets/utils.py:159-170: Resize(224, BICUBIC) -> CenterCrop(224) -> ToTensor ->
+ * Normalize) for a batch of equally sized uint8 HWC images, bit-identical to PIL + torch: the two integer
+ * resampling passes of PIL (22-bit fixed-point taps, horizontal then vertical, clip8) and (v/255-mean)/std.
+ * img_dev [batch, in_h, in_w, 3] uint8; kk_*_dev [out_size, ks_*] int32 taps and bnd_*_dev [out_size, 2]
+ * (first input index, tap count) for the out_size CROPPED output columns / rows (built on the host:
+ * lemon_amd/data.py::pil_bicubic_tables); rows_per_block output rows per workgroup, max_rows_per_block
+ * = the largest number of input rows one block's vertical windows span (x out_size x 3 bytes <= 64 KB);
+ * mean3_host/std3_host: 3 floats each (host memory); out_dev [batch, 3, out_size, out_size] float32. */
+int lemon_preprocess_u8(const uint8_t *img_dev, int64_t batch, int in_h, int in_w, const int32_t *kk_h_dev,
+                        const int32_t *bnd_h_dev, int ks_h, const int32_t *kk_v_dev, const int32_t *bnd_v_dev,
+                        int ks_v, int out_size, int max_rows_per_block, int rows_per_block,
+                        const float *mean3_host, const float *std3_host, float *out_dev, void *stream);
+
 /* Multi-head self-attention of the CLIP towers, fused to one pass: the attention inside
  * encode_image / encode_text (lib/models/downstream_models.py:37-41 -> HF CLIPAttention; in-tree twin
  * lib/models/chexzero_clip.py:191-212 with the causal mask of :348-354 for text).

@@ -185,7 +185,7 @@ def main(argv=None):
         """this rank's contiguous shard of a split -> (emb_img, emb_txt, meta) on the device"""
         lo, hi = shard_bounds(len(dset), world, rank)
         imgs, toks, meta = [], [], dict(noisy=[], clean=[], noisy_txt=[], clean_txt=[], prompts=[])
-        for px, clean, noisy in dset.batches(args.batch_size, lo, hi):
+        for px, clean, noisy in dset.batches(args.batch_size, lo, hi, device=device):
             noisy_txt, clean_txt, prompts = texts_of(noisy, clean)
             imgs.append(embedder.embed_images(px))
             toks.append(tokenize(prompts))

@@ -328,6 +328,20 @@ def test_quick_gelu_and_encoder_gpu_vs_cpu(hip):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("h,w", [(32, 32), (48, 64), (300, 200), (500, 375), (37, 91), (224, 224), (640, 480), (225, 224)])
+def test_gpu_preprocess_bit_identical_to_pil_pipeline(hip, h, w):
+    # lemon_preprocess_u8 vs generic_transform (PIL bicubic resize -> center crop -> /255 -> normalise)
+    from PIL import Image
+    from lemon_amd.data import generic_transform, gpu_transform_batch
+    rng = np.random.default_rng(h * 1000 + w)
+    imgs = rng.integers(0, 256, (3, h, w, 3), dtype=np.uint8)
+    ref = torch.stack([generic_transform(Image.fromarray(im), 224) for im in imgs])
+    got = gpu_transform_batch(torch.from_numpy(imgs).cuda(), 224).cpu()
+    assert got.shape == ref.shape == (3, 3, 224, 224)
+    assert torch.equal(got, ref), (got - ref).abs().max()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,L,H,causal", [
     (3, 50, 12, False), (2, 77, 8, True), (5, 8, 8, True), (1, 197, 12, False), (1, 257, 16, False),
     (2, 1, 2, False), (2, 33, 3, True), (2, 64, 2, True), (1, 288, 1, True),

@@ -144,3 +144,25 @@ def test_gemm_tuning_results_file_is_well_formed():
     assert ops and all(len(l) == 4 and l[0].startswith("Gemm") and float(l[3]) > 0 for l in ops)
     keys = {l[1] for l in ops}
     assert "tn_2304_50000_768_ld_768_768_2304" in keys      # ViT-B/32 QKV projection at encoder batch 1000
+
+
+@pytest.mark.parametrize("h,w,oh,ow", [(32, 32, 224, 224), (48, 64, 224, 298), (300, 200, 336, 224), (500, 375, 298, 224),
+                                       (37, 91, 224, 550), (640, 480, 298, 224)])
+def test_pil_bicubic_tables_reproduce_pil_resize(h, w, oh, ow):
+    # lemon_amd/data.py::pil_bicubic_tables (what lemon_preprocess_u8 consumes) against PIL itself
+    from PIL import Image
+    from lemon_amd.data import PIL_PRECISION_BITS, pil_bicubic_tables
+
+    def axis(img, out_size):          # resample axis 1 of a uint8 [H, W, C] array
+        kk, b = pil_bicubic_tables(img.shape[1], out_size)
+        out = np.zeros((img.shape[0], out_size, img.shape[2]), np.uint8)
+        for xx in range(out_size):
+            x0, n = b[xx]
+            acc = (1 << (PIL_PRECISION_BITS - 1)) + (img[:, x0:x0 + n].astype(np.int64) * kk[xx, :n][None, :, None]).sum(1)
+            out[:, xx] = np.clip(acc >> PIL_PRECISION_BITS, 0, 255)
+        return out
+
+    img = np.random.default_rng(h + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    got = axis(axis(img, ow).transpose(1, 0, 2), oh).transpose(1, 0, 2)      # horizontal pass, then vertical
+    ref = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BICUBIC))
+    assert np.array_equal(got, ref)
