@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--algo", default="auto", choices=["auto", "f32", "bf16"])
     ap.add_argument("--knn_n", type=int, default=1_000_000)
     ap.add_argument("--knn_d", type=int, default=768)
+    ap.add_argument("--input", default="u8", choices=["u8", "f32"],
+                    help="u8: raw 32x32 uint8 images resident in HBM, preprocessing (bicubic resize to 224, normalise) "
+                         "inside the timed step; f32: already preprocessed pixel tensors")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--tunableop", action="store_true",
                     help="also turn on PyTorch TunableOp for the few GEMMs still issued by torch (the towers' Linear "
@@ -114,8 +117,9 @@ def max_over_ranks(x, world, dev):
 
 # ------------------------------------------------------------------------------ workloads
 def make_cifar_like(args, cfg, rank, dev):
-    """Synthetic CIFAR-100-shaped input, resident in HBM: normalised pixel tensors (what
-    generic_transform hands the model, lib/datasets/utils.py:163-170) and tokenised prompts
+    """Synthetic CIFAR-100-shaped input, resident in HBM: raw 32x32 uint8 images (what the CIFAR
+    pickles hold; generic_transform, lib/datasets/utils.py:163-170, then runs inside the step) or, with
+    --input f32, already preprocessed pixel tensors; and tokenised prompts
     'A photo of a <noisy label>' (run_lemon.py:117-119,140-146)."""
     from lemon_amd import datasets as ds
     from lemon_amd.clip import SyntheticTokenizer
@@ -129,9 +133,12 @@ def make_cifar_like(args, cfg, rank, dev):
         clean = rng.integers(0, 100, n)
         flip = rng.random(n) < 0.4
         noisy = np.where(flip, (clean + 1) % 100, clean)          # pair-flip ("asymmetric") noise
-        px = torch.empty((n, 3, cfg.image_size, cfg.image_size), dtype=torch.float32, device=dev)
-        for i in range(0, n, 2000):                               # chunked: keeps the RNG workspace small
-            px[i:i + 2000].normal_(generator=g)
+        if args.input == "u8":       # raw CIFAR-shaped images: generic_transform runs inside the timed step (on the GPU)
+            px = torch.randint(0, 256, (n, 32, 32, 3), dtype=torch.uint8, device=dev, generator=g)
+        else:
+            px = torch.empty((n, 3, cfg.image_size, cfg.image_size), dtype=torch.float32, device=dev)
+            for i in range(0, n, 2000):                           # chunked: keeps the RNG workspace small
+                px[i:i + 2000].normal_(generator=g)
         data[name] = dict(pixels=px, ids=class_ids[torch.from_numpy(noisy)].to(dev),
                           label_id=torch.from_numpy(noisy.astype(np.int32)).to(dev),
                           clean=clean, noisy=noisy)
@@ -199,7 +206,7 @@ def bench_cifar(args, world, rank, dev):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"CIFAR-100 shape per GPU: {args.n_train} train (=DB shard) + {args.n_val} val + {args.n_test} test "
-                        f"image/prompt pairs, CLIP {args.arch} random-init fp32 encoder -> {cfg.embed_dim}-d, "
+                        f"image/prompt pairs ({'raw 32x32 uint8 images, bicubic resize to 224 + normalise in the step' if args.input == 'u8' else 'preprocessed float pixels'}), CLIP {args.arch} random-init fp32 encoder -> {cfg.embed_dim}-d, "
                         f"{args.dist_type} brute-force kNN k={args.knn_k} over the all-gathered {args.n_train * world}-row DB, "
                         "multimodal-neighbour scores (beta=gamma=5,tau1=0.1,tau2=5)",
             "noise": "pair-flip 0.4 (reference's 'asymmetric'; 'cat' is not defined for CIFAR upstream)",
@@ -245,6 +252,14 @@ def cpu_baseline_cifar(args, cfg, model, data, recs, db, n_scored):
     cpu_model = cpu_model.float().eval()
     ni = min(args.cpu_sample_images, args.n_val)
     px = data["val"]["pixels"][:ni].cpu()
+    if px.dtype == torch.uint8:      # the reference's CPU path: PIL bicubic resize + normalise per image
+        from PIL import Image
+        from lemon_amd.data import generic_transform
+        t_pre = time.perf_counter()
+        px = torch.stack([generic_transform(Image.fromarray(im.numpy()), cfg.image_size) for im in px])
+        t_pre = (time.perf_counter() - t_pre) / ni
+    else:
+        t_pre = 0.0
     ids = data["val"]["ids"][:ni].cpu()
     cpu_model.encode_image(px[:8])                              # warm
     t0 = time.perf_counter()
@@ -262,7 +277,8 @@ def cpu_baseline_cifar(args, cfg, model, data, recs, db, n_scored):
     ref = o.neighbors(args.dist_type, img_tr, txt_tr, q_img, q_txt, args.knn_k)
     sref = o.score(ref, FIXED_HPARAMS)
     t_knn = (time.perf_counter() - t0) / nqs                    # s per query (DB fixed at n_train rows)
-    per_sample = t_embed + t_knn
+    t_pre /= cores                                               # PIL work spread over all cores (generous to the CPU)
+    per_sample = t_pre + t_embed + t_knn
     y = (data["val"]["clean"] != data["val"]["noisy"])[:nqs]
     sgpu = rv["score"][:nqs].cpu().numpy()
     same_sets = bool(np.array_equal(rv["I_n"][:nqs].cpu().numpy(), ref["I_n"]) and
@@ -274,10 +290,10 @@ def cpu_baseline_cifar(args, cfg, model, data, recs, db, n_scored):
              "per_sample_arrays_bit_exact": bool(arrays_equal)}
     base = {
         "value": 1.0 / per_sample, "unit": "scores/s", "cores": cores, "kind": "port",
-        "sample": f"{ni} image+prompt pairs through the same CLIP module on CPU fp32 (torch, {cores} threads) "
+        "sample": f"{ni} images through PIL generic_transform (time / {cores} cores) and {ni} image+prompt pairs through the same CLIP module on CPU fp32 (torch, {cores} threads) "
                   f"+ oracle kNN/neighbours/score for {nqs} val queries against the full {args.n_train}-row DB "
                   f"(OpenMP, {cores} threads); per-sample times added and inverted; train embedded once as on the GPU",
-        "embed_s_per_sample": t_embed, "knn_score_s_per_sample": t_knn,
+        "preprocess_s_per_sample": t_pre, "embed_s_per_sample": t_embed, "knn_score_s_per_sample": t_knn,
     }
     return base, auroc
 

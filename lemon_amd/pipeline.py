@@ -53,9 +53,16 @@ class Embedder:
 
     @torch.no_grad()
     def embed_images(self, pixel_values):
+        """pixel_values: float [n,3,S,S] already preprocessed, or uint8 [n,H,W,3] raw images -- then
+        generic_transform runs on the GPU per micro-batch (lemon_preprocess_u8, lib/datasets/utils.py:159-170)."""
+        raw = pixel_values.dtype == torch.uint8
+        if raw:
+            from .data import gpu_transform_batch
         outs = []
         for i in range(0, pixel_values.shape[0], self.batch_size):
             px = pixel_values[i:i + self.batch_size].to(self.device, non_blocking=True)
+            if raw:
+                px = gpu_transform_batch(px, self.model.cfg.image_size)
             outs.append(self.model.encode_image(px).float())
         e = torch.cat(outs) if outs else torch.empty((0, self.model.cfg.embed_dim), device=self.device)
         return ops.normalize_vectors(e) if e.shape[0] else e                          # :164 / :233
@@ -124,7 +131,7 @@ def score_splits(db, splits, k, hparams=None, discrete=False):
 
 def run_hot_path(embedder, data, k=5, dist_type="cosine", hparams=FIXED_HPARAMS, discrete=False,
                  world_size=1, rank=0, algo=None, timers=None, profile_index=False):
-    """One pass of the hot path over `data` = {split: {"pixels": [n,3,H,W], "ids": [n,L], "label_id": [n]}}
+    """One pass of the hot path over `data` = {split: {"pixels": float [n,3,S,S] or raw uint8 [n,H,W,3], "ids": [n,L], "label_id": [n]}}
     for split in train/val/test, this rank's shard of each.  DB = all ranks' train shards in global
     order.  The train split is embedded ONCE and reused as DB and as queries (the reference embeds it
     twice, run_lemon.py:137-161 and :198-233; same model, same inputs => same embeddings)."""
