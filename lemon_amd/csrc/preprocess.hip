@@ -48,28 +48,34 @@ __global__ __launch_bounds__(256) void k_preprocess_u8(PreParams p) {
     const int rows = vmax - vmin;
     const uint8_t *img = p.img + b * (int64_t)p.H * p.W * 3;
 
-    for (int e = tid; e < rows * S3; e += blockDim.x) {
-        const int r = e / S3, rem = e - r * S3, x = rem / 3, c = rem - 3 * x;
-        const int xmin = p.bnd_h[2 * x], n = p.bnd_h[2 * x + 1];
-        const int32_t *k = p.kk_h + x * p.ks_h;
-        const uint8_t *src = img + ((int64_t)(vmin + r) * p.W + xmin) * 3 + c;
-        int acc = 1 << (PIL_PRECISION_BITS - 1);
-        for (int t = 0; t < n; ++t) acc += (int)src[3 * t] * k[t];
-        s_tmp[e] = pil_clip8(acc);
+    for (int r = 0; r < rows; ++r) {                                 // uniform outer loops: no per-element div/mod
+        const uint8_t *row = img + (int64_t)(vmin + r) * p.W * 3;
+        for (int xc = tid; xc < S3; xc += blockDim.x) {
+            const int x = xc / 3, c = xc - 3 * x;
+            const int xmin = p.bnd_h[2 * x], n = p.bnd_h[2 * x + 1];
+            const int32_t *k = p.kk_h + x * p.ks_h;
+            const uint8_t *src = row + xmin * 3 + c;
+            int acc = 1 << (PIL_PRECISION_BITS - 1);
+            for (int t = 0; t < n; ++t) acc += (int)src[3 * t] * k[t];
+            s_tmp[r * S3 + xc] = pil_clip8(acc);
+        }
     }
     __syncthreads();
 
-    const int nrow = y1 - y0;
-    for (int e = tid; e < 3 * nrow * S; e += blockDim.x) {
-        const int x = e % S, yy = (e / S) % nrow, c = e / (S * nrow), y = y0 + yy;
-        const int ymin = p.bnd_v[2 * y], n = p.bnd_v[2 * y + 1];
-        const int32_t *k = p.kk_v + y * p.ks_v;
-        const uint8_t *src = s_tmp + (ymin - vmin) * S3 + 3 * x + c;
-        int acc = 1 << (PIL_PRECISION_BITS - 1);
-        for (int t = 0; t < n; ++t) acc += (int)src[t * S3] * k[t];
-        float f = (float)pil_clip8(acc) / 255.0f;                    // ToTensor
-        f = (f - p.mean[c]) / p.stdv[c];                             // Normalize
-        p.out[((b * 3 + c) * S + y) * (int64_t)S + x] = f;
+    for (int c = 0; c < 3; ++c) {
+        const float mean = p.mean[c], stdv = p.stdv[c];
+        for (int y = y0; y < y1; ++y) {
+            const int ymin = p.bnd_v[2 * y], n = p.bnd_v[2 * y + 1];
+            const int32_t *k = p.kk_v + y * p.ks_v;
+            float *dst = p.out + ((b * 3 + c) * S + y) * (int64_t)S;
+            for (int x = tid; x < S; x += blockDim.x) {
+                const uint8_t *src = s_tmp + (ymin - vmin) * S3 + 3 * x + c;
+                int acc = 1 << (PIL_PRECISION_BITS - 1);
+                for (int t = 0; t < n; ++t) acc += (int)src[t * S3] * k[t];
+                float f = (float)pil_clip8(acc) / 255.0f;                // ToTensor
+                dst[x] = (f - mean) / stdv;                              // Normalize
+            }
+        }
     }
 }
 
