@@ -214,6 +214,17 @@ int lemon_score(const float *d1_dev, const float *D_n_dev, const float *dists_tr
                 const float *dists_m_dev, int64_t n, int k, const double hp[6],
                 double *score_dev, double *d_n_dev, double *d_m_dev, void *stream);
 
+/* The hyper-parameter grid of run_lemon.py:319-384 as one batch: for each of G rows of hp_dev
+ * [G,6] = (beta, gamma, tau_1_n, tau_2_n, tau_1_m, tau_2_m) the scores of lemon_score (same float64
+ * arithmetic) and optimize_f1_efficient (lib/metrics/utils.py:286-296: scipy fminbound on -F1(y, score >= t),
+ * xtol, maxfun) -> f1_dev[G], thres_dev[G] (float64), bit-identical to evaluating the grid points one by one
+ * on the host.  y_dev [n] uint8 (is_mislabel); scores_ws_dev: caller-provided [G, n] float64 workspace;
+ * G <= 65535.  A grid point whose scores are not all finite gets f1 = 0, thres = NaN. */
+int lemon_grid_f1(const float *d1_dev, const float *D_n_dev, const float *dists_tr_n_dev, const float *dists_n_dev,
+                  const float *D_m_dev, const float *dists_tr_m_dev, const float *dists_m_dev,
+                  const uint8_t *y_dev, int64_t n, int k, const double *hp_dev, int G, double xtol, int maxfun,
+                  double *scores_ws_dev, double *f1_dev, double *thres_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,7 @@ EXPORTS = [
     "lemon_linear_dump_tuned", "lemon_index_create", "lemon_index_free", "lemon_index_add",
     "lemon_index_ntotal", "lemon_index_dim", "lemon_index_data", "lemon_index_search",
     "lemon_index_set_algo", "lemon_index_last_search_info", "lemon_index_set_profiling",
-    "lemon_index_profile_read", "lemon_neighbors", "lemon_discrepancy", "lemon_score",
+    "lemon_index_profile_read", "lemon_neighbors", "lemon_discrepancy", "lemon_score", "lemon_grid_f1",
 ]
 
 
@@ -61,6 +61,7 @@ def load():
     lib.lemon_quick_gelu.argtypes = [vp, c_i64, vp]
     lib.lemon_preprocess_u8.argtypes = [vp, c_i64, c_int, c_int, vp, vp, c_int, vp, vp, c_int, c_int, c_int, c_int,
                                         ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), vp, vp]
+    lib.lemon_grid_f1.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_int, vp, c_int, ctypes.c_double, c_int, vp, vp, vp, vp]
     lib.lemon_attention_f32.argtypes = [vp, c_i64, c_int, c_int, c_int, c_int, vp, vp]
     lib.lemon_linear_f32.argtypes = [vp, vp, vp, vp, c_i64, c_int, c_int, ctypes.c_float, c_int, vp, vp]
     lib.lemon_linear_load_tuned.argtypes = [ctypes.c_char_p]

@@ -9,7 +9,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "liblemon_hip.so")
-SOURCES = ["api.hip", "rowwise.hip", "knn_f32.hip", "knn_bf16.hip", "attention.hip", "linear.hip", "preprocess.hip"]
+SOURCES = ["api.hip", "rowwise.hip", "knn_f32.hip", "knn_bf16.hip", "attention.hip", "linear.hip", "preprocess.hip", "gridf1.hip"]
 HEADERS = ["common.hpp", os.path.join("..", "..", "include", "lemon_hip.h")]
 
 

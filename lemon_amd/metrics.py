@@ -185,7 +185,8 @@ def _torch_lbfgs(rec_t, y, x0, force_zero, force_one, max_iter=20):
 
 
 def maximize_metric(score_fn, y, grid, x0s, obj_func=optimize_f1_efficient, obj_func_args=None,
-                    force_zero=(), force_one=(), scipy_methods=("Powell", "Nelder-Mead"), rec_for_lbfgs=None):
+                    force_zero=(), force_one=(), scipy_methods=("Powell", "Nelder-Mead"), rec_for_lbfgs=None,
+                    batch_grid=None):
     """lib/metrics/utils.py:151-196.  score_fn(hparams dict) -> scores (numpy [n]); y = is_mislabel.
     Order of candidates (and therefore tie-breaking on equal objective) follows the reference:
     scipy local searches from every start, LBFGS-polished starts, then the full grid; strict '>'."""
@@ -218,6 +219,7 @@ def maximize_metric(score_fn, y, grid, x0s, obj_func=optimize_f1_efficient, obj_
             val = -objective(cand)
             if val > best_val:
                 best_val, best_x = val, cand
+    gs = []
     for c in combinations_base(grid):
         g = []
         for name in HP_NAMES:
@@ -231,7 +233,12 @@ def maximize_metric(score_fn, y, grid, x0s, obj_func=optimize_f1_efficient, obj_
                 raise NotImplementedError(name)
             if name in force_zero:
                 g[-1] = 0.0
-        val = -objective(g)
+        gs.append(g)
+    # batch_grid: all grid points in one device launch (ops.grid_f1: same scores, same bounded-Brent search,
+    # bit-identical values); the winner is still picked in grid order with the reference's strict '>'
+    vals = batch_grid([unpack_vector(g, force_zero, force_one) for g in gs]) if (batch_grid is not None and gs) else None
+    for j, g in enumerate(gs):
+        val = float(vals[j]) if vals is not None else -objective(g)
         if val > best_val:
             best_val, best_x = val, g
     best_x = list(best_x)

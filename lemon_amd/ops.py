@@ -82,6 +82,34 @@ def quick_gelu_(x):
     return x
 
 
+def grid_f1(rec, y, hparams, xtol=1e-8, maxfun=500, return_scores=False):
+    """Batched hyper-parameter grid: for every row (beta, gamma, tau_1_n, tau_2_n, tau_1_m, tau_2_m) of
+    `hparams` [G,6] the F1-optimal threshold search of optimize_f1_efficient on the device-resident
+    record `rec` (lemon_grid_f1) -> (f1 [G], thres [G]) numpy float64, bit-identical to the host loop."""
+    import numpy as np
+    dev = rec["D_n"].device
+    f32 = lambda key: dev_f32(rec[key], key)
+    d1, Dn, trn, dn, Dm, trm, dm = (f32(key) for key in ("d_1", "D_n", "dists_tr_n", "dists_n", "D_m", "dists_tr_m", "dists_m"))
+    n, k = Dn.shape
+    yb = torch.as_tensor(np.asarray(y).astype(bool).astype(np.uint8)).to(dev)
+    hp = torch.as_tensor(np.asarray(hparams, dtype=np.float64).reshape(-1, 6)).to(dev)
+    G = hp.shape[0]
+    f1 = torch.empty(G, dtype=torch.float64, device=dev)
+    th = torch.empty(G, dtype=torch.float64, device=dev)
+    lib = _lib.load()
+    chunk = max(1, min(65535, (1 << 30) // (8 * n)))             # <= 1 GiB of score workspace per launch
+    ws = torch.empty((min(G, chunk), n), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        for g0 in range(0, G, chunk):
+            g1 = min(G, g0 + chunk)
+            _lib.check(lib.lemon_grid_f1(ptr(d1), ptr(Dn), ptr(trn), ptr(dn), ptr(Dm), ptr(trm), ptr(dm), ptr(yb), n, k,
+                                         ptr(hp[g0:g1]), g1 - g0, float(xtol), int(maxfun), ptr(ws), ptr(f1[g0:g1]),
+                                         ptr(th[g0:g1]), stream_ptr(dev)), "lemon_grid_f1")
+    if return_scores:
+        return f1.cpu().numpy(), th.cpu().numpy(), ws[:min(G, chunk)].cpu().numpy()
+    return f1.cpu().numpy(), th.cpu().numpy()
+
+
 ATTENTION_MAX_SEQ = 288
 ACT_NONE, ACT_SILU = 0, 1
 QUICK_GELU_SCALE = 1.702

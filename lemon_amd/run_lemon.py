@@ -298,7 +298,8 @@ def main(argv=None):
                              for c in ("d_1", "D_n", "dists_tr_n", "dists_n", "D_m", "dists_tr_m", "dists_m")}
                 best, best_f1, best_thres = M.maximize_metric(
                     score_fn, y_val, grid, [[0] * 6, [0.5] * 6, [1] * 6, [10] * 6], M.optimize_f1_efficient, {},
-                    force_zero=force_zero, force_one=force_one, rec_for_lbfgs=rec_lbfgs)
+                    force_zero=force_zero, force_one=force_one, rec_for_lbfgs=rec_lbfgs,
+                    batch_grid=lambda hps: ops.grid_f1(rec_val, y_val, [[hp[n] for n in M.HP_NAMES] for hp in hps])[0])
             sel_res = dict(zip(M.HP_NAMES, best))
             sel_res.update(thres=best_thres, selected_val=best_f1)
         s, dn, dm = ops.lemon_score(device_rec(df), sel_res, return_dn=True)

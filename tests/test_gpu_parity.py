@@ -328,6 +328,32 @@ def test_quick_gelu_and_encoder_gpu_vs_cpu(hip):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,k", [(700, 5), (5000, 50), (63, 1)])
+def test_grid_f1_batch_bit_identical_to_host_loop(hip, N, k):
+    # lemon_grid_f1 (scores + bounded-Brent threshold search per grid point on the GPU) vs the host loop
+    # K5 -> numpy -> scipy.fminbound that maximize_metric runs per grid point (lib/metrics/utils.py:151-196,286-296)
+    from lemon_amd import metrics as M, ops
+    g = torch.Generator(device="cuda").manual_seed(N + k)
+    rnd = lambda *s: torch.rand(*s, generator=g, device="cuda")
+    y = (rnd(N) < 0.4).cpu().numpy()
+    rec = {"d_1": rnd(N) + torch.as_tensor(y, device="cuda") * 0.2, "D_n": -rnd(N, k), "dists_tr_n": rnd(N, k),
+           "dists_n": rnd(N, k), "D_m": -rnd(N, k), "dists_tr_m": rnd(N, k), "dists_m": rnd(N, k)}
+    rng = np.random.default_rng(0)
+    hps = [[0, 0, 0, 0, 0, 0], [5, 5, 0.1, 5, 0.1, 5], [100, 0, 10, 0, 10, 0], [0, 100, 0, 10, 0, 10], [1, 1, 1, 1, 1, 1]]
+    hps += [list(rng.choice([0, 5, 10, 50, 100], 2)) + list(rng.choice([0, 1, 5, 10], 4)) for _ in range(120)]
+    hps += [[1e308, 1e308, 800, 800, 800, 800]]                     # overflows to inf/nan scores: objective 0
+    f1, thres, scores = ops.grid_f1(rec, y, hps, return_scores=True)
+    for j, hp in enumerate(hps):
+        s = ops.lemon_score(rec, dict(zip(M.HP_NAMES, hp))).cpu().numpy()
+        assert np.array_equal(s, scores[j], equal_nan=True), f"scores differ at grid point {j}"
+        if not np.all(np.isfinite(s)):
+            assert f1[j] == 0.0
+            continue
+        ref_f1, ref_t = M.optimize_f1_efficient(y, s, return_thres=True)
+        assert f1[j] == ref_f1 and thres[j] == ref_t, (j, hp, f1[j], ref_f1, thres[j], ref_t)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("h,w", [(32, 32), (48, 64), (300, 200), (500, 375), (37, 91), (224, 224), (640, 480), (225, 224)])
 def test_gpu_preprocess_bit_identical_to_pil_pipeline(hip, h, w):
     # lemon_preprocess_u8 vs generic_transform (PIL bicubic resize -> center crop -> /255 -> normalise)

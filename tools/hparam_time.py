@@ -15,6 +15,10 @@ best, f1, thr = M.maximize_metric(score_fn, y, grid, [[0] * 6, [0.5] * 6, [1] * 
                                   scipy_methods=())      # grid part only
 print("grid only:", round(time.perf_counter() - t0, 2), "s", best, f1, thr)
 t0 = time.perf_counter()
+best, f1, thr = M.maximize_metric(score_fn, y, grid, [[0] * 6, [0.5] * 6, [1] * 6, [10] * 6], M.optimize_f1_efficient, {}, scipy_methods=(),
+                                  batch_grid=lambda hps: ops.grid_f1(rec, y, [[hp[n] for n in M.HP_NAMES] for hp in hps])[0])
+print("grid only, batched on the GPU:", round(time.perf_counter() - t0, 3), "s", best, f1, thr)
+t0 = time.perf_counter()
 best, f1, thr = M.maximize_metric(score_fn, y, {"beta": [0], "gamma": [0], "tau_1": [0], "tau_2": [0]},
                                   [[0] * 6, [0.5] * 6, [1] * 6, [10] * 6], M.optimize_f1_efficient, {})
 print("scipy local searches only:", round(time.perf_counter() - t0, 2), "s", best, f1, thr)
