@@ -8,7 +8,7 @@ Mirrors (behaviour, not code) of:
   get_captioning_dataset / CaptioningDataset   lib/datasets/utils.py:275-323, dataloader.py:167-198
   get_large_scale_dataset / LargeScaleDataset  lib/datasets/utils.py:325-347, dataloader.py:113-133
 Datasets are read from LOCAL paths only (no download: there is no network).  A synthetic class dataset
-(`dataset_root='synthetic:N'`) stands in when no data is present.
+(`dataset_root='synthetic:N'`: seeded random uint8 images with the dataset's label set) stands in when no data is present.
 """
 import functools
 import math
@@ -184,32 +184,6 @@ class ImageLabelSet:
                 yield px, self.clean[sl], self.noisy[sl]
 
 
-class SyntheticPixelSet(ImageLabelSet):
-    """Seeded random 'images' generated per batch (no PIL): for runs without any dataset on disk."""
-
-    def __init__(self, n, clean, noisy, image_size=224, seed=0):
-        self.n, self.clean, self.noisy, self.image_size, self.seed = n, clean, noisy, image_size, seed
-        self.images = None
-
-    def __len__(self):
-        return self.n
-
-    def subset(self, idx):
-        out = SyntheticPixelSet(len(idx), self.clean[idx], self.noisy[idx], self.image_size, self.seed)
-        out.rows = (self.rows[idx] if hasattr(self, "rows") else np.asarray(idx))
-        return out
-
-    def batches(self, batch_size, lo=0, hi=None, device=None):
-        hi = self.n if hi is None else hi
-        rows = self.rows if hasattr(self, "rows") else np.arange(self.n)
-        for s in range(lo, hi, batch_size):
-            e = min(hi, s + batch_size)
-            px = torch.stack([torch.randn(3, self.image_size, self.image_size,
-                                          generator=torch.Generator().manual_seed(self.seed * 1_000_003 + int(r)))
-                              for r in rows[s:e]])
-            yield px, self.clean[s:e], self.noisy[s:e]
-
-
 # ------------------------------------------------------------------------------ dataset factory
 def _read_cifar(root, name):
     if name.startswith("cifar100"):
@@ -233,17 +207,16 @@ def get_dataset(name, data_seed, percent_flips=0.40, flip_type="real", data_root
         C = ds.class_num_dict[name]
         if str(data_root).startswith("synthetic"):
             n = int(str(data_root).split(":")[1]) if ":" in str(data_root) else 5000
-            y = np.random.RandomState(data_seed).randint(0, C, n)
-            images = None
+            rs = np.random.RandomState(data_seed)
+            y = rs.randint(0, C, n)
+            # seeded random CIFAR-shaped uint8 images: the same code path (and GPU preprocessing) as the real pickles
+            images = rs.randint(0, 256, (n, 32, 32, 3), dtype=np.uint8)
         else:
             images, y = _read_cifar(data_root, name)
             n = len(y)
         noisy = np.asarray(ds.add_noisy_labels(name, flip_type, percent_flips, data_seed, list(y), data_root))
         tr, va, te = ds.split_80_10_10(n, data_seed)
-        if images is None:
-            full = SyntheticPixelSet(n, y, noisy, image_size, data_seed)
-        else:
-            full = ImageLabelSet(images, y, noisy, image_size)
+        full = ImageLabelSet(images, y, noisy, image_size)
         return full.subset(tr), full.subset(va), full.subset(te)
     if name in ("mscoco", "flickr30k", "mimiccxr_caption", "mmimdb", "cc3m"):
         import pandas as pd

@@ -62,6 +62,8 @@ def build_parser():
     p.add_argument("--data_root", default="./data", help="local dataset root, or synthetic:N")
     p.add_argument("--algo", default="auto", choices=["auto", "f32", "bf16"], help="kNN scan algorithm")
     p.add_argument("--encoder_batch", default=512, type=int, help="encoder micro-batch on the GPU")
+    p.add_argument("--lbfgs_device", default="cuda", choices=["cuda", "cpu"],
+                   help="where the SoftMargin/LBFGS polish of the hyper-parameter search runs (lib/metrics/utils.py:121-149)")
     p.add_argument("--gemm_tuning", action="store_true",
                    help="let TunableOp pick the hipBLASLt solution per encoder GEMM shape (lemon_amd/tuning.py)")
     p.add_argument("--hparam_grid", default="full", choices=["full", "small"],
@@ -185,7 +187,9 @@ def main(argv=None):
         """this rank's contiguous shard of a split -> (emb_img, emb_txt, meta) on the device"""
         lo, hi = shard_bounds(len(dset), world, rank)
         imgs, toks, meta = [], [], dict(noisy=[], clean=[], noisy_txt=[], clean_txt=[], prompts=[])
-        for px, clean, noisy in dset.batches(args.batch_size, lo, hi, device=device):
+        # data chunks of the encoder micro-batch (the reference's --batch_size only sizes its DataLoader batches;
+        # per-sample results do not depend on it)
+        for px, clean, noisy in dset.batches(max(args.batch_size, args.encoder_batch), lo, hi, device=device):
             noisy_txt, clean_txt, prompts = texts_of(noisy, clean)
             imgs.append(embedder.embed_images(px))
             toks.append(tokenize(prompts))
@@ -299,6 +303,7 @@ def main(argv=None):
                 best, best_f1, best_thres = M.maximize_metric(
                     score_fn, y_val, grid, [[0] * 6, [0.5] * 6, [1] * 6, [10] * 6], M.optimize_f1_efficient, {},
                     force_zero=force_zero, force_one=force_one, rec_for_lbfgs=rec_lbfgs,
+                    lbfgs_device=str(device) if args.lbfgs_device == "cuda" else "cpu",
                     batch_grid=lambda hps: ops.grid_f1(rec_val, y_val, [[hp[n] for n in M.HP_NAMES] for hp in hps])[0])
             sel_res = dict(zip(M.HP_NAMES, best))
             sel_res.update(thres=best_thres, selected_val=best_f1)
