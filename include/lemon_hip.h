@@ -88,11 +88,14 @@ int lemon_quick_gelu(float *x_dev, int64_t n, void *stream);
  * (first input index, tap count) for the out_size CROPPED output columns / rows (built on the host:
  * lemon_amd/data.py::pil_bicubic_tables); rows_per_block output rows per workgroup, max_rows_per_block
  * = the largest number of input rows one block's vertical windows span (x out_size x 3 bytes <= 64 KB);
- * mean3_host/std3_host: 3 floats each (host memory); out_dev [batch, 3, out_size, out_size] float32. */
+ * mean3_host/std3_host: 3 floats each (host memory); out_dev [batch, 3, out_size, out_size] float32 when
+ * patch == 0, else patch-major [batch, (out_size/patch)^2, 3*patch*patch] -- the rows the ViT patch
+ * embedding (a stride == kernel convolution, HF CLIPVisionEmbeddings / chexzero_clip.py:226-238) multiplies,
+ * so that it becomes one lemon_linear_f32 GEMM with no im2col pass. */
 int lemon_preprocess_u8(const uint8_t *img_dev, int64_t batch, int in_h, int in_w, const int32_t *kk_h_dev,
                         const int32_t *bnd_h_dev, int ks_h, const int32_t *kk_v_dev, const int32_t *bnd_v_dev,
                         int ks_v, int out_size, int max_rows_per_block, int rows_per_block,
-                        const float *mean3_host, const float *std3_host, float *out_dev, void *stream);
+                        const float *mean3_host, const float *std3_host, int patch, float *out_dev, void *stream);
 
 /* Multi-head self-attention of the CLIP towers, fused to one pass: the attention inside
  * encode_image / encode_text (lib/models/downstream_models.py:37-41 -> HF CLIPAttention; in-tree twin

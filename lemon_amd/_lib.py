@@ -60,7 +60,7 @@ def load():
     lib.lemon_paired_metric.argtypes = [c_int, vp, vp, c_i64, c_int, vp, vp]
     lib.lemon_quick_gelu.argtypes = [vp, c_i64, vp]
     lib.lemon_preprocess_u8.argtypes = [vp, c_i64, c_int, c_int, vp, vp, c_int, vp, vp, c_int, c_int, c_int, c_int,
-                                        ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), vp, vp]
+                                        ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_int, vp, vp]
     lib.lemon_grid_f1.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_int, vp, c_int, ctypes.c_double, c_int, vp, vp, vp, vp]
     lib.lemon_attention_f32.argtypes = [vp, c_i64, c_int, c_int, c_int, c_int, vp, vp]
     lib.lemon_linear_f32.argtypes = [vp, vp, vp, vp, c_i64, c_int, c_int, ctypes.c_float, c_int, vp, vp]

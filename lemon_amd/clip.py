@@ -132,7 +132,13 @@ class VisionTower(nn.Module):
         self.proj = nn.Linear(v.width, cfg.embed_dim, bias=False)
 
     def forward(self, pixel_values):
-        x = self.patch(pixel_values.to(self.patch.weight.dtype)).flatten(2).transpose(1, 2)
+        if pixel_values.dim() == 3:
+            # patch-major input [B, nP, 3*P*P] (lemon_preprocess_u8 with patch=P): the stride == kernel
+            # convolution is a plain GEMM with the flattened filter bank, no im2col and no MIOpen
+            from . import ops
+            x = ops.linear(pixel_values, self.patch.weight.reshape(self.patch.weight.shape[0], -1))
+        else:
+            x = self.patch(pixel_values.to(self.patch.weight.dtype)).flatten(2).transpose(1, 2)
         x = torch.cat([self.cls.expand(x.shape[0], 1, -1), x], dim=1) + self.pos
         x = self.pre_ln(x)
         for b in self.blocks:

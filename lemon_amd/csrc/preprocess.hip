@@ -27,6 +27,7 @@ struct PreParams {
     const int32_t *kk_h, *bnd_h, *kk_v, *bnd_v;   // [S, ks_h], [S, 2] (xmin, count), [S, ks_v], [S, 2]
     float *out;              // [B, 3, S, S]
     int H, W, S, ks_h, ks_v, R, blocks_per_img;
+    int patch;               // 0: NCHW; P > 0: patch-major [B, (S/P)^2, 3*P*P] (what the patch-embedding GEMM reads)
     float mean[3], stdv[3];
 };
 
@@ -67,13 +68,17 @@ __global__ __launch_bounds__(256) void k_preprocess_u8(PreParams p) {
         for (int y = y0; y < y1; ++y) {
             const int ymin = p.bnd_v[2 * y], n = p.bnd_v[2 * y + 1];
             const int32_t *k = p.kk_v + y * p.ks_v;
-            float *dst = p.out + ((b * 3 + c) * S + y) * (int64_t)S;
+            // NCHW row, or the row's place inside its patches: out[b][py*nP+px][c*P*P + (y%P)*P + (x%P)]
+            const int P = p.patch, nP = P ? S / P : 0;
+            float *dst = P ? p.out + (b * nP * nP + (int64_t)(y / P) * nP) * (3 * P * P) + c * P * P + (y % P) * P
+                           : p.out + ((b * 3 + c) * S + y) * (int64_t)S;
             for (int x = tid; x < S; x += blockDim.x) {
                 const uint8_t *src = s_tmp + (ymin - vmin) * S3 + 3 * x + c;
                 int acc = 1 << (PIL_PRECISION_BITS - 1);
                 for (int t = 0; t < n; ++t) acc += (int)src[t * S3] * k[t];
                 float f = (float)pil_clip8(acc) / 255.0f;                // ToTensor
-                dst[x] = (f - mean) / stdv;                              // Normalize
+                const float v = (f - mean) / stdv;                       // Normalize
+                if (P) dst[(int64_t)(x / P) * (3 * P * P) + (x % P)] = v; else dst[x] = v;
             }
         }
     }
@@ -84,15 +89,18 @@ __global__ __launch_bounds__(256) void k_preprocess_u8(PreParams p) {
 extern "C" int lemon_preprocess_u8(const uint8_t *img_dev, int64_t batch, int in_h, int in_w, const int32_t *kk_h_dev,
                                    const int32_t *bnd_h_dev, int ks_h, const int32_t *kk_v_dev, const int32_t *bnd_v_dev,
                                    int ks_v, int out_size, int max_rows_per_block, int rows_per_block,
-                                   const float *mean3_host, const float *std3_host, float *out_dev, void *stream) {
+                                   const float *mean3_host, const float *std3_host, int patch, float *out_dev,
+                                   void *stream) {
     LEMON_REQUIRE(batch >= 0 && in_h > 0 && in_w > 0 && out_size > 0, "batch >= 0, sizes > 0");
     LEMON_REQUIRE(ks_h > 0 && ks_v > 0 && rows_per_block > 0 && max_rows_per_block > 0, "table geometry");
+    LEMON_REQUIRE(patch >= 0 && (patch == 0 || out_size % patch == 0), "patch must divide out_size");
     if (batch == 0) return LEMON_OK;
     LEMON_REQUIRE(img_dev && kk_h_dev && bnd_h_dev && kk_v_dev && bnd_v_dev && mean3_host && std3_host && out_dev, "null pointer");
     const size_t lds = (size_t)max_rows_per_block * out_size * 3;
     LEMON_REQUIRE(lds <= 64 * 1024, "rows_per_block too large: the horizontal tile must fit 64 KB of LDS");
     PreParams p;
     p.img = img_dev; p.kk_h = kk_h_dev; p.bnd_h = bnd_h_dev; p.kk_v = kk_v_dev; p.bnd_v = bnd_v_dev; p.out = out_dev;
+    p.patch = patch;
     p.H = in_h; p.W = in_w; p.S = out_size; p.ks_h = ks_h; p.ks_v = ks_v; p.R = rows_per_block;
     p.blocks_per_img = (out_size + rows_per_block - 1) / rows_per_block;
     for (int c = 0; c < 3; ++c) { p.mean[c] = mean3_host[c]; p.stdv[c] = std3_host[c]; }

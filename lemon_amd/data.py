@@ -117,9 +117,10 @@ def _gpu_transform_plan(h, w, size, device_index):
                 max_rows=max(spans), rows_per_block=rows_per_block)
 
 
-def gpu_transform_batch(images_u8, size=224):
+def gpu_transform_batch(images_u8, size=224, patch=0):
     """generic_transform for a uint8 CUDA batch [B,H,W,3] in one HIP kernel (lemon_preprocess_u8):
-    -> float32 [B,3,size,size], bit-identical to the PIL + torch pipeline."""
+    -> float32 [B,3,size,size], bit-identical to the PIL + torch pipeline; with patch=P the same values
+    in patch-major order [B, (size/P)^2, 3*P*P] (the ViT patch embedding then is one GEMM)."""
     import ctypes
     from . import _lib
     from .ops import ptr, stream_ptr
@@ -127,14 +128,15 @@ def gpu_transform_batch(images_u8, size=224):
     x = images_u8.contiguous()
     B, H, W, _ = x.shape
     plan = _gpu_transform_plan(H, W, size, x.device.index or 0)
-    out = torch.empty((B, 3, size, size), dtype=torch.float32, device=x.device)
+    out = torch.empty((B, 3, size, size) if not patch else (B, (size // patch) ** 2, 3 * patch * patch),
+                      dtype=torch.float32, device=x.device)
     mean = (ctypes.c_float * 3)(*[float(np.float32(v)) for v in ds.CLIP_MEAN])
     std = (ctypes.c_float * 3)(*[float(np.float32(v)) for v in ds.CLIP_STD])
     lib = _lib.load()
     with torch.cuda.device(x.device):
         _lib.check(lib.lemon_preprocess_u8(ptr(x), B, H, W, ptr(plan["kk_h"]), ptr(plan["b_h"]), plan["ks_h"],
                                            ptr(plan["kk_v"]), ptr(plan["b_v"]), plan["ks_v"], size, plan["max_rows"],
-                                           plan["rows_per_block"], mean, std, ptr(out), stream_ptr(x.device)),
+                                           plan["rows_per_block"], mean, std, int(patch), ptr(out), stream_ptr(x.device)),
                    "lemon_preprocess_u8")
     return out
 

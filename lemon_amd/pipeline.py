@@ -62,7 +62,7 @@ class Embedder:
         for i in range(0, pixel_values.shape[0], self.batch_size):
             px = pixel_values[i:i + self.batch_size].to(self.device, non_blocking=True)
             if raw:
-                px = gpu_transform_batch(px, self.model.cfg.image_size)
+                px = gpu_transform_batch(px, self.model.cfg.image_size, patch=self.model.cfg.patch_size)
             outs.append(self.model.encode_image(px).float())
         e = torch.cat(outs) if outs else torch.empty((0, self.model.cfg.embed_dim), device=self.device)
         return ops.normalize_vectors(e) if e.shape[0] else e                          # :164 / :233

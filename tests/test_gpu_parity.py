@@ -365,6 +365,10 @@ def test_gpu_preprocess_bit_identical_to_pil_pipeline(hip, h, w):
     got = gpu_transform_batch(torch.from_numpy(imgs).cuda(), 224).cpu()
     assert got.shape == ref.shape == (3, 3, 224, 224)
     assert torch.equal(got, ref), (got - ref).abs().max()
+    # patch-major variant: same values where the patch-embedding GEMM expects them
+    pm = gpu_transform_batch(torch.from_numpy(imgs).cuda(), 224, patch=32).cpu()
+    expect = ref.view(3, 3, 7, 32, 7, 32).permute(0, 2, 4, 1, 3, 5).reshape(3, 49, 3 * 32 * 32)
+    assert torch.equal(pm, expect)
 
 
 @pytest.mark.gpu
@@ -423,6 +427,21 @@ def test_encoder_vit_b32_block_fused_attention_vs_sdpa(hip):
         ref = blk(x, causal=False)                       # CPU: SDPA branch
         got = blk.cuda()(x.cuda(), causal=False).cpu()   # GPU, no grad: fused branch
     assert (got - ref).abs().max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_patch_major_preprocess_feeds_patch_embedding_gemm(hip):
+    # raw uint8 -> lemon_preprocess_u8(patch=P) -> GEMM patch embedding  ==  PIL transform -> Conv2d patch embedding
+    from PIL import Image
+    from lemon_amd.clip import ClipConfig, LemonCLIP
+    from lemon_amd.data import generic_transform, gpu_transform_batch
+    cfg = ClipConfig.named("tiny")                                   # 32x32 images, 8x8 patches
+    m = LemonCLIP(cfg).eval().cuda()
+    imgs = np.random.default_rng(5).integers(0, 256, (6, 40, 56, 3), dtype=np.uint8)
+    px = torch.stack([generic_transform(Image.fromarray(im), cfg.image_size) for im in imgs]).cuda()
+    patches = gpu_transform_batch(torch.from_numpy(imgs).cuda(), cfg.image_size, patch=cfg.patch_size)
+    a, b = m.encode_image(px), m.encode_image(patches)
+    assert a.shape == b.shape and (a - b).abs().max() < 1e-4
 
 
 def test_fused_split_scoring_equals_per_split_calls(hip, oracle):

@@ -19,7 +19,9 @@ for spec in (sys.argv[1:] or ["vit-b-32:1000"]):
     prompts = (["A photo of a " + l for l in ds.cifar100_labels] * (bs // 100 + 1))[:bs]
     prompts = prompts * 4                                   # text micro-batch = 4 x image micro-batch (pipeline.Embedder)
     ids = torch.tensor(tok(prompts, padding="max_length", truncation=True)["input_ids"]).to(dev)
-    px = torch.randn(bs, 3, cfg.image_size, cfg.image_size, device=dev)
+    from lemon_amd.data import gpu_transform_batch
+    u8 = torch.randint(0, 256, (bs, 32, 32, 3), dtype=torch.uint8, device=dev)
+    px = gpu_transform_batch(u8, cfg.image_size, patch=cfg.patch_size)      # patch-major: the patch embedding is a GEMM
     t0 = time.perf_counter()
     with torch.no_grad():
         model.encode_image(px); model.encode_text(ids); model.encode_text(ids[:bs])
