@@ -90,7 +90,11 @@ class Block(nn.Module):
         self.fc1 = nn.Linear(cfg.width, cfg.mlp)
         self.fc2 = nn.Linear(cfg.mlp, cfg.width)
 
-    def forward(self, x, causal):
+    def forward(self, x, causal, rows=None):
+        """x [B,L,W] -> [B,L,W]; with rows = (batch_index, token_index) the block's output for those tokens
+        only, [len(rows), W].  The towers read ONE token of the last block (CLS / EOT pooling): attention
+        still sees every token's keys and values, but the output projection and the MLP -- 3/4 of the block's
+        FLOPs, all row-wise -- are then evaluated for the pooled rows only.  Same function of the input."""
         B, L, W = x.shape
         fused = x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
         if fused:
@@ -102,12 +106,16 @@ class Block(nn.Module):
                 a = ops.attention(qkv, self.heads, causal)
             else:
                 a = self._sdpa(qkv, B, L, W, causal)
+            if rows is not None:
+                a, x = a[rows].contiguous(), x[rows].contiguous()
             x = ops.linear(a, self.out.weight, self.out.bias, residual=x)
             # QuickGELU(z) = silu(1.702 z) / 1.702: scale going in (alpha, bias), un-scale in fc2's alpha
             s = ops.QUICK_GELU_SCALE
             h = ops.linear(self.ln2(x), self.fc1.weight, self.fc1.bias * s, act="silu", alpha=s)
             return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=x, alpha=1.0 / s)
         a = self._sdpa(self.qkv(self.ln1(x)), B, L, W, causal)
+        if rows is not None:
+            a, x = a[rows], x[rows]
         x = x + self.out(a)
         h = self.fc1(self.ln2(x))
         h = h * torch.sigmoid(1.702 * h)          # QuickGELU
@@ -141,9 +149,11 @@ class VisionTower(nn.Module):
             x = self.patch(pixel_values.to(self.patch.weight.dtype)).flatten(2).transpose(1, 2)
         x = torch.cat([self.cls.expand(x.shape[0], 1, -1), x], dim=1) + self.pos
         x = self.pre_ln(x)
-        for b in self.blocks:
+        for b in self.blocks[:-1]:
             x = b(x, causal=False)
-        return self.proj(self.post_ln(x[:, 0]))
+        batch = torch.arange(x.shape[0], device=x.device)
+        x = self.blocks[-1](x, causal=False, rows=(batch, torch.zeros_like(batch)))   # CLS rows of the last block
+        return self.proj(self.post_ln(x))
 
 
 class TextTower(nn.Module):
@@ -164,10 +174,10 @@ class TextTower(nn.Module):
         L = int(eot.max().item()) + 1
         ids = input_ids[:, :L]
         x = self.tok(ids) + self.pos[:L]
-        for b in self.blocks:
+        for b in self.blocks[:-1]:
             x = b(x, causal=True)
-        x = self.final_ln(x)
-        return self.proj(x[torch.arange(x.shape[0], device=x.device), eot])
+        x = self.blocks[-1](x, causal=True, rows=(torch.arange(x.shape[0], device=x.device), eot))   # EOT rows only
+        return self.proj(self.final_ln(x))
 
 
 class LemonCLIP(nn.Module):
@@ -313,10 +323,12 @@ def algorithm_class_from_scratch(name, text_base_name="openai/clip-vit-base-patc
 
 
 def encoder_flops(cfg: ClipConfig, n_tokens_text=None):
-    """Algorithmic forward FLOPs per (image, caption) pair: 2*m*n*k per GEMM + attention."""
+    """Forward FLOPs per (image, caption) pair as executed: 2*m*n*k per GEMM + attention; the last block's
+    output projection and MLP run for the pooled token only (Block.forward(rows=...))."""
     def tower(t: TowerConfig, L):
-        per_layer = 2 * L * (4 * t.width * t.width + 2 * t.width * t.mlp) + 4 * L * L * t.width
-        return t.layers * per_layer
+        attn = 2 * L * 3 * t.width * t.width + 4 * L * L * t.width            # QKV projection + attention
+        rowwise = 2 * (t.width * t.width + 2 * t.width * t.mlp)                # out-proj + MLP, per token
+        return t.layers * attn + ((t.layers - 1) * L + 1) * rowwise
     Lv = (cfg.image_size // cfg.patch_size) ** 2 + 1
     Lt = n_tokens_text or cfg.context_length
     img = tower(cfg.vision, Lv) + 2 * (Lv - 1) * 3 * cfg.patch_size ** 2 * cfg.vision.width + 2 * cfg.vision.width * cfg.embed_dim
