@@ -134,7 +134,12 @@ def make_cifar_like(args, cfg, rank, dev):
         flip = rng.random(n) < 0.4
         noisy = np.where(flip, (clean + 1) % 100, clean)          # pair-flip ("asymmetric") noise
         if args.input == "u8":       # raw CIFAR-shaped images: generic_transform runs inside the timed step (on the GPU)
-            px = torch.randint(0, 256, (n, 32, 32, 3), dtype=torch.uint8, device=dev, generator=g)
+            # planted structure: a fixed random pattern per CLEAN class + per-image noise, so that even a
+            # random-init encoder puts same-class images near each other and the AUROC check is informative
+            pat = torch.randint(0, 256, (100, 32, 32, 3), dtype=torch.int16, device=dev,
+                                generator=torch.Generator(device=dev).manual_seed(7))
+            noise = torch.randint(-96, 97, (n, 32, 32, 3), dtype=torch.int16, device=dev, generator=g)
+            px = (pat[torch.from_numpy(clean).to(dev)] + noise).clamp_(0, 255).to(torch.uint8)
         else:
             px = torch.empty((n, 3, cfg.image_size, cfg.image_size), dtype=torch.float32, device=dev)
             for i in range(0, n, 2000):                           # chunked: keeps the RNG workspace small
