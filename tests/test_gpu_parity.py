@@ -261,6 +261,50 @@ def test_bf16_filter_equals_f32_scan_at_cifar_scale(hip):
     assert torch.equal(out[0][0], out[1][0])
 
 
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+def test_headline_size_fp32_scan_independent_of_work_decomposition(hip, oracle, metric):
+    # BASELINE configs[1] shape (50 000 queries x 40 000 x 512, k+1 = 51): the balanced decomposition cuts the
+    # panels x tiles space differently for 50 000 queries (510 workgroups, pieces merged per panel) than for a
+    # 1 000-query subset; both must agree bit for bit, and the subset agrees with the oracle
+    rng = np.random.default_rng(77)
+    X, Q = unit_rows(rng, 40000, 512), unit_rows(rng, 50000, 512)
+    Xg, Qg = torch.from_numpy(X).cuda(), torch.from_numpy(Q).cuda()
+    idx = hip.IndexFlatIP(512) if metric == "ip" else hip.IndexFlatL2(512)
+    idx.set_algo(1)
+    idx.add(Xg)
+    D, I = idx.search(Qg, 51)
+    sub = torch.arange(0, 50000, 50, device="cuda")
+    Ds, Is = idx.search(Qg[sub].contiguous(), 51)
+    assert torch.equal(I[sub], Is) and torch.equal(D[sub], Ds)
+    Dr, Ir = oracle.knn(metric, X, Q[::50][:200], 51)
+    assert np.array_equal(Is[:200].cpu().numpy(), Ir) and np.array_equal(Ds[:200].cpu().numpy().view(np.uint32), Dr.view(np.uint32))
+
+
+def test_full_size_1m_self_join_bf16_rows_equal_f32_scan(hip):
+    # BASELINE configs[3] at full size (1 000 000 x 768, k+1 = 51): the bf16 filter scan over ALL queries
+    # (chunked database, state carried between launches) must reproduce, bit for bit, what the exact fp32
+    # scan returns for a strided subset of the queries -- the size-independent property that ties the
+    # full-size run to the oracle-checked small cases
+    n, d, k = 1_000_000, 768, 51
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.empty((n, d), device="cuda")
+    for i in range(0, n, 100_000):
+        x[i:i + 100_000].normal_(generator=g)
+    x = hip.normalize_vectors(x)
+    idx = hip.IndexFlatIP(d)
+    idx.set_algo(2)
+    idx.add(x)
+    D, I = idx.search(x, k)
+    assert idx.last_search_info()["algo"] == 2
+    sub = torch.arange(0, n, 123, device="cuda")[:8192]
+    assert torch.equal(I[sub, 0], sub)                         # self is its own nearest neighbour
+    ref = hip.IndexFlatIP(d)
+    ref.set_algo(1)
+    ref.add(x)
+    Dr, Ir = ref.search(x[sub].contiguous(), k)
+    assert torch.equal(I[sub], Ir) and torch.equal(D[sub], Dr)
+
+
 def test_neighbors_record_bf16_algo(hip, oracle):
     s = planted(seed=1, n_tr=3000, n_q=300, d=64, C=16)
     img_tr, txt_tr, _, noisy_tr = s["train"]
