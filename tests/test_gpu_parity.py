@@ -183,6 +183,24 @@ def test_neighbors_record_bit_exact(hip, oracle, metric, drop_self, discrete):
     assert np.allclose(sc, sref, rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("metric", ["cosine", "euclidean"])
+@pytest.mark.parametrize("n_tr,n_q,k,drop_self", [(3, 4, 5, False), (4, 4, 5, True), (1, 3, 1, False), (70, 9, 63, True), (64, 5, 64, False)])
+def test_neighbors_record_padding_and_extreme_k(hip, oracle, metric, n_tr, n_q, k, drop_self):
+    # k (+1 on the train split) larger than the DB: -1 / +-FLT_MAX / NaN padding exactly as the oracle; k at
+    # the LEMON_MAX_K limit; single-row DB
+    rng = np.random.default_rng(n_tr * 100 + k)
+    img_tr, txt_tr = unit_rows(rng, n_tr, 24), unit_rows(rng, n_tr, 24)
+    if drop_self:
+        q_img, q_txt = img_tr[:n_q].copy(), txt_tr[:n_q].copy()
+    else:
+        q_img, q_txt = unit_rows(rng, n_q, 24), unit_rows(rng, n_q, 24)
+    db = hip.LemonDB(cu(img_tr), cu(txt_tr), metric)
+    rec = db.neighbors(cu(q_img), cu(q_txt), k, drop_self=drop_self)
+    ref = oracle.neighbors(metric, img_tr, txt_tr, q_img, q_txt, k, drop_self=drop_self)
+    for key in ("d_1", "D_n", "dists_n", "dists_tr_n", "D_m", "dists_m", "dists_tr_m", "I_n", "I_m"):
+        assert np.array_equal(rec[key].cpu().numpy(), ref[key], equal_nan=True), key
+
+
 def test_d1_normalized(hip, oracle):
     s = planted(seed=4, n_tr=10, n_q=300, d=64, C=100)
     q_img, _, _, noisy = s["query"]
