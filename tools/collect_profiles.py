@@ -36,5 +36,5 @@ for d, dst in ((f"prof_bench_{tag}", "bench_default_kernel_stats.csv"), (f"prof_
     f = one(f"{d}/**/*kernel_stats.csv")
     if f:
         shutil.copyfile(f, os.path.join(P, dst)); print(dst)
-write_pmc("bench_default_pmc.csv", [f"pmc_bench_fetch_{tag}", f"pmc_bench_write_{tag}"])
+write_pmc("bench_default_pmc.csv", [f"pmc_bench_fetch_{tag}", f"pmc_bench_write_{tag}", f"pmc_bench_mfma_{tag}"])
 write_pmc("knn_262144x768_pmc.csv", [f"pmc_fetch_{tag}", f"pmc_write_{tag}"])

@@ -14,5 +14,6 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$TAG -- python3
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -- python3 $R/bench.py --workload knn --knn_n 262144 --steps 1 --warmup 0 > $OUT/pmc_write_$TAG.json 2> $OUT/pmc_write_$TAG.err || exit 5
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_scan|k_neighbors|k_merge" --output-format csv -d $OUT/pmc_bench_fetch_$TAG -- python3 $R/bench.py --steps 1 --warmup 0 --no_cpu_baseline > /dev/null 2> $OUT/pmc_bench_fetch_$TAG.err || exit 6
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_scan|k_neighbors|k_merge" --output-format csv -d $OUT/pmc_bench_write_$TAG -- python3 $R/bench.py --steps 1 --warmup 0 --no_cpu_baseline > /dev/null 2> $OUT/pmc_bench_write_$TAG.err || exit 7
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "k_scan|k_neighbors|k_merge" --output-format csv -d $OUT/pmc_bench_mfma_$TAG -- python3 $R/bench.py --steps 1 --warmup 0 --no_cpu_baseline > /dev/null 2> $OUT/pmc_bench_mfma_$TAG.err || exit 8
 find $OUT -name "*_kernel_trace.csv" -size +20M -delete
 ls -la $OUT/prof_bench_$TAG/*/ | head -20
