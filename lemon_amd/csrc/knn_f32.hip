@@ -214,12 +214,21 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
             PH_STAMP(ph0);
             __builtin_amdgcn_s_setprio(3);
             const int64_t jb = (int64_t)(t_begin + jl) * BX + 4 * h;
+            const int ccnt_in = ccnt;
+            if (PROF && (p.ablate & 16)) {           // diagnostic: bit 4 = time the bare accumulator read-out (64-value max)
+                float mx = acc0[0];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mx = fmaxf(fmaxf(mx, acc0[e]), fmaxf(fmaxf(acc1[e], acc2[e]), acc3[e]));
+                if (mx == 123.456f) ph3 += 1;       // keep it alive
+                PH_STAMP(ph3);                       // reported in the 'final' column
+            }
             if (!(PROF && (p.ablate & 4) && jl > 4)) {     // diagnostic: bit 2 = skip the filter after 5 tiles
             f32_filter_tile<L2>(acc0, th, jb, my_qn, p.xnorm, p.n, ccnt, mylist);
             f32_filter_tile<L2>(acc1, th, jb + 32, my_qn, p.xnorm, p.n, ccnt, mylist);
             f32_filter_tile<L2>(acc2, th, jb + 64, my_qn, p.xnorm, p.n, ccnt, mylist);
             f32_filter_tile<L2>(acc3, th, jb + 96, my_qn, p.xnorm, p.n, ccnt, mylist);
             }
+            if (PROF && (p.ablate & 8) && jl > 4) ccnt = ccnt_in;   // diagnostic: bit 3 = appends land but are forgotten
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc0[e] = 0.0f; acc1[e] = 0.0f; acc2[e] = 0.0f; acc3[e] = 0.0f; }
             ++jl;
