@@ -70,9 +70,6 @@ def parse():
                     help="u8: raw 32x32 uint8 images resident in HBM, preprocessing (bicubic resize to 224, normalise) "
                          "inside the timed step; f32: already preprocessed pixel tensors")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--tunableop", action="store_true",
-                    help="also turn on PyTorch TunableOp for the few GEMMs still issued by torch (the towers' Linear "
-                         "layers go through lemon_linear_f32, which selects hipBLASLt solutions itself)")
     ap.add_argument("--cpu_sample_images", type=int, default=96)
     ap.add_argument("--cpu_sample_queries", type=int, default=2048)
     return ap.parse_args()
@@ -155,9 +152,6 @@ def bench_cifar(args, world, rank, dev):
     from lemon_amd.clip import ClipConfig, LemonCLIP, encoder_flops
     from lemon_amd.pipeline import Embedder, FIXED_HPARAMS, run_hot_path
 
-    if args.tunableop:
-        from lemon_amd.tuning import enable_gemm_tuning
-        enable_gemm_tuning()
     cfg = ClipConfig.named(args.arch)
     model = LemonCLIP(cfg)                       # seeded random init (no checkpoints offline)
     emb = Embedder(model, dev, batch_size=args.encoder_batch, text_dedup=args.text_dedup)

@@ -16,7 +16,9 @@
  *   - return value: 0 = ok, <0 = error (LEMON_E_*); lemon_last_error() returns a
  *     thread-local description of the last failure;
  *   - caller owns every output buffer; the library owns only what is inside a
- *     lemon_index handle; no hidden global state; one handle per thread.
+ *     lemon_index handle; one handle per thread.  The ONLY process-wide state is
+ *     lemon_linear_f32's hipBLASLt handle + workspace + solution cache (one set per
+ *     device, mutex-guarded; see its comment) and the thread-local error string.
  *   - numeric contract ("chain" numerics): dot(a,b) is the float32 fmaf chain in
  *     ascending k starting from +0 (bit-for-bit what v_mfma_f32_32x32x2_f32
  *     accumulates); ties in every top-k are broken towards the lower index.
@@ -76,11 +78,6 @@ int lemon_d1_normalized(int metric, const float *q_img_dev, int64_t n, int d,
                         const float *cls_txt_dev, int C, const int32_t *noisy_label_dev,
                         float *d1_dev, void *stream);
 
-/* QuickGELU x*sigmoid(1.702x), in place, float32 (lib/models/chexzero_clip.py:186-188; HF CLIP's
- * "quick_gelu"): the activation of encode_image / encode_text's MLP blocks, fused to one pass.
- * x_dev must be 16-byte aligned. */
-int lemon_quick_gelu(float *x_dev, int64_t n, void *stream);
-
 /* generic_transform (lib/datasets/utils.py:159-170: Resize(224, BICUBIC) -> CenterCrop(224) -> ToTensor ->
  * Normalize) for a batch of equally sized uint8 HWC images, bit-identical to PIL + torch: the two integer
  * resampling passes of PIL (22-bit fixed-point taps, horizontal then vertical, clip8) and (v/255-mean)/std.
@@ -113,17 +110,27 @@ int lemon_attention_f32(const float *qkv_dev, int64_t batch, int seq_len, int he
  * (u*sigmoid(u)) and the residual add ride in its epilogue.  QuickGELU z*sigmoid(1.702z)
  * (chexzero_clip.py:186-188) is silu(1.702 z)/1.702: call with alpha = 1.702 and a bias scaled by 1.702,
  * and give the consuming GEMM alpha = 1/1.702 (lemon_amd/clip.py does).  bias_dev / residual_dev may
- * be NULL; residual_dev may alias y_dev; activation and residual cannot be combined.  The first call
- * for a new (m,n,k,epilogue) benchmarks the library's solutions on the caller's stream (synchronises;
- * bounded by LEMON_LINEAR_TUNE_MS, default 6000) unless lemon_linear_load_tuned() supplied the key. */
+ * be NULL; residual_dev may alias y_dev; activation and residual cannot be combined.
+ * Solution choice per (m,n,k,epilogue,residual) key -- reproducible by default: a key supplied by
+ * lemon_linear_load_tuned() uses the recorded hipBLASLt solution index (checked once per process, on first
+ * use and on the caller's operands, against the library's first-ranked solution: one extra GEMM, one stream
+ * synchronisation; dropped if it disagrees); every other key uses the library's first-ranked supported
+ * solution (no timing, no allocation, no synchronisation; identical in every process).  Only after
+ * lemon_linear_set_tuning(1) (or LEMON_LINEAR_TUNE=1) is an unknown key benchmarked over all solutions
+ * (synchronises; bounded by LEMON_LINEAR_TUNE_MS, default 6000): that is the offline tuner's mode
+ * (tools/tune_gemms.py), never the inference path's. */
 #define LEMON_ACT_NONE 0
 #define LEMON_ACT_SILU 1
 int lemon_linear_f32(const float *x_dev, const float *w_dev, const float *bias_dev, const float *residual_dev,
                      int64_t m, int n, int k, float alpha, int act, float *y_dev, void *stream);
-/* Recorded solution choices ("m,n,k,epilogue,residual,index,usec" lines): load returns the number of
- * keys read, dump the number written (<0 on error). */
+/* Recorded solution choices: a "# lemon_linear hipblaslt=<version> arch=<gfx name>" stamp line followed by
+ * "m,n,k,epilogue,residual,index,usec" lines.  load returns the number of keys taken -- 0 when the stamp
+ * does not match this process's hipBLASLt version / device arch (the file is then ignored) -- and dump the
+ * number written (<0 on error).  lemon_linear_stamp reports the stamp of the current device. */
 int lemon_linear_load_tuned(const char *path);
 int lemon_linear_dump_tuned(const char *path);
+int lemon_linear_set_tuning(int enabled);
+int lemon_linear_stamp(int *hipblaslt_version, char *arch, int arch_len);
 
 /* ---- flat index (faiss.IndexFlatIP / IndexFlatL2 as used by run_lemon.py) ---------- */
 

@@ -1,16 +1,22 @@
 """Builds liblemon_hip.so (the C-ABI HIP library) in-tree for gfx950.
 
-hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container.
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container.  Each
+translation unit is compiled to an object under lemon_amd/csrc/_obj/ (only when it or a header
+changed, several at a time) and the objects are linked into the shared library.
 """
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 SO = os.path.join(HERE, "liblemon_hip.so")
-SOURCES = ["api.hip", "rowwise.hip", "knn_f32.hip", "knn_bf16.hip", "attention.hip", "linear.hip", "preprocess.hip", "gridf1.hip"]
-HEADERS = ["common.hpp", os.path.join("..", "..", "include", "lemon_hip.h")]
+SOURCES = ["api.hip", "rowwise.hip", "knn_f32.hip", "knn_bf16.hip", "attention.hip", "linear.hip", "preprocess.hip",
+           "gridf1.hip", "encoder.hip"]
+HEADERS = ["common.hpp", "knn_common.hpp", os.path.join("..", "..", "include", "lemon_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
 def _hipcc():
@@ -20,24 +26,47 @@ def _hipcc():
     raise RuntimeError("hipcc not found: liblemon_hip.so cannot be built")
 
 
-def needs_build():
-    if not os.path.exists(SO):
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build_hip(force=False, verbose=False):
+def needs_build():
+    deps = [os.path.join(CSRC, s) for s in _sources() + HEADERS]
+    return _stale(SO, deps)
+
+
+def build_hip(force=False, verbose=False, jobs=None):
     if not force and not needs_build():
         return SO
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result", "-o", SO] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lhipblaslt"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    hipcc = _hipcc()
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    todo, objs = [], []
+    for s in _sources():
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            todo.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=jobs or min(4, len(todo))) as pool:
+            list(pool.map(run, todo))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-lhipblaslt"])
     return SO
 
 
 if __name__ == "__main__":
-    print(build_hip(force=True, verbose=True))
+    import sys
+    print(build_hip(force="--force" in sys.argv, verbose=True))

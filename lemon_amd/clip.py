@@ -60,6 +60,11 @@ class ClipConfig:
         if name in ("vit-l-14", "vit-large-patch14", "l14"):
             return ClipConfig(embed_dim=768, patch_size=14, vision=TowerConfig(1024, 24, 16, 4096),
                               text=TowerConfig(768, 12, 12, 3072))
+        if name in ("chexzero-scratch-256", "mimic-clip-from-scratch", "scratch-b16-256"):
+            # lib/models/chexzero_clip.py:458-470 load_clip(): ViT-B/16 vision, 512-wide text, 768-d, context 256
+            return ClipConfig(embed_dim=768, patch_size=16, context_length=256)
+        if name in ("chexzero-scratch-77", "cc3m-clip-from-scratch", "scratch-b16-77"):
+            return ClipConfig(embed_dim=768, patch_size=16, context_length=77)          # load_clip(context_length=77)
         if name in ("tiny", "test"):
             return ClipConfig(embed_dim=32, image_size=32, patch_size=8, vision=TowerConfig(48, 2, 4, 96),
                               text=TowerConfig(40, 2, 4, 80), vocab_size=300, context_length=16, eos_token_id=299)
@@ -77,6 +82,24 @@ class ClipConfig:
                              t.get("num_attention_heads", 8), t.get("intermediate_size", 2048)),
             vocab_size=t.get("vocab_size", 49408), context_length=t.get("max_position_embeddings", 77),
             eos_token_id=t.get("eos_token_id", 49407), layer_norm_eps=v.get("layer_norm_eps", 1e-5))
+
+    @staticmethod
+    def from_openai_state_dict(sd):
+        """Architecture of an OpenAI-format CLIP state dict, read off the tensor shapes the way
+        lib/models/chexzero_clip.py:411-441 (build_model) does.  ViT visual towers only."""
+        if "visual.proj" not in sd:
+            raise NotImplementedError("ResNet visual towers (ModifiedResNet, chexzero_clip.py:94-174) are not on LEMoN's path")
+        vw = sd["visual.conv1.weight"].shape[0]
+        patch = sd["visual.conv1.weight"].shape[-1]
+        grid = round((sd["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+        vl = len([k for k in sd if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+        tw = sd["ln_final.weight"].shape[0]
+        tl = len({k.split(".")[2] for k in sd if k.startswith("transformer.resblocks")})
+        vocab = sd["token_embedding.weight"].shape[0]
+        return ClipConfig(embed_dim=sd["text_projection"].shape[1], image_size=patch * grid, patch_size=patch,
+                          vision=TowerConfig(vw, vl, vw // 64, sd["visual.transformer.resblocks.0.mlp.c_fc.weight"].shape[0]),
+                          text=TowerConfig(tw, tl, tw // 64, sd["transformer.resblocks.0.mlp.c_fc.weight"].shape[0]),
+                          vocab_size=vocab, context_length=sd["positional_embedding"].shape[0], eos_token_id=vocab - 1)
 
 
 class Block(nn.Module):
@@ -167,11 +190,19 @@ class TextTower(nn.Module):
         self.final_ln = nn.LayerNorm(t.width, eps=cfg.layer_norm_eps)
         self.proj = nn.Linear(t.width, cfg.embed_dim, bias=False)
 
-    def forward(self, input_ids):
+    def seq_len_for(self, eot_max):
+        """Token count the tower runs for a batch whose last EOT sits at `eot_max`: the longest prompt rounded up
+        to a multiple of 8 (capped at the context length).  Truncation is exact under the causal mask; the
+        bucket keeps the GEMM row count m = B*L to a handful of values, so caption batches do not meet a new
+        (m,n,k) solution key -- and a new summation order -- for every prompt length."""
+        return min(self.pos.shape[0], (int(eot_max) + 8) // 8 * 8)
+
+    def forward(self, input_ids, seq_len=None):
         # EOT position = argmax of the ids (EOT has the largest id: chexzero_clip.py:374-376 and HF's
-        # legacy eos path); truncate the batch to the longest prompt (exact under the causal mask)
+        # legacy eos path); truncate the batch to the longest prompt (exact under the causal mask).
+        # seq_len: precomputed on the host by the caller (pipeline.Embedder) to avoid a device sync here.
         eot = input_ids.argmax(dim=-1)
-        L = int(eot.max().item()) + 1
+        L = self.seq_len_for(eot.max().item()) if seq_len is None else int(seq_len)
         ids = input_ids[:, :L]
         x = self.tok(ids) + self.pos[:L]
         for b in self.blocks[:-1]:
@@ -189,6 +220,7 @@ class LemonCLIP(nn.Module):
         self.cfg = cfg or ClipConfig()
         self.vision = VisionTower(self.cfg)
         self.text = TextTower(self.cfg)
+        self.logit_scale = math.log(1 / 0.07)          # CLIP's temperature parameter (log scale), chexzero_clip.py:319
         self.reset_parameters()
 
     def reset_parameters(self, seed=0):
@@ -210,10 +242,10 @@ class LemonCLIP(nn.Module):
         return self.vision(pixel_values)
 
     @torch.no_grad()
-    def encode_text(self, input_ids=None, attention_mask=None):
+    def encode_text(self, input_ids=None, attention_mask=None, seq_len=None):
         # attention_mask is accepted for signature parity and ignored: EOT-pooled features of a causal
         # transformer do not depend on it (max |delta| = 0.0 measured)
-        return self.text(input_ids)
+        return self.text(input_ids, seq_len=seq_len)
 
     @torch.no_grad()
     def encode_text_dedup(self, input_ids):
@@ -253,6 +285,59 @@ class LemonCLIP(nn.Module):
         own["text.proj.weight"] = sd["text_projection.weight"]
         missing, unexpected = self.load_state_dict(own, strict=True), None
         return self
+
+    # ---------------------------------------------------------------- OpenAI-format checkpoint mapping
+    def load_openai_state_dict(self, sd):
+        """Load a state dict with the names of OpenAI CLIP / the in-tree copy (lib/models/chexzero_clip.py:263-392):
+        what `load_clip(model_path)` (:458-479) and `clip.load(...)` + `load_state_dict` (lib/models/utils.py:94-97)
+        consume.  nn.MultiheadAttention's packed in_proj is already this module's fused QKV layout; the two
+        projections are stored [width, embed_dim] there (x @ proj) and transposed here."""
+        own = {}
+
+        def tower(prefix, blocks, n):
+            for i in range(n):
+                p, b = f"{prefix}transformer.resblocks.{i}.", f"{blocks}.{i}."
+                own[b + "qkv.weight"], own[b + "qkv.bias"] = sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"]
+                for kind in ("weight", "bias"):
+                    own[b + f"out.{kind}"] = sd[p + f"attn.out_proj.{kind}"]
+                    own[b + f"ln1.{kind}"] = sd[p + f"ln_1.{kind}"]
+                    own[b + f"ln2.{kind}"] = sd[p + f"ln_2.{kind}"]
+                    own[b + f"fc1.{kind}"] = sd[p + f"mlp.c_fc.{kind}"]
+                    own[b + f"fc2.{kind}"] = sd[p + f"mlp.c_proj.{kind}"]
+
+        tower("visual.", "vision.blocks", self.cfg.vision.layers)
+        tower("", "text.blocks", self.cfg.text.layers)
+        own["vision.patch.weight"] = sd["visual.conv1.weight"]
+        own["vision.cls"] = sd["visual.class_embedding"]
+        own["vision.pos"] = sd["visual.positional_embedding"]
+        for kind in ("weight", "bias"):
+            own[f"vision.pre_ln.{kind}"] = sd[f"visual.ln_pre.{kind}"]
+            own[f"vision.post_ln.{kind}"] = sd[f"visual.ln_post.{kind}"]
+            own[f"text.final_ln.{kind}"] = sd[f"ln_final.{kind}"]
+        own["vision.proj.weight"] = sd["visual.proj"].t()
+        own["text.tok.weight"] = sd["token_embedding.weight"]
+        own["text.pos"] = sd["positional_embedding"]
+        own["text.proj.weight"] = sd["text_projection"].t()
+        self.load_state_dict({k: v.float() for k, v in own.items()}, strict=True)
+        if "logit_scale" in sd:
+            self.logit_scale = float(sd["logit_scale"])
+        return self
+
+    @classmethod
+    def from_openai_checkpoint(cls, path, cfg=None):
+        """A LOCAL `.pt` holding an OpenAI-format state dict (the files lib/models/utils.py:20-25 points at)."""
+        if not os.path.isfile(path):
+            raise FileNotFoundError(
+                f"CLIP checkpoint {path!r} not found. The reference loads its in-tree CLIP variants from the authors' cluster "
+                "paths (lib/models/utils.py:20-25); pass a local OpenAI-format state dict with --clip_path.")
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd
+        sd = {k: v for k, v in sd.items() if k not in ("input_resolution", "context_length", "vocab_size")}
+        return cls(cfg or ClipConfig.from_openai_state_dict(sd)).load_openai_state_dict(sd)
+
+    @property
+    def context_length(self):
+        return self.cfg.context_length
 
     @classmethod
     def from_pretrained(cls, path):
@@ -300,26 +385,88 @@ class SyntheticTokenizer:
         return {"input_ids": ids, "attention_mask": mask}
 
 
+IN_TREE_CLIP = {   # lib/models/utils.py:82-103: branch -> (architecture of the checkpoint it loads, context length)
+    "mimic_clip_from_scratch_random": "chexzero-scratch-256", "mimic_clip_from_scratch_cat": "chexzero-scratch-256",
+    "cc3m_clip_from_scratch": "chexzero-scratch-77", "chexzero": "vit-b-32",
+}
+
+
+def _bpe_tokenizer(bpe_path):
+    from .tokenizer import ClipBPE, find_bpe_file
+    f = find_bpe_file(bpe_path)
+    return ClipBPE.from_file(f) if f else None
+
+
 def algorithm_class_from_scratch(name, text_base_name="openai/clip-vit-base-patch32", img_base=None,
-                                 return_tokenizer=False, arch=None):
-    """lib/models/utils.py:64-105, 'huggingface_clip' branch.  `text_base_name` is a LOCAL checkpoint
-    directory, or 'random[:arch]' for seeded random weights (synthetic / smoke runs).  The other
-    branches of the reference (biomed_clip, chexzero, *_from_scratch) need weights that only exist on
-    the authors' cluster paths (lib/models/utils.py:20-25) and are refused explicitly."""
-    if name != "huggingface_clip":
+                                 return_tokenizer=False, arch=None, bpe_path=None):
+    """lib/models/utils.py:64-105.  Returns `model` or `(model, tokenizer)` with the reference's two calling
+    conventions:
+      'huggingface_clip'             model.encode_text(input_ids, attention_mask); tokenizer(texts, padding=
+                                     "max_length", truncation=True) -> dict of lists          (:65-71)
+      'mimic_clip_from_scratch_*', 'cc3m_clip_from_scratch', 'chexzero'
+                                     model.encode_text(tokens); tokenizer(texts) -> LongTensor [n, ctx]  (:82-103,
+                                     lib/models/chexzero_clip.py:458-493)
+    `text_base_name` is LOCAL: an HF checkpoint directory (huggingface_clip), an OpenAI-format `.pt` state dict (the
+    in-tree branches; the reference hard-codes the authors' cluster paths, :20-25), or 'random[:arch]' for seeded
+    random weights.  Tokenizer: the HF tokenizer files of the checkpoint directory when present, else a CLIP BPE
+    built from a user-supplied merges file (`bpe_path` / $LEMON_BPE_PATH), else -- random weights only -- the
+    hash-based SyntheticTokenizer.  'biomed_clip' (open_clip BiomedCLIP: a PubMedBERT text tower + WordPiece) is a
+    different model family and is refused."""
+    rand = str(text_base_name).startswith("random")
+    parts = str(text_base_name).split(":")
+    if name == "huggingface_clip":
+        if rand:
+            model = LemonCLIP(ClipConfig.named(arch or (parts[1] if len(parts) > 1 else "vit-b-32")))
+            bpe = _bpe_tokenizer(bpe_path) if model.cfg.vocab_size == 49408 else None
+        else:
+            model = LemonCLIP.from_pretrained(text_base_name)
+            bpe = None
+        if not return_tokenizer:
+            return model
+        cfg = model.cfg
+        if not rand and any(os.path.exists(os.path.join(text_base_name, f)) for f in ("tokenizer.json", "vocab.json")):
+            from transformers import AutoTokenizer
+            tok = AutoTokenizer.from_pretrained(text_base_name, local_files_only=True)
+        else:
+            bpe = bpe or (_bpe_tokenizer(bpe_path or (None if rand else text_base_name)) if cfg.vocab_size == 49408 else None)
+            if bpe is not None:
+                from .tokenizer import HFStyleClipTokenizer
+                tok = HFStyleClipTokenizer(bpe, cfg.context_length)
+            elif rand:
+                tok = SyntheticTokenizer(cfg.vocab_size, cfg.context_length, cfg.eos_token_id)
+            else:
+                raise FileNotFoundError(f"no tokenizer files in {text_base_name!r} and no merges file (--bpe_path / LEMON_BPE_PATH)")
+        return model, tok
+    if name in IN_TREE_CLIP:
+        if rand:
+            model = LemonCLIP(ClipConfig.named(arch or (parts[1] if len(parts) > 1 else IN_TREE_CLIP[name])))
+        else:
+            # mimic/cc3m: load_clip(model_path, context_length) builds the fixed architecture then loads the weights
+            # (:458-479); chexzero: clip.load("ViT-B/32") + load_state_dict (:94-97) -- both = the checkpoint's shapes
+            model = LemonCLIP.from_openai_checkpoint(text_base_name)
+            want = ClipConfig.named(IN_TREE_CLIP[name])
+            if (model.cfg.embed_dim, model.cfg.patch_size, model.cfg.context_length) != (want.embed_dim, want.patch_size, want.context_length):
+                raise ValueError(f"{text_base_name!r} is not a {name} checkpoint: embed_dim/patch/context "
+                                 f"{(model.cfg.embed_dim, model.cfg.patch_size, model.cfg.context_length)} != "
+                                 f"{(want.embed_dim, want.patch_size, want.context_length)}")
+        if not return_tokenizer:
+            return model
+        bpe = _bpe_tokenizer(bpe_path) if model.cfg.vocab_size == 49408 else None
+        if bpe is not None:
+            from .tokenizer import tokenize
+            tok = lambda texts: tokenize(texts, model, bpe)
+        elif rand:
+            syn = SyntheticTokenizer(model.cfg.vocab_size, model.cfg.context_length, model.cfg.eos_token_id)
+            tok = lambda texts: torch.tensor(syn(texts)["input_ids"], dtype=torch.long)
+        else:
+            raise FileNotFoundError("the in-tree CLIP branches tokenise with the CLIP BPE (chexzero_clip.py:481-493): "
+                                    "supply its merges file with --bpe_path or LEMON_BPE_PATH")
+        return model, tok
+    if name == "biomed_clip":
         raise NotImplementedError(
-            f"clip_model={name!r}: only 'huggingface_clip' is available; the other reference branches load "
-            "checkpoints from the authors' cluster paths (lib/models/utils.py:20-25,72-103)")
-    if str(text_base_name).startswith("random"):
-        parts = str(text_base_name).split(":")
-        cfg = ClipConfig.named(arch or (parts[1] if len(parts) > 1 else "vit-b-32"))
-        model = LemonCLIP(cfg)
-        tok = SyntheticTokenizer(cfg.vocab_size, cfg.context_length, cfg.eos_token_id)
-    else:
-        model = LemonCLIP.from_pretrained(text_base_name)
-        from transformers import AutoTokenizer
-        tok = AutoTokenizer.from_pretrained(text_base_name, local_files_only=True)
-    return (model, tok) if return_tokenizer else model
+            "clip_model='biomed_clip' (lib/models/utils.py:72-79) is open_clip's BiomedCLIP: a PubMedBERT text tower with a "
+            "WordPiece tokenizer, loaded from the HF hub -- not a CLIP-architecture checkpoint; not available in this build")
+    raise NotImplementedError(name)
 
 
 def encoder_flops(cfg: ClipConfig, n_tokens_text=None):

@@ -9,9 +9,21 @@
 // silu(1.702 z)/1.702: alpha = 1.702 here with a pre-scaled bias, alpha = 1/1.702 in the GEMM that
 // consumes it) and the residual add as the GEMM's beta*C term -- which removes one read+write pass
 // over the [m,3072] MLP activations and both residual-add passes per block, and (2) explicit solution selection: the
-// library's default heuristic is ~15 % off the best solution for the ViT-B/32 shapes, so every
-// (m,n,k,epilogue) key is benchmarked once over the solutions that support it (bounded by a time
-// budget) and the winner's index is cached, in process and in a results file.
+// library's default heuristic is ~15 % off the best solution for the ViT-B/32 shapes.
+//
+// Solution policy (reproducibility first: a different solution = a different fp32 summation order = different
+// embedding bits):
+//   * a key (m,n,k,epilogue,residual) found in the results file (lemon_amd/data/linear_gfx950.csv, written by the
+//     OFFLINE tuner tools/tune_gemms.py) uses the recorded solution index.  The file is stamped with the hipBLASLt
+//     version and the gfx arch it was made with and is ignored on a mismatch; each recorded index is checked ONCE per
+//     process, on its first use, against the library's first-ranked solution on the caller's own operands
+//     (|delta| <= 1e-3 max|y|) and dropped if it disagrees;
+//   * any other key uses the library's first-ranked supported solution (hipblasLtMatmulAlgoGetHeuristic): no timing,
+//     no allocation, no synchronisation in the inference path, and the same choice in every process;
+//   * the timing race over all solutions runs only when tuning was switched on explicitly
+//     (lemon_linear_set_tuning(1) or LEMON_LINEAR_TUNE=1).
+// The hipBLASLt handle, its workspace and the solution cache are the library's only process-wide state (one set per
+// device, guarded by a mutex).
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt.h>
 #include <hipblaslt/hipblaslt-ext.hpp>
@@ -44,16 +56,23 @@ namespace {
 typedef std::tuple<int64_t, int, int, int, int> LinKey;   // m, n, k, epilogue, has_residual
 
 struct LinState {
-    std::mutex mu;
     hipblasLtHandle_t handle = nullptr;
     void *ws = nullptr;
     size_t ws_bytes = 0;
-    std::map<LinKey, hipblasLtMatmulAlgo_t> algo;     // validated for the key in this process
-    std::map<LinKey, int> index;                      // solution index (from file or tuning)
+    std::map<LinKey, hipblasLtMatmulAlgo_t> algo;     // the solution in use for the key in this process
+    std::map<LinKey, int> index;                      // solution index (results file or tuner)
     std::map<LinKey, float> usec;
+    std::map<LinKey, bool> from_file;                 // recorded index not yet checked against the first-ranked solution
     double tune_budget_ms = 6000.0;
+    int version = 0;                                  // hipblasLtGetVersion
+    char arch[64] = {0};                              // gcnArchName up to the first ':'
 };
-LinState g_lin;
+constexpr int LEMON_MAX_DEVICES = 16;
+std::mutex g_mu;
+LinState g_states[LEMON_MAX_DEVICES];
+int g_tuning = -1;                                    // -1: read LEMON_LINEAR_TUNE on first use
+#define g_lin (*g_cur)
+thread_local LinState *g_cur = nullptr;               // state of the calling thread's current device (set under g_mu)
 
 // validation of a candidate's output against the library's first-ranked solution: a solution that is
 // merely fast but wrong for an odd shape must never be recorded
@@ -101,9 +120,24 @@ int make_problem(Problem &p, int64_t m, int n, int k, int epilogue, const float 
 }
 
 int ensure_state(hipStream_t stream) {
+    int dev = 0;
+    LEMON_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= LEMON_MAX_DEVICES) { lemon_set_error("device ordinal %d out of range", dev); return LEMON_E_INVALID; }
+    g_cur = &g_states[dev];
+    if (g_tuning < 0) {
+        const char *e = getenv("LEMON_LINEAR_TUNE");
+        g_tuning = (e && *e && strcmp(e, "0") != 0) ? 1 : 0;
+    }
     if (!g_lin.handle) {
         LT_CHECK(hipblasLtCreate(&g_lin.handle));
         if (const char *e = getenv("LEMON_LINEAR_TUNE_MS")) g_lin.tune_budget_ms = atof(e);
+        (void)hipblasLtGetVersion(g_lin.handle, &g_lin.version);
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+            size_t i = 0;
+            for (; i + 1 < sizeof g_lin.arch && prop.gcnArchName[i] && prop.gcnArchName[i] != ':'; ++i) g_lin.arch[i] = prop.gcnArchName[i];
+            g_lin.arch[i] = 0;
+        }
     }
     if (!g_lin.ws) {
         g_lin.ws_bytes = (size_t)64 << 20;
@@ -173,13 +207,9 @@ int tune(const LinKey &key, Problem &p, const float *x, const float *w, const fl
                                        all) == HIPBLAS_STATUS_SUCCESS)
             cand.insert(cand.end(), all.begin(), all.end());
     }
-    // LEMON_LINEAR_DETERMINISTIC=1: no timing race -- the library's first-ranked supported solution, so
-    // that two processes produce bit-identical activations for shapes that are not in the results file
-    static const bool deterministic = getenv("LEMON_LINEAR_DETERMINISTIC") != nullptr;
     std::vector<std::pair<float, size_t>> timed;        // (usec, candidate)
     for (size_t i = 0; i < cand.size(); ++i) {
         if (!supported(p, cand[i].algo, beta)) continue;
-        if (deterministic) { timed.push_back({1.0f, i}); break; }
         const float us = time_algo(p, cand[i].algo, x, w, c, beta, scratch, 1, stream, e0, e1);
         if (us > 0.f) timed.push_back({us, i});
         if (i >= n_heur) {                               // budget applies to the exhaustive part only
@@ -251,7 +281,67 @@ int tune(const LinKey &key, Problem &p, const float *x, const float *w, const fl
     return rc;
 }
 
+// the library's own first choice among the solutions that support the problem (deterministic, no timing)
+int first_ranked(Problem &p, float beta, hipblasLtMatmulAlgo_t *out) {
+    hipblasLtMatmulPreference_t pref = nullptr;
+    LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
+    (void)hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &g_lin.ws_bytes,
+                                                sizeof(g_lin.ws_bytes));
+    hipblasLtMatmulHeuristicResult_t top[8];
+    int got = 0;
+    const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_lin.handle, p.desc, p.la, p.lb, p.lc, p.lc, pref, 8, top, &got);
+    (void)hipblasLtMatmulPreferenceDestroy(pref);
+    if (st == HIPBLAS_STATUS_SUCCESS)
+        for (int i = 0; i < got; ++i)
+            if (supported(p, top[i].algo, beta)) { *out = top[i].algo; return LEMON_OK; }
+    lemon_set_error("lemon_linear_f32: hipBLASLt offers no solution for this problem (heuristic status %d, %d candidates)", (int)st, got);
+    return LEMON_E_INVALID;
+}
+
+// one-time check of a recorded solution index on the caller's operands: its output must agree with the first-ranked
+// solution's (synchronises the stream; runs once per key and process).  Returns 1 = agrees, 0 = rejected, <0 error.
+int recorded_agrees(Problem &p, const hipblasLtMatmulAlgo_t &rec, const hipblasLtMatmulAlgo_t &first, const float *x,
+                    const float *w, const float *residual, float alpha, int64_t m, int n, hipStream_t stream) {
+    const float beta = residual ? 1.0f : 0.0f;
+    const int64_t cnt = (int64_t)m * n;
+    float *buf = nullptr;
+    unsigned *flag = nullptr;
+    if (hipMalloc((void **)&buf, (size_t)2 * cnt * sizeof(float)) != hipSuccess || hipMalloc((void **)&flag, 2 * sizeof(unsigned)) != hipSuccess) {
+        if (buf) (void)hipFree(buf);
+        lemon_set_error("lemon_linear_f32: validation buffers (2 x %lld x %d floats)", (long long)m, n);
+        return LEMON_E_NOMEM;
+    }
+    float *ya = buf, *yb = buf + cnt;
+    (void)hipMemsetAsync(ya, 0, (size_t)cnt * sizeof(float), stream);
+    (void)hipMemsetAsync(yb, 0xFF, (size_t)cnt * sizeof(float), stream);      // NaN-poisoned C for the candidate (beta == 0 must not read it)
+    (void)hipMemsetAsync(flag, 0, 2 * sizeof(unsigned), stream);
+    bool ok = hipblasLtMatmul(g_lin.handle, p.desc, &alpha, w, p.la, x, p.lb, &beta, residual ? residual : ya, p.lc, ya, p.lc, &first,
+                              g_lin.ws, g_lin.ws_bytes, stream) == HIPBLAS_STATUS_SUCCESS;
+    ok = ok && hipblasLtMatmul(g_lin.handle, p.desc, &alpha, w, p.la, x, p.lb, &beta, residual ? residual : yb, p.lc, yb, p.lc, &rec,
+                               g_lin.ws, g_lin.ws_bytes, stream) == HIPBLAS_STATUS_SUCCESS;
+    unsigned h[2] = {0, 1};
+    if (ok) {
+        const unsigned blocks = (unsigned)std::min<int64_t>((cnt + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_absmax, dim3(blocks), dim3(256), 0, stream, ya, cnt, flag);
+        (void)hipMemcpyAsync(h, flag, sizeof(unsigned), hipMemcpyDeviceToHost, stream);
+        (void)hipStreamSynchronize(stream);
+        float ref_max; memcpy(&ref_max, &h[0], sizeof(float));
+        hipLaunchKernelGGL(k_count_off, dim3(blocks), dim3(256), 0, stream, yb, ya, cnt, 1e-3f * ref_max + 1e-6f, flag + 1);
+        (void)hipMemcpyAsync(&h[1], flag + 1, sizeof(unsigned), hipMemcpyDeviceToHost, stream);
+        (void)hipStreamSynchronize(stream);
+        if (!(ref_max < INFINITY)) h[1] = 0;              // non-finite inputs: nothing to compare, keep the record
+    }
+    (void)hipFree(buf); (void)hipFree(flag);
+    return ok && h[1] == 0 ? 1 : 0;
+}
+
 }  // namespace
+
+extern "C" int lemon_linear_set_tuning(int enabled) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_tuning = enabled ? 1 : 0;
+    return LEMON_OK;
+}
 
 extern "C" int lemon_linear_f32(const float *x_dev, const float *w_dev, const float *bias_dev, const float *residual_dev,
                                 int64_t m, int n, int k, float alpha, int act, float *y_dev, void *stream_) {
@@ -261,7 +351,7 @@ extern "C" int lemon_linear_f32(const float *x_dev, const float *w_dev, const fl
     if (m == 0) return LEMON_OK;
     LEMON_REQUIRE(x_dev && w_dev && y_dev, "null pointer");
     hipStream_t stream = (hipStream_t)stream_;
-    std::lock_guard<std::mutex> lock(g_lin.mu);
+    std::lock_guard<std::mutex> lock(g_mu);
     int rc = ensure_state(stream);
     if (rc) return rc;
     int epilogue = HIPBLASLT_EPILOGUE_DEFAULT;
@@ -274,26 +364,40 @@ extern "C" int lemon_linear_f32(const float *x_dev, const float *w_dev, const fl
     if (rc) return rc;
 
     hipblasLtMatmulAlgo_t algo;
-    auto it = g_lin.algo.find(key);
     bool have = false;
+    auto it = g_lin.algo.find(key);
     if (it != g_lin.algo.end()) {
         algo = it->second;
         have = supported(p, algo, beta);                 // also binds the problem to the algo struct
-    } else {
-        auto ix = g_lin.index.find(key);
-        if (ix != g_lin.index.end()) {                   // recorded index (results file)
-            std::vector<int> idx{ix->second};
-            std::vector<hipblasLtMatmulHeuristicResult_t> res;
-            if (hipblaslt_ext::getAlgosFromIndex(g_lin.handle, idx, res) == HIPBLAS_STATUS_SUCCESS && !res.empty()) {
-                algo = res[0].algo;
-                have = supported(p, algo, beta);
-            }
-        }
     }
     if (!have) {
+        auto ix = g_lin.index.find(key);
+        if (ix != g_lin.index.end() && g_lin.from_file.count(key)) {     // recorded index: check it once, then trust it
+            std::vector<int> idx{ix->second};
+            std::vector<hipblasLtMatmulHeuristicResult_t> res;
+            hipblasLtMatmulAlgo_t first;
+            if (hipblaslt_ext::getAlgosFromIndex(g_lin.handle, idx, res) == HIPBLAS_STATUS_SUCCESS && !res.empty() &&
+                supported(p, res[0].algo, beta) && first_ranked(p, beta, &first) == LEMON_OK) {
+                const int ok = recorded_agrees(p, res[0].algo, first, x_dev, w_dev, residual_dev, alpha, m, n, stream);
+                if (ok < 0) return ok;
+                if (ok == 1) { algo = res[0].algo; have = supported(p, algo, beta); }
+                else if (getenv("LEMON_LINEAR_VERBOSE"))
+                    fprintf(stderr, "[lemon_linear] recorded solution %d for m=%lld n=%d k=%d epi=%d disagrees with the first-ranked one: dropped\n",
+                            ix->second, (long long)m, n, k, epilogue);
+            }
+            g_lin.from_file.erase(key);
+            if (!have) { g_lin.index.erase(key); g_lin.usec.erase(key); }
+        }
+    }
+    if (!have && g_tuning == 1) {                        // explicit offline tuning only
         rc = tune(key, p, x_dev, w_dev, residual_dev, m, n, stream, &algo);
         if (rc) return rc;
-        if (!supported(p, algo, beta)) { lemon_set_error("lemon_linear_f32: tuned solution rejected"); return LEMON_E_HIP; }
+        have = supported(p, algo, beta);
+        if (!have) { lemon_set_error("lemon_linear_f32: tuned solution rejected"); return LEMON_E_HIP; }
+    }
+    if (!have) {
+        rc = first_ranked(p, beta, &algo);
+        if (rc) return rc;
     }
     g_lin.algo[key] = algo;
     const float *c = residual_dev ? residual_dev : y_dev;
@@ -302,18 +406,34 @@ extern "C" int lemon_linear_f32(const float *x_dev, const float *w_dev, const fl
     return LEMON_OK;
 }
 
+// Results file: first line "# lemon_linear hipblaslt=<int> arch=<name>", then m,n,k,epilogue,residual,index,usec rows.
+// Returns the number of keys taken (0 when the stamp does not match this process's library / device), <0 on error.
 extern "C" int lemon_linear_load_tuned(const char *path) {
     LEMON_REQUIRE(path != nullptr, "path");
     FILE *f = fopen(path, "r");
     if (!f) { lemon_set_error("cannot open %s", path); return LEMON_E_INVALID; }
-    std::lock_guard<std::mutex> lock(g_lin.mu);
+    std::lock_guard<std::mutex> lock(g_mu);
+    int rc = ensure_state(nullptr);
+    if (rc) { fclose(f); return rc; }
     char line[512];
-    int loaded = 0;
+    int loaded = 0, version = -1;
+    char arch[64] = {0};
+    bool stamped = false;
     while (fgets(line, sizeof line, f)) {
+        if (!stamped && sscanf(line, "# lemon_linear hipblaslt=%d arch=%63s", &version, arch) == 2) {
+            stamped = true;
+            if (version != g_lin.version || strcmp(arch, g_lin.arch) != 0) {
+                if (getenv("LEMON_LINEAR_VERBOSE"))
+                    fprintf(stderr, "[lemon_linear] %s was tuned for hipblaslt=%d arch=%s, this process has hipblaslt=%d arch=%s: ignored\n",
+                            path, version, arch, g_lin.version, g_lin.arch);
+                break;
+            }
+            continue;
+        }
         long long m; int n, k, epi, res, index; float us;
-        if (sscanf(line, "%lld,%d,%d,%d,%d,%d,%f", &m, &n, &k, &epi, &res, &index, &us) == 7) {
+        if (stamped && sscanf(line, "%lld,%d,%d,%d,%d,%d,%f", &m, &n, &k, &epi, &res, &index, &us) == 7) {
             const LinKey key((int64_t)m, n, k, epi, res);
-            if (!g_lin.algo.count(key)) { g_lin.index[key] = index; g_lin.usec[key] = us; ++loaded; }
+            if (!g_lin.algo.count(key)) { g_lin.index[key] = index; g_lin.usec[key] = us; g_lin.from_file[key] = true; ++loaded; }
         }
     }
     fclose(f);
@@ -322,10 +442,13 @@ extern "C" int lemon_linear_load_tuned(const char *path) {
 
 extern "C" int lemon_linear_dump_tuned(const char *path) {
     LEMON_REQUIRE(path != nullptr, "path");
+    std::lock_guard<std::mutex> lock(g_mu);
+    int rc = ensure_state(nullptr);
+    if (rc) return rc;
     FILE *f = fopen(path, "w");
     if (!f) { lemon_set_error("cannot write %s", path); return LEMON_E_INVALID; }
-    std::lock_guard<std::mutex> lock(g_lin.mu);
-    fprintf(f, "# m,n,k,epilogue,residual,hipblaslt_solution_index,usec   (fp32, y = act(x W^T + b) [+ residual]; gfx950)\n");
+    fprintf(f, "# lemon_linear hipblaslt=%d arch=%s\n", g_lin.version, g_lin.arch);
+    fprintf(f, "# m,n,k,epilogue,residual,hipblaslt_solution_index,usec   (fp32, y = act(x W^T + b) [+ residual])\n");
     int rows = 0;
     for (const auto &kv : g_lin.index) {
         const LinKey &key = kv.first;
@@ -335,4 +458,14 @@ extern "C" int lemon_linear_dump_tuned(const char *path) {
     }
     fclose(f);
     return rows;
+}
+
+// hipBLASLt version / arch stamp of the calling thread's current device (for the results file and for logs)
+extern "C" int lemon_linear_stamp(int *hipblaslt_version, char *arch, int arch_len) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    int rc = ensure_state(nullptr);
+    if (rc) return rc;
+    if (hipblaslt_version) *hipblaslt_version = g_lin.version;
+    if (arch && arch_len > 0) { strncpy(arch, g_lin.arch, (size_t)arch_len - 1); arch[arch_len - 1] = 0; }
+    return LEMON_OK;
 }

@@ -163,42 +163,6 @@ __global__ __launch_bounds__(256) void k_score(const float *__restrict__ d1, con
     score[i] = (double)d1[i] + hp.beta * a + hp.gamma * b;
 }
 
-// ---------------------------------------------------------------------------------
-// QuickGELU x * sigmoid(1.702 x) in place (lib/models/chexzero_clip.py:186-188): the encoder's MLP
-// activation.  PyTorch runs it as three elementwise kernels (scale, sigmoid, multiply = 3 reads +
-// 3 writes of the [tokens, 4*width] activation, ~10 % of the ViT-B/32 forward on MI355X); this is one
-// read + one write, float4 per lane, grid-stride.
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_quick_gelu(float *__restrict__ x, int64_t n4, int64_t n) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    float4 *x4 = reinterpret_cast<float4 *>(x);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 v = x4[i];
-        v.x = v.x / (1.0f + expf(-1.702f * v.x));
-        v.y = v.y / (1.0f + expf(-1.702f * v.y));
-        v.z = v.z / (1.0f + expf(-1.702f * v.z));
-        v.w = v.w / (1.0f + expf(-1.702f * v.w));
-        x4[i] = v;
-    }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {     // tail
-        const int64_t i = n4 * 4 + threadIdx.x;
-        const float v = x[i];
-        x[i] = v / (1.0f + expf(-1.702f * v));
-    }
-}
-
-extern "C" int lemon_quick_gelu(float *x_dev, int64_t n, void *stream) {
-    LEMON_REQUIRE(n >= 0, "n >= 0");
-    if (n == 0) return LEMON_OK;
-    LEMON_REQUIRE(x_dev != nullptr && (((uintptr_t)x_dev) & 15) == 0, "x_dev must be 16-byte aligned");
-    const int64_t n4 = n / 4;
-    int64_t blocks = (n4 + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_quick_gelu, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_dev, n4, n);
-    LEMON_HIP_CHECK(hipGetLastError());
-    return LEMON_OK;
-}
 
 // ---------------------------------------------------------------------------------
 // C ABI

@@ -73,15 +73,6 @@ def our_metric(first, second, dist="cosine"):
     return out
 
 
-def quick_gelu_(x):
-    """In-place QuickGELU on a contiguous float32 CUDA tensor (one fused HIP pass)."""
-    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
-    lib = _lib.load()
-    with torch.cuda.device(x.device):
-        _lib.check(lib.lemon_quick_gelu(ptr(x), x.numel(), stream_ptr(x.device)), "lemon_quick_gelu")
-    return x
-
-
 def grid_f1(rec, y, hparams, xtol=1e-8, maxfun=500, return_scores=False):
     """Batched hyper-parameter grid: for every row (beta, gamma, tau_1_n, tau_2_n, tau_1_m, tau_2_m) of
     `hparams` [G,6] the F1-optimal threshold search of optimize_f1_efficient on the device-resident

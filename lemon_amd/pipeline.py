@@ -69,18 +69,31 @@ class Embedder:
 
     @torch.no_grad()
     def embed_texts(self, input_ids):
+        eot = None if input_ids.is_cuda else input_ids.argmax(dim=-1)       # host ids: EOT positions without a sync
         input_ids = input_ids.to(self.device)
         if self.text_dedup:
             uniq, inv = torch.unique(input_ids, dim=0, return_inverse=True)
             e = self._embed_texts(uniq)[inv]
         else:
-            e = self._embed_texts(input_ids)
+            e = self._embed_texts(input_ids, eot)
         return ops.normalize_vectors(e) if e.shape[0] else e                          # :163 / :230-232
 
-    def _embed_texts(self, ids):
-        outs = [self.model.encode_text(ids[i:i + self.text_batch_size]).float()
-                for i in range(0, ids.shape[0], self.text_batch_size)]
-        return torch.cat(outs) if outs else torch.empty((0, self.model.cfg.embed_dim), device=self.device)
+    def _embed_texts(self, ids, eot=None):
+        """ids on the device; eot = per-row EOT position on the HOST (one transfer for the whole array instead of a
+        device sync per micro-batch) from which each micro-batch's bucketed token count is taken."""
+        if ids.shape[0] == 0:
+            return torch.empty((0, self.model.cfg.embed_dim), device=self.device)
+        tower = getattr(self.model, "text", None)
+        if eot is None and hasattr(tower, "seq_len_for"):
+            eot = ids.argmax(dim=-1).cpu()
+        outs = []
+        for i in range(0, ids.shape[0], self.text_batch_size):
+            if eot is not None and hasattr(tower, "seq_len_for"):
+                L = tower.seq_len_for(int(eot[i:i + self.text_batch_size].max()))
+                outs.append(self.model.encode_text(ids[i:i + self.text_batch_size], seq_len=L).float())
+            else:
+                outs.append(self.model.encode_text(ids[i:i + self.text_batch_size]).float())
+        return torch.cat(outs)
 
 
 def score_splits(db, splits, k, hparams=None, discrete=False):

@@ -58,14 +58,15 @@ def build_parser():
     p.add_argument("--skip_train", action="store_true")
     p.add_argument("--skip_hparam_optim", action="store_true")
     # ---- extensions (not in the reference) ----
-    p.add_argument("--clip_path", default="random", help="local HF CLIP checkpoint dir, or random[:arch]")
+    p.add_argument("--clip_path", default="random",
+                   help="local HF CLIP checkpoint dir (huggingface_clip), local OpenAI-format .pt (in-tree CLIP branches), or random[:arch]")
+    p.add_argument("--bpe_path", default=None,
+                   help="CLIP BPE merges file (bpe_simple_vocab_16e6.txt.gz / merges.txt) when the checkpoint has no tokenizer files")
     p.add_argument("--data_root", default="./data", help="local dataset root, or synthetic:N")
     p.add_argument("--algo", default="auto", choices=["auto", "f32", "bf16"], help="kNN scan algorithm")
     p.add_argument("--encoder_batch", default=512, type=int, help="encoder micro-batch on the GPU")
     p.add_argument("--lbfgs_device", default="cuda", choices=["cuda", "cpu"],
                    help="where the SoftMargin/LBFGS polish of the hyper-parameter search runs (lib/metrics/utils.py:121-149)")
-    p.add_argument("--gemm_tuning", action="store_true",
-                   help="let TunableOp pick the hipBLASLt solution per encoder GEMM shape (lemon_amd/tuning.py)")
     p.add_argument("--hparam_grid", default="full", choices=["full", "small"],
                    help="'small' = 3x3x2x2 grid for smoke runs (reference grid is 21x21x4x4)")
     return p
@@ -137,7 +138,8 @@ def main(argv=None):
     label_set = ds.LABEL_SETS.get(args.dataset)
     is_clf = args.dataset in CLF_DATASETS
     model, tokenizer = algorithm_class_from_scratch(args.clip_model, text_base_name=args.clip_path, img_base=None,
-                                                    return_tokenizer=True)
+                                                    return_tokenizer=True, bpe_path=args.bpe_path)
+    hf_style = args.clip_model == "huggingface_clip"      # the other branches' tokenizer returns a LongTensor (:148-154)
     train_set, val_set, test_set = get_dataset(args.dataset, args.data_seed, percent_flips=args.noise_level,
                                                flip_type=args.noise_type, data_root=args.data_root,
                                                image_size=model.cfg.image_size)
@@ -145,9 +147,6 @@ def main(argv=None):
         rng = np.random.default_rng(args.data_seed)
         val_set = val_set.subset(rng.choice(np.arange(len(val_set)), min(args.subset_val_set, len(val_set)), replace=False))
 
-    if args.gemm_tuning:
-        from .tuning import enable_gemm_tuning
-        enable_gemm_tuning()
     embedder = Embedder(model, device, batch_size=args.encoder_batch)
     prefix = "A photo of a " if args.custom_cifar_prompt is None else args.custom_cifar_prompt
     prompt_fn = lambda x: prefix + x
@@ -166,6 +165,8 @@ def main(argv=None):
         return list(noisy), list(clean), list(noisy)
 
     def tokenize(prompts):
+        if not hf_style:
+            return tokenizer(prompts)
         enc = tokenizer(prompts, padding="max_length", truncation=True)
         return torch.tensor(enc["input_ids"])
 

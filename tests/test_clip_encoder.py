@@ -78,3 +78,43 @@ def test_flop_model_matches_survey():
     assert 8.0e9 < img < 9.6e9 and 5.4e9 < txt < 6.6e9          # ~8.8 / ~6.0 GFLOP
     n = sum(p.numel() for p in LemonCLIP(ClipConfig.named("vit-b-32")).parameters())
     assert abs(n - 151.3e6) < 0.3e6                              # 151.3 M params
+
+
+# ------------------------------------------------------------------ in-tree CLIP (A3'): reference-generated goldens
+@pytest.mark.parametrize("name", ["small_hd64", "scratch_b16_77"])
+def test_openai_format_loader_matches_reference_clip(name):
+    """LemonCLIP loaded from an OpenAI-format state dict vs the outputs of the reference's own CLIP module
+    (lib/models/chexzero_clip.py:263-392; `scratch_b16_77` is built by its load_clip(None, 77), :458-479) on the same
+    seeded weights and inputs (tools/make_golden_encoder.py -> tests/golden/encoder_chexzero.npz)."""
+    import os
+    from tests.encoder_recipe import CONFIGS, inputs, lemon_clip_from_recipe, openai_state_dict
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "encoder_chexzero.npz"))
+    cfg = CONFIGS[name]
+    sd = openai_state_dict(cfg)
+    px, ids = inputs(cfg)
+    assert abs(sum(float(v.double().abs().sum()) for v in sd.values()) / float(fx[f"{name}_weights_abs_sum"]) - 1) < 1e-9
+    assert abs((float(px.double().abs().sum()) + float(ids.double().sum())) / float(fx[f"{name}_inputs_abs_sum"]) - 1) < 1e-9
+    m = lemon_clip_from_recipe(name)
+    assert m.context_length == cfg["context_length"] and m.cfg.embed_dim == cfg["embed_dim"]
+    gi, gt = m.encode_image(px).numpy(), m.encode_text(ids).numpy()
+    ri, rt = fx[f"{name}_img"], fx[f"{name}_txt"]
+    assert np.abs(gi - ri).max() < 2e-5 * max(1.0, np.abs(ri).max()), np.abs(gi - ri).max()
+    assert np.abs(gt - rt).max() < 2e-5 * max(1.0, np.abs(rt).max()), np.abs(gt - rt).max()
+
+
+def test_in_tree_branches_of_the_factory(tmp_path):
+    """algorithm_class_from_scratch for the in-tree CLIP branches (lib/models/utils.py:82-103): tokenizer -> LongTensor,
+    encode_text(tokens); a checkpoint of the wrong architecture is refused; biomed_clip is refused."""
+    from tests.encoder_recipe import CONFIGS, openai_state_dict
+    model, tok = algorithm_class_from_scratch("cc3m_clip_from_scratch", "random:tiny", None, return_tokenizer=True)
+    t = tok(["a b c", "d"])
+    assert t.dtype == torch.long and t.shape == (2, 16)
+    assert model.encode_text(t).shape == (2, 32)
+    path = tmp_path / "ckpt.pt"
+    torch.save(openai_state_dict(CONFIGS["small_hd64"]), path)
+    m2 = LemonCLIP.from_openai_checkpoint(str(path))
+    assert m2.cfg.embed_dim == 64 and m2.cfg.vision.heads == 2
+    with pytest.raises(ValueError):
+        algorithm_class_from_scratch("chexzero", str(path), None)
+    with pytest.raises(NotImplementedError):
+        algorithm_class_from_scratch("biomed_clip", "x", None)

@@ -372,13 +372,8 @@ def test_auto_picks_bf16_on_spread_data_and_f32_on_band_crowded_data(hip):
         assert torch.equal(Ia, Ir) and torch.equal(Da, Dr)
 
 
-def test_quick_gelu_and_encoder_gpu_vs_cpu(hip):
+def test_tiny_encoder_gpu_vs_cpu(hip):
     from lemon_amd.clip import ClipConfig, LemonCLIP
-    from lemon_amd.ops import quick_gelu_
-    x = torch.randn(1000, 77, generator=torch.Generator().manual_seed(0)) * 3
-    ref = x * torch.sigmoid(1.702 * x)
-    got = quick_gelu_(x.cuda().contiguous()).cpu()
-    assert (got - ref).abs().max() < 2e-6
     m = LemonCLIP(ClipConfig.named("tiny")).eval()
     px = torch.randn(9, 3, 32, 32, generator=torch.Generator().manual_seed(1))
     ids = torch.randint(1, 290, (9, 16), generator=torch.Generator().manual_seed(2))
