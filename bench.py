@@ -30,22 +30,25 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0          # HBM3E spec peak (6.3 TB/s achievable)
 
 
-def pmc_traffic(kernel_substr, path=os.path.join(ROOT, "profiles", "r1", "bench_default_pmc.csv")):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of THIS
-    command (tools/gpu_profile.sh; FETCH_SIZE and WRITE_SIZE in separate runs, KB units, FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane streaming reads on gfx950).  None when
-    the summary is absent: PMC counters cannot be collected from inside the timed process."""
+def pmc_traffic(kernel_substr):
+    """(bytes, source): HBM-side bytes per launch of the dominant kernel from the COMMITTED rocprofv3 --pmc passes of
+    this command (tools/gpu_profile.sh; FETCH_SIZE and WRITE_SIZE in separate runs, KB units, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for 16-B-per-lane streaming reads on gfx950).  PMC counters cannot be collected
+    from inside the timed process, so this is NOT a measurement of the current run: the file it came from is
+    reported next to it as `traffic_source`.  (None, None) when no summary is committed."""
     import csv
-    if not os.path.exists(path):
-        return None
+    path = next((p for p in (os.path.join(ROOT, "profiles", r, "bench_default_pmc.csv") for r in ("r2", "r1"))
+                 if os.path.exists(p)), None)
+    if path is None:
+        return None, None
     acc = {"FETCH_SIZE": [], "WRITE_SIZE": []}
     for r in csv.DictReader(open(path)):
         if kernel_substr in r["kernel"] and r["counter"] in acc and int(r["grid"]) >= 256 * 256:
             acc[r["counter"]].append(float(r["value_KB"]))
     if not acc["FETCH_SIZE"] or not acc["WRITE_SIZE"]:
-        return None
+        return None, None
     mean = lambda v: sum(v) / len(v)
-    return (2.0 * mean(acc["FETCH_SIZE"]) + mean(acc["WRITE_SIZE"])) * 1024.0
+    return (2.0 * mean(acc["FETCH_SIZE"]) + mean(acc["WRITE_SIZE"])) * 1024.0, os.path.relpath(path, ROOT)
 
 
 def parse():
@@ -72,7 +75,34 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_sample_images", type=int, default=96)
     ap.add_argument("--cpu_sample_queries", type=int, default=2048)
+    ap.add_argument("--no_knn_1m", action="store_true",
+                    help="skip the extra 1M x 768 self-join object (`knn_1m`) the N=1 headline line carries")
+    ap.add_argument("--knn_cpu_queries", type=int, default=4096, help="query slice of the kNN workload's CPU baseline")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` started by hand (no torchrun): start N fresh rank processes BEFORE anything touches the
+    GPU in this one, wait for them, relay rank 0's JSON line, fail if any rank fails.  No exec: children are ordinary
+    subprocesses with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what torch.distributed.run sets)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f"bench.py: rank exit codes {codes}")
+    return 0
 
 
 def init_dist(args):
@@ -91,8 +121,8 @@ def init_dist(args):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     return world, rank, torch.device("cuda", local)
 
 
@@ -195,7 +225,8 @@ def bench_cifar(args, world, rank, dev):
     for k_ in stage:
         stage[k_] += timers[k_]
     info = db.index_img.last_search_info()
-    f_img, f_txt = encoder_flops(cfg, n_tokens_text=int(data["train"]["ids"].argmax(-1).max().item()) + 1)
+    # text tokens actually run: the longest prompt rounded up to the tower's bucket (clip.TextTower.seq_len_for)
+    f_img, f_txt = encoder_flops(cfg, n_tokens_text=model.text.seq_len_for(int(data["train"]["ids"].argmax(-1).max().item())))
 
     value = n_scored * world * args.steps / elapsed
     line = {
@@ -222,18 +253,28 @@ def bench_cifar(args, world, rank, dev):
     if prof["launches"]:
         sec = prof["kernel_ms"] / 1e3
         tf = prof["algo_flops"] / sec / 1e12
+        traffic, traffic_src = pmc_traffic("k_scan_f32")
         line["roofline"] = {
             "kernel": "k_scan_f32" if info["algo"] == _lib.ALGO_F32_MFMA else "k_scan_bf16",
             "bound": "mfma", "achieved": tf,
             "peak": PEAK_F32_MFMA_TFLOPS if info["algo"] == _lib.ALGO_F32_MFMA else PEAK_BF16_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": tf / (PEAK_F32_MFMA_TFLOPS if info["algo"] == _lib.ALGO_F32_MFMA else PEAK_BF16_MFMA_TFLOPS),
-            "traffic": pmc_traffic("k_scan_f32"), "launches": prof["launches"],
+            "traffic": traffic, "traffic_source": traffic_src, "launches": prof["launches"],
             "avg_launch_ms": prof["kernel_ms"] / prof["launches"],
             "hbm_scan_model": {"B": info["query_panel"], "achieved_GBs": prof["algo_bytes"] / sec / 1e9,
                                "peak_GBs": PEAK_HBM_GBS, "frac": prof["algo_bytes"] / sec / 1e9 / PEAK_HBM_GBS},
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"], line["auroc_check"] = cpu_baseline_cifar(args, cfg, model, data, recs, db, n_scored)
+    if world == 1 and not args.no_knn_1m:
+        # north_star's second target inside the same driver-timed run: the 1M x 768, k=50 self-join on this GPU
+        del recs, db, data, emb, model
+        torch.cuda.empty_cache()
+        ka = argparse.Namespace(**{**vars(args), "knn_n": 1_000_000, "knn_d": 768, "knn_k": 50, "steps": 1, "warmup": 0,
+                                   "algo": "auto", "dist_type": "cosine"})
+        k1 = bench_knn(ka, world, rank, dev)
+        line["knn_1m"] = {"workload": k1["config"]["workload"], "ms": k1["ms_per_step"], "scores_per_s": k1["value"],
+                          "roofline": k1["roofline"], "cpu_baseline": k1.get("cpu_baseline")}
     return line
 
 
@@ -336,7 +377,10 @@ def bench_knn(args, world, rank, dev):
     sec = prof["kernel_ms"] / 1e3
     f32 = info["algo"] == _lib.ALGO_F32_MFMA
     peak = PEAK_F32_MFMA_TFLOPS if f32 else PEAK_BF16_MFMA_TFLOPS
-    return {
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_knn(args, db, img, txt, s, k)
+    line = {
         "metric": "label-error scores/sec (kNN+score only), synthetic embeddings", "value": n * args.steps / elapsed,
         "unit": "scores/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
@@ -348,12 +392,38 @@ def bench_knn(args, world, rank, dev):
                      "frac": prof["algo_flops"] / sec / 1e12 / peak, "traffic": None,
                      "launches": prof["launches"], "avg_launch_ms": prof["kernel_ms"] / max(prof["launches"], 1),
                      "hbm_scan_model": {"B": info["query_panel"], "achieved_GBs": prof["algo_bytes"] / sec / 1e9,
-                                        "peak_GBs": PEAK_HBM_GBS, "frac": prof["algo_bytes"] / sec / 1e9 / PEAK_HBM_GBS}},
+                                        "peak_GBs": PEAK_HBM_GBS, "frac": prof["algo_bytes"] / sec / 1e9 / PEAK_HBM_GBS,
+                                        "note": "MODEL bytes (one DB stream per 128-query panel, SURVEY 8d), not measured "
+                                                "traffic: the kernel is MFMA-bound, `frac` above is the binding fraction"}},
     }
+    if cpu is not None:
+        line["cpu_baseline"] = cpu
+    return line
+
+
+def cpu_baseline_knn(args, db, img, txt, s_gpu, k):
+    """The CPU oracle (AVX2 + OpenMP C restatement, `kind: port`) on a bounded query slice of the SAME self-join: the first
+    nq rows as queries against the full DB, both modalities, neighbours + scores; also checks the GPU result on the slice."""
+    from oracle import oracle as o
+    from lemon_amd.pipeline import FIXED_HPARAMS
+    cores = o.usable_cores()
+    o.set_threads(cores)
+    nq = min(args.knn_cpu_queries, img.shape[0])
+    img_tr, txt_tr = db.img.cpu().numpy(), db.txt.cpu().numpy()
+    t0 = time.perf_counter()
+    ref = o.neighbors(args.dist_type, img_tr, txt_tr, img_tr[:nq], txt_tr[:nq], k, drop_self=True)
+    sref = o.score(ref, FIXED_HPARAMS)
+    dt = time.perf_counter() - t0
+    return {"value": nq / dt, "unit": "scores/s", "cores": cores, "kind": "port",
+            "sample": f"oracle neighbours+score for the first {nq} of {img.shape[0]} queries against the full {img_tr.shape[0]}x{img_tr.shape[1]} "
+                      f"DB, both modalities, k={k}+1 ({dt:.1f} s, OpenMP {cores} threads); scaled per query",
+            "gpu_scores_match_on_slice": bool(np.abs(s_gpu[:nq].cpu().numpy() - sref).max() <= 1e-9)}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)               # before any GPU call in this process
     world, rank, dev = init_dist(args)
     from lemon_amd import _lib
     _lib.load()                                   # fail loudly if the HIP library is missing

@@ -160,6 +160,13 @@ const float *lemon_index_data(const lemon_index_t *idx);
 int lemon_index_search(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
                        float *D_dev, int64_t *I_dev, void *stream);
 int lemon_index_set_algo(lemon_index_t *idx, int algo);
+/* Query de-duplication (on by default; LEMON_QUERY_DEDUP=0 disables it process-wide): from 1024 queries on, the rows of
+ * q are grouped by content (64-bit hash + stable sort + full bitwise comparison) and, when at most half of them are
+ * distinct, the search runs once per distinct row and its (D, I) lists are copied to every member -- exact, because a
+ * query's result does not depend on the other queries.  Classification datasets make the text-side search of
+ * run_lemon.py:236 a C-query problem this way.  Costs one stream synchronisation per search call (the group
+ * count is read back). */
+int lemon_index_set_query_dedup(lemon_index_t *idx, int enabled);
 
 /* last search's dominant-kernel launch statistics (for bench/roofline bookkeeping) */
 typedef struct {
@@ -169,6 +176,7 @@ typedef struct {
     int db_splits;       /* how many workgroups share one query panel        */
     int64_t nq, n;
     int d, k;
+    int64_t nq_distinct; /* query rows actually searched (== the call's nq unless duplicates were folded) */
 } lemon_search_info_t;
 int lemon_index_last_search_info(const lemon_index_t *idx, lemon_search_info_t *out);
 

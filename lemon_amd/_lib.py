@@ -19,7 +19,7 @@ EXPORTS = [
     "lemon_d1_normalized", "lemon_paired_metric", "lemon_preprocess_u8", "lemon_attention_f32", "lemon_linear_f32", "lemon_linear_load_tuned",
     "lemon_linear_dump_tuned", "lemon_linear_set_tuning", "lemon_linear_stamp", "lemon_index_create", "lemon_index_free", "lemon_index_add",
     "lemon_index_ntotal", "lemon_index_dim", "lemon_index_data", "lemon_index_search",
-    "lemon_index_set_algo", "lemon_index_last_search_info", "lemon_index_set_profiling",
+    "lemon_index_set_algo", "lemon_index_set_query_dedup", "lemon_index_last_search_info", "lemon_index_set_profiling",
     "lemon_index_profile_read", "lemon_neighbors", "lemon_discrepancy", "lemon_score", "lemon_grid_f1",
 ]
 
@@ -31,7 +31,8 @@ class LemonHipError(RuntimeError):
 class SearchInfo(ctypes.Structure):
     _fields_ = [("algo", ctypes.c_int), ("grid", ctypes.c_int), ("block", ctypes.c_int),
                 ("query_panel", ctypes.c_int), ("db_splits", ctypes.c_int),
-                ("nq", ctypes.c_int64), ("n", ctypes.c_int64), ("d", ctypes.c_int), ("k", ctypes.c_int)]
+                ("nq", ctypes.c_int64), ("n", ctypes.c_int64), ("d", ctypes.c_int), ("k", ctypes.c_int),
+                ("nq_distinct", ctypes.c_int64)]
 
 
 _lib = None
@@ -77,6 +78,7 @@ def load():
     lib.lemon_index_data.restype = vp
     lib.lemon_index_search.argtypes = [vp, vp, c_i64, c_int, vp, vp, vp]
     lib.lemon_index_set_algo.argtypes = [vp, c_int]
+    lib.lemon_index_set_query_dedup.argtypes = [vp, c_int]
     lib.lemon_index_last_search_info.argtypes = [vp, ctypes.POINTER(SearchInfo)]
     lib.lemon_index_set_profiling.argtypes = [vp, c_int]
     lib.lemon_index_profile_read.argtypes = [vp, ctypes.POINTER(c_i64)] + [ctypes.POINTER(ctypes.c_double)] * 3

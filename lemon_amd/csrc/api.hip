@@ -38,6 +38,10 @@ extern "C" int lemon_index_create(int metric, int d, lemon_index_t **out) {
     idx->d = d;
     idx->dpad = (int)round_up64(d, 64);   // even number of 32-wide k-slices (fp32 scan's two-set prefetch)
     idx->algo = LEMON_ALGO_AUTO;
+    {   // query de-duplication: on by default, LEMON_QUERY_DEDUP=0 turns it off process-wide
+        const char *e = getenv("LEMON_QUERY_DEDUP");
+        idx->qdedup = (e && e[0] == '0') ? 0 : 1;
+    }
     idx->prof_events = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
     if (hipGetDevice(&idx->device) != hipSuccess) {
         delete idx->prof_events;
@@ -52,7 +56,7 @@ extern "C" int lemon_index_create(int metric, int d, lemon_index_t **out) {
 extern "C" int lemon_index_free(lemon_index_t *idx) {
     if (!idx) return LEMON_OK;
     void *ptrs[] = {idx->x, idx->xp, idx->xnorm, idx->xh, idx->xh_stats, idx->xn2max_dev, idx->ws_qp, idx->ws_qnorm,
-                    idx->ws_cand, idx->ws_part, idx->ws_state, idx->ws_D, idx->ws_I};
+                    idx->ws_cand, idx->ws_part, idx->ws_state, idx->ws_D, idx->ws_I, idx->ws_dd, idx->ws_ddq};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &e : *idx->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -64,6 +68,12 @@ extern "C" int lemon_index_free(lemon_index_t *idx) {
 extern "C" int64_t lemon_index_ntotal(const lemon_index_t *idx) { return idx ? idx->n : -1; }
 extern "C" int lemon_index_dim(const lemon_index_t *idx) { return idx ? idx->d : -1; }
 extern "C" const float *lemon_index_data(const lemon_index_t *idx) { return idx ? idx->x : nullptr; }
+
+extern "C" int lemon_index_set_query_dedup(lemon_index_t *idx, int enabled) {
+    LEMON_REQUIRE(idx != nullptr, "index handle");
+    idx->qdedup = enabled ? 1 : 0;
+    return LEMON_OK;
+}
 
 extern "C" int lemon_index_set_algo(lemon_index_t *idx, int algo) {
     LEMON_REQUIRE(idx != nullptr, "index handle");
@@ -229,10 +239,42 @@ int lemon_search_internal(lemon_index_t *idx, const float *q_dev, int64_t nq, in
     LEMON_REQUIRE(k >= 1 && k <= LEMON_MAX_K, "1 <= k <= LEMON_MAX_K");
     if (nq == 0) return LEMON_OK;
     LEMON_REQUIRE(q_dev && D_dev && I_dev, "null pointer");
+    // identical query rows (class prompts: 50 000 text queries, 100 distinct rows on CIFAR-100) are searched once
+    if (idx->qdedup && nq >= LEMON_DEDUP_MIN_NQ && nq < ((int64_t)1 << 31) && idx->n > 0) {
+        int64_t U = 0;
+        const int *rep = nullptr, *grp = nullptr;
+        int rc = lemon_dedup_queries(idx, q_dev, nq, stream, &U, &rep, &grp);
+        if (rc) return rc;
+        if (U * 2 <= nq) {
+            const size_t qb = ((size_t)U * idx->d * 4 + 255) & ~(size_t)255, db = ((size_t)U * k * 4 + 255) & ~(size_t)255;
+            const size_t need = qb + db + (size_t)U * k * 8;
+            if (need > idx->ws_ddq_bytes) {
+                LEMON_HIP_CHECK(hipStreamSynchronize(stream));
+                if (idx->ws_ddq) (void)hipFree(idx->ws_ddq);
+                idx->ws_ddq = nullptr; idx->ws_ddq_bytes = 0;
+                if (hipMalloc((void **)&idx->ws_ddq, need) != hipSuccess) { lemon_set_error("dedup result workspace allocation failed"); return LEMON_E_NOMEM; }
+                idx->ws_ddq_bytes = need;
+            }
+            float *qrep = idx->ws_ddq;
+            float *Dr = (float *)((char *)idx->ws_ddq + qb);
+            int64_t *Ir = (int64_t *)((char *)idx->ws_ddq + qb + db);
+            rc = lemon_gather_query_rows(q_dev, rep, U, idx->d, qrep, stream);
+            if (rc) return rc;
+            const int saved = idx->qdedup;
+            idx->qdedup = 0;
+            rc = lemon_search_internal(idx, qrep, U, k, Dr, Ir, stream);
+            idx->qdedup = saved;
+            if (rc) return rc;
+            idx->last.nq_distinct = U;
+            return lemon_expand_results(Dr, Ir, grp, nq, k, D_dev, I_dev, stream);
+        }
+    }
     int algo = idx->algo;
     if (algo == LEMON_ALGO_AUTO) algo = lemon_auto_choose(idx, q_dev, nq, k, stream);
-    if (algo == LEMON_ALGO_BF16_FILTER) return lemon_search_bf16(idx, q_dev, nq, k, D_dev, I_dev, stream);
-    return lemon_search_f32(idx, q_dev, nq, k, D_dev, I_dev, stream);
+    int rc = (algo == LEMON_ALGO_BF16_FILTER) ? lemon_search_bf16(idx, q_dev, nq, k, D_dev, I_dev, stream)
+                                              : lemon_search_f32(idx, q_dev, nq, k, D_dev, I_dev, stream);
+    idx->last.nq_distinct = nq;
+    return rc;
 }
 
 extern "C" int lemon_index_search(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,

@@ -73,6 +73,12 @@ struct lemon_index {
     // LEMON_ALGO_AUTO decision cache (valid while auto_n == n)
     int auto_algo;
     int64_t auto_n;
+    // query de-duplication (dedup.hip): mode (0 off, 1 auto) and its workspace
+    int qdedup;
+    void *ws_dd;
+    size_t ws_dd_bytes;
+    float *ws_ddq;        // gathered representative queries + their results
+    size_t ws_ddq_bytes;
     // optional scan-kernel timing (lemon_index_set_profiling)
     int profiling;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> *prof_events;
@@ -125,8 +131,14 @@ __host__ __device__ inline float lemon_key_score(u64 key) { return lemon_ord2f((
 __host__ __device__ inline u32 lemon_key_index(u64 key) { return 0xffffffffu - (u32)(key & 0xffffffffu); }
 
 #define LEMON_CAND_CAP 256 // candidate slots per query in the scan workspace
+#define LEMON_DEDUP_MIN_NQ 1024 // query de-duplication is attempted from this many queries on
 
 // internal entry points shared between translation units
 int lemon_search_internal(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
                           float *D_dev, int64_t *I_dev, hipStream_t stream);
 int lemon_rowdot_chain(const float *a, const float *b, int64_t n, int d, float *out, hipStream_t s);
+int lemon_dedup_queries(lemon_index_t *idx, const float *q_dev, int64_t nq, hipStream_t stream, int64_t *U_host,
+                        const int **rep_dev, const int **group_dev);
+int lemon_gather_query_rows(const float *q_dev, const int *rep_dev, int64_t U, int d, float *out_dev, hipStream_t stream);
+int lemon_expand_results(const float *Dr, const int64_t *Ir, const int *group_dev, int64_t nq, int k, float *D_dev, int64_t *I_dev,
+                         hipStream_t stream);

@@ -142,8 +142,12 @@ def gpu_transform_batch(images_u8, size=224, patch=0):
 
 
 class ImageLabelSet:
-    """(x, clean, noisy) triples like NoisyCombinedDataset; `images` is uint8 [N,H,W,3] or a list of
-    file paths; labels are ints (class datasets) or strings (captions)."""
+    """(x, clean, noisy) triples like NoisyCombinedDataset / CaptioningDataset.  `images` is one of
+      * uint8 [N,H,W,3] in memory (CIFAR pickles, `pixels.npy`): generic_transform runs on the GPU per batch;
+      * float32 [N,...] in memory: pixel tensors that are ALREADY what the model consumes (a preprocessed cache);
+        passed through unchanged;
+      * a list of file paths: PIL decode + generic_transform in a thread pool.
+    Labels are ints (class datasets) or strings (captions)."""
 
     def __init__(self, images, clean, noisy, image_size=224, workers=8):
         assert len(images) == len(clean) == len(noisy)
@@ -169,6 +173,11 @@ class ImageLabelSet:
         short: SURVEY Appendix B.6).  PIL work runs in a thread pool (the reference forks 8 DataLoader
         workers, run_lemon.py:129-131; threads avoid fork-after-HIP-init)."""
         hi = len(self) if hi is None else hi
+        if isinstance(self.images, np.ndarray) and self.images.dtype == np.float32:
+            for s in range(lo, hi, batch_size):
+                sl = slice(s, min(hi, s + batch_size))
+                yield torch.from_numpy(np.ascontiguousarray(self.images[sl])), self.clean[sl], self.noisy[sl]
+            return
         if device is not None and torch.device(device).type == "cuda" and isinstance(self.images, np.ndarray) \
                 and self.images.dtype == np.uint8 and self.images.ndim == 4:
             # in-memory uint8 arrays (CIFAR): 3 KB per image cross PCIe instead of 602 KB, and the
@@ -187,6 +196,34 @@ class ImageLabelSet:
 
 
 # ------------------------------------------------------------------------------ dataset factory
+def synthetic_caption_frame(n, seed, n_cat=80, image_hw=32):
+    """Stand-in for a caption dataset's `multimodal_mislabel_split.pkl` (lib/datasets/utils.py:275-323) when no data is
+    present: n rows with the columns the reader uses -- split (train/val/test/restval in Karpathy-like proportions;
+    restval rows are dropped by the reference's no-op remap), a UNIQUE sentence per row (a few exact
+    duplicates, as in COCO), `cat_labels` / `nouns_int` id lists (some rows without categories) -- plus in-memory
+    uint8 images [n, hw, hw, 3] whose pattern depends on the first category, so an encoder sees structure."""
+    import pandas as pd
+    rs = np.random.RandomState(seed)
+    cats = [sorted(set(rs.randint(0, n_cat, rs.randint(1, 4)).tolist())) for _ in range(n)]
+    for j in range(0, n, 53):
+        cats[j] = []
+    nouns = [sorted(set(rs.randint(0, 400, rs.randint(1, 6)).tolist())) for _ in range(n)]
+    first = np.array([c[0] if c else rs.randint(0, n_cat) for c in cats])
+    words = ["red", "small", "two", "wooden", "old", "bright", "open", "tall", "wet", "quiet", "busy", "empty"]
+    sent = [f"a {words[i % 12]} {words[(i // 12) % 12]} scene number {i} showing object {first[i]} near thing {nouns[i][0]}"
+            for i in range(n)]
+    for j in range(7, n, 97):
+        sent[j] = sent[j - 7]
+    u = rs.rand(n)
+    split = np.where(u < 0.66, "train", np.where(u < 0.70, "val", np.where(u < 0.74, "test", "restval"))).astype(object)
+    cocoid = 100000 + rs.permutation(3 * n)[:n]
+    pat = rs.randint(0, 256, (n_cat, image_hw, image_hw, 3)).astype(np.int16)
+    px = np.clip(pat[first] + rs.randint(-64, 65, (n, image_hw, image_hw, 3)), 0, 255).astype(np.uint8)
+    df = pd.DataFrame({"split": split, "filepath": "synthetic", "filename": [f"{c}.jpg" for c in cocoid], "sentence": sent,
+                       "cat_labels": cats, "nouns_int": nouns}, index=cocoid)
+    return df, px
+
+
 def _read_cifar(root, name):
     if name.startswith("cifar100"):
         with open(os.path.join(root, "cifar-100-python", "train"), "rb") as f:
@@ -222,10 +259,24 @@ def get_dataset(name, data_seed, percent_flips=0.40, flip_type="real", data_root
         return full.subset(tr), full.subset(va), full.subset(te)
     if name in ("mscoco", "flickr30k", "mimiccxr_caption", "mmimdb", "cc3m"):
         import pandas as pd
-        df = pd.read_pickle(os.path.join(data_root, "multimodal_mislabel_split.pkl"))
+        pixels = None
+        if str(data_root).startswith("synthetic"):
+            n = int(str(data_root).split(":")[1]) if ":" in str(data_root) else 5000
+            df, pixels = synthetic_caption_frame(n, data_seed)
+        else:
+            df = pd.read_pickle(os.path.join(data_root, "multimodal_mislabel_split.pkl"))
+            # optional pre-decoded images aligned with the frame's rows: uint8 [N,H,W,3] (GPU preprocessing) or
+            # float32 [N,...] (already preprocessed); replaces per-file JPEG decoding
+            if os.path.exists(os.path.join(data_root, "pixels.npy")):
+                pixels = np.load(os.path.join(data_root, "pixels.npy"), mmap_mode="r")
+                assert len(pixels) == len(df), "pixels.npy must have one entry per frame row"
         if "restval" in df.split:      # quirk kept: tests the Series INDEX
             df.loc[df.split == "restval", "split"] = "train"
-        if "path" not in df:
+        if name == "mimiccxr_caption":
+            df = df[df.sentence.str.len() > 0]       # lib/datasets/utils.py:293
+        if pixels is not None:
+            df = df.assign(_row=np.arange(len(df)))
+        elif "path" not in df:
             df["path"] = [os.path.join(data_root, *(p for p in (r.get("filepath", ""), r["filename"]) if p))
                           for _, r in df.iterrows()]
         out = []
@@ -240,7 +291,8 @@ def get_dataset(name, data_seed, percent_flips=0.40, flip_type="real", data_root
             else:
                 raise NotImplementedError(flip_type)
             part = ds.noise_given_dict(part, nd)
-            out.append(ImageLabelSet(list(part["path"]), list(part["gold_sentence"]), list(part["sentence"]), image_size))
+            images = np.ascontiguousarray(pixels[part["_row"].values]) if pixels is not None else list(part["path"])
+            out.append(ImageLabelSet(images, list(part["gold_sentence"]), list(part["sentence"]), image_size))
         return tuple(out)
     if name in ("stanford_cars", "mini_imagenet"):
         import pandas as pd

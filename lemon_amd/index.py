@@ -49,6 +49,10 @@ class _IndexFlat:
     def set_algo(self, algo):
         _lib.check(self._lib.lemon_index_set_algo(self._h, int(algo)), "lemon_index_set_algo")
 
+    def set_query_dedup(self, enabled=True):
+        """Fold identical query rows into one search each (exact; on by default -- see include/lemon_hip.h)."""
+        _lib.check(self._lib.lemon_index_set_query_dedup(self._h, int(bool(enabled))), "lemon_index_set_query_dedup")
+
     def last_search_info(self):
         info = _lib.SearchInfo()
         _lib.check(self._lib.lemon_index_last_search_info(self._h, ctypes.byref(info)), "last_search_info")

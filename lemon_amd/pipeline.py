@@ -36,6 +36,12 @@ def all_gather_rows(t, n_total, group=None):
     per = (n_total + W - 1) // W
     pad = torch.zeros((per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[: t.shape[0]] = t
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal mode only (several ranks on ONE card, LEMON_DIST_BACKEND=gloo: RCCL needs distinct devices):
+        # gloo gathers host buffers, so the shard is staged through the host; the product path is the RCCL branch below
+        host = torch.empty((W * per,) + tuple(t.shape[1:]), dtype=t.dtype)
+        dist.all_gather_into_tensor(host, pad.cpu(), group=group)
+        return host[:n_total].to(t.device)
     out = torch.empty((W * per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, pad, group=group)
     return out[:n_total]

@@ -67,6 +67,11 @@ def build_parser():
     p.add_argument("--encoder_batch", default=512, type=int, help="encoder micro-batch on the GPU")
     p.add_argument("--lbfgs_device", default="cuda", choices=["cuda", "cpu"],
                    help="where the SoftMargin/LBFGS polish of the hyper-parameter search runs (lib/metrics/utils.py:121-149)")
+    p.add_argument("--no_text_dedup", action="store_true",
+                   help="encode every sample's prompt (the reference does) instead of each distinct prompt once")
+    p.add_argument("--embedding_cache", default=None,
+                   help="directory for per-split embedding caches (lemon_amd/cache.py): re-runs with another k / metric / "
+                        "ablation skip the encoder")
     p.add_argument("--hparam_grid", default="full", choices=["full", "small"],
                    help="'small' = 3x3x2x2 grid for smoke runs (reference grid is 21x21x4x4)")
     return p
@@ -87,6 +92,17 @@ class Tee:
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    saved = (sys.stdout, sys.stderr)
+    try:
+        return _run(args)
+    finally:                      # the Tee objects are per run (the reference is a one-shot script; this is a function)
+        for cur, old in ((sys.stdout, saved[0]), (sys.stderr, saved[1])):
+            if isinstance(cur, Tee):
+                cur.file.close()
+        sys.stdout, sys.stderr = saved
+
+
+def _run(args):
     hparams = vars(args)
     out_dir = Path(args.output_dir)
     out_dir.mkdir(exist_ok=True, parents=True)
@@ -107,12 +123,16 @@ def main(argv=None):
     _lib.load()
     if not torch.cuda.is_available():
         raise _lib.LemonHipError("run_lemon needs a HIP device (no CPU fallback for the hot path)")
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % max(torch.cuda.device_count(), 1))     # rehearsals: ranks may share one card
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("LEMON_DIST_BACKEND", "nccl")   # nccl = RCCL over xGMI; gloo only to rehearse on one card
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if rank == 0:
         print("Environment:")
@@ -147,7 +167,9 @@ def main(argv=None):
         rng = np.random.default_rng(args.data_seed)
         val_set = val_set.subset(rng.choice(np.arange(len(val_set)), min(args.subset_val_set, len(val_set)), replace=False))
 
-    embedder = Embedder(model, device, batch_size=args.encoder_batch)
+    # identical prompts are embedded once and gathered (class datasets: C prompts for N samples): the same function
+    # of the input, independent of how samples fall into micro-batches; --no_text_dedup encodes every sample's prompt
+    embedder = Embedder(model, device, batch_size=args.encoder_batch, text_dedup=not args.no_text_dedup)
     prefix = "A photo of a " if args.custom_cifar_prompt is None else args.custom_cifar_prompt
     prompt_fn = lambda x: prefix + x
 
@@ -184,9 +206,21 @@ def main(argv=None):
             return np.asarray(meta["noisy"], dtype=np.int32)
         return np.array([text_ids[p] for p in meta["prompts"]], dtype=np.int32)
 
-    def embed_split(dset):
+    from .cache import EmbeddingCache
+    cache = EmbeddingCache(args.embedding_cache, dataset=args.dataset, noise_type=args.noise_type,
+                           noise_level=args.noise_level, data_seed=args.data_seed, clip_model=args.clip_model,
+                           clip_path=os.path.abspath(args.clip_path) if os.path.exists(str(args.clip_path)) else args.clip_path,
+                           data_root=args.data_root, prompt=args.custom_cifar_prompt, subset_val_set=args.subset_val_set)
+
+    def embed_split(dset, sname):
         """this rank's contiguous shard of a split -> (emb_img, emb_txt, meta) on the device"""
         lo, hi = shard_bounds(len(dset), world, rank)
+        if cache.root:
+            sl = slice(lo, hi)
+            key_prompts = texts_of(dset.noisy[sl], dset.clean[sl])[2]
+            hit = cache.load(sname, lo, hi, key_prompts, device)
+            if hit is not None:
+                return hit
         imgs, toks, meta = [], [], dict(noisy=[], clean=[], noisy_txt=[], clean_txt=[], prompts=[])
         # data chunks of the encoder micro-batch (the reference's --batch_size only sizes its DataLoader batches;
         # per-sample results do not depend on it)
@@ -200,10 +234,12 @@ def main(argv=None):
         e_img = torch.cat(imgs) if imgs else torch.empty((0, d), device=device)
         e_txt = embedder.embed_texts(torch.cat(toks)) if toks else torch.empty((0, d), device=device)
         meta["lo"] = lo
+        if cache.root:
+            cache.store(sname, lo, hi, meta["prompts"], e_img, e_txt, meta)
         return e_img, e_txt, meta
 
     start_t = datetime.now()
-    emb = {"train": embed_split(train_set)}
+    emb = {"train": embed_split(train_set, "train")}
     # DB = train rows listed in train_indices_in_compr, in that order (Subset order, run_lemon.py:124)
     n_train = len(train_set)
     full_img = all_gather_rows(emb["train"][0], n_train)
@@ -227,7 +263,7 @@ def main(argv=None):
     frames = []
     for sname in names:
         if sname not in emb:
-            emb[sname] = embed_split(sets[sname])
+            emb[sname] = embed_split(sets[sname], sname)
         e_img, e_txt, meta = emb[sname]
         nq, lo = e_img.shape[0], meta["lo"]
         rec = db.neighbors(e_img, e_txt, k, drop_self=(sname == "train"),

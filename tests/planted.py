@@ -1,0 +1,74 @@
+"""Product-side twins of the stand-ins tools/make_golden_loop.py gave the REFERENCE run: a planted "CLIP" whose image
+embedding is the vector carried as the pixel tensor and whose text embedding is a table row, and its tokenizer.  With
+them `lemon_amd.run_lemon.main` consumes exactly the inputs the reference's run_lemon.py consumed for a loop fixture."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pandas as pd
+import torch
+
+
+class PlantedCLIP(torch.nn.Module):
+    def __init__(self, txt_table):
+        super().__init__()
+        self.register_buffer("table", torch.from_numpy(np.ascontiguousarray(txt_table)))
+        d = txt_table.shape[1]
+        self.cfg = SimpleNamespace(image_size=1, patch_size=1, embed_dim=d, context_length=8)
+        self.context_length = 8
+
+    def encode_image(self, pixel_values=None):
+        return pixel_values.float().clone()
+
+    def encode_text(self, input_ids=None, attention_mask=None, seq_len=None):
+        return self.table[input_ids[:, 0]].clone()
+
+
+class PlantedTokenizer:
+    def __init__(self, prompt_ids, hf):
+        self.prompt_ids, self.hf = prompt_ids, hf
+
+    def __call__(self, texts, padding=None, truncation=None):
+        ids = [[self.prompt_ids[t], 0] for t in texts]
+        if self.hf:
+            return {"input_ids": ids, "attention_mask": [[1, 0] for _ in ids]}
+        return torch.tensor(ids, dtype=torch.long)
+
+
+def install(case, monkeypatch, tmp_path):
+    """Point lemon_amd.run_lemon at the fixture's planted model / data.  Returns the extra CLI args."""
+    import lemon_amd.clip as clip
+    import lemon_amd.data as data
+    from lemon_amd import datasets as ds
+    fx = case.fx
+    table = fx["txt_table"]
+    if case.is_caption:
+        prompt_ids = {str(c): i for i, c in enumerate(fx["captions"])}
+    else:
+        labels = ds.LABEL_SETS[case.dataset]
+        prompt_ids = {str(fx["prefix"]) + l: i for i, l in enumerate(labels)}
+
+    def factory(name, text_base_name=None, img_base=None, return_tokenizer=False, arch=None, bpe_path=None):
+        model = PlantedCLIP(table)
+        tok = PlantedTokenizer(prompt_ids, hf=(name == "huggingface_clip"))
+        return (model, tok) if return_tokenizer else model
+
+    monkeypatch.setattr(clip, "algorithm_class_from_scratch", factory)
+    root = str(tmp_path / "data")
+    os.makedirs(root, exist_ok=True)
+    if case.is_caption:
+        def unflat(flat, lens):
+            out, p = [], 0
+            for n in lens:
+                out.append([int(v) for v in flat[p:p + n]])
+                p += n
+            return out
+        df = pd.DataFrame({"split": fx["frame_split"].astype(object), "filepath": "synthetic",
+                           "filename": fx["frame_filename"].astype(object), "sentence": fx["frame_sentence"].astype(object),
+                           "cat_labels": unflat(fx["frame_cat_flat"], fx["frame_cat_len"]),
+                           "nouns_int": unflat(fx["frame_noun_flat"], fx["frame_noun_len"])}, index=fx["frame_index"])
+        df.to_pickle(os.path.join(root, "multimodal_mislabel_split.pkl"))
+        np.save(os.path.join(root, "pixels.npy"), fx["img_all"])
+    else:
+        monkeypatch.setattr(data, "_read_cifar", lambda r, n: (fx["img_all"], fx["y_all"]))
+    return ["--data_root", root, "--clip_path", "planted"]

@@ -58,3 +58,45 @@ def test_cli_cat_noise_on_cifar_raises(hip, tmp_path):
     with pytest.raises(NotImplementedError):
         main(["--output_dir", str(tmp_path / "x"), "--dataset", "cifar100", "--noise_type", "cat",
               "--data_root", "synthetic:200", "--clip_path", "random:tiny", "--debug"])
+
+
+@pytest.mark.parametrize("discrete", [False, True])
+def test_cli_synthetic_mscoco_cat_noise_matches_oracle(hip, oracle, tmp_path, discrete):
+    """BASELINE configs[2] plumbing offline: mscoco surface, noise_type cat, caption-side text kNN, DB = random subset
+    smaller than train (mixed in_db), tiny random CLIP.  The per-sample records of res.pkl must equal the oracle's on the
+    embeddings the run itself cached (--embedding_cache), incl. the reference's DB-subset draw."""
+    import glob
+    import pickle
+    from lemon_amd.run_lemon import main
+    out, cache = str(tmp_path / "run"), str(tmp_path / "cache")
+    argv = ["--output_dir", out, "--dataset", "mscoco", "--noise_type", "cat", "--noise_level", "0.4", "--data_root",
+            "synthetic:3000", "--clip_path", "random:tiny", "--knn_k", "5", "--compr_dataset_size_limit", "800",
+            "--skip_hparam_optim", "--embedding_cache", cache, "--seed", "4"] + (["--use_discrete_for_text"] if discrete else [])
+    assert main(argv) == 0
+    df = pickle.load(open(os.path.join(out, "res.pkl"), "rb"))["df"]
+    emb = {}
+    for d_ in glob.glob(os.path.join(cache, "*")):
+        meta = pickle.load(open(os.path.join(d_, "meta.pkl"), "rb"))
+        emb[len(meta["prompts"])] = (np.load(os.path.join(d_, "img.npy")), np.load(os.path.join(d_, "txt.npy")), meta)
+    n_tr = (df.sset == "train").sum()
+    assert n_tr > 1500 and 0.3 < df[df.sset == "train"].is_mislabel.mean() < 0.45
+    np.random.seed(4)
+    sel = np.random.choice(np.arange(n_tr), 800, replace=False)                # run_lemon.py:81,123
+    img_tr, txt_tr, meta_tr = emb[n_tr]
+    vocab = {}
+    ids = lambda prompts: np.array([vocab.setdefault(p, len(vocab)) for p in prompts], np.int32)
+    tr_ids = ids(meta_tr["prompts"])
+    for s in ("train", "val", "test"):
+        sub = df[df.sset == s]
+        q_img, q_txt, meta = emb[len(sub)]
+        in_db = np.isin(np.arange(len(sub)), sel).astype(np.uint8) if s == "train" else None
+        ref = oracle.neighbors("cosine", img_tr[sel], txt_tr[sel], q_img, q_txt, 5, drop_self=(s == "train"), in_db=in_db,
+                               discrete=discrete, tr_label_id=tr_ids[sel], q_label_id=ids(meta["prompts"]))
+        for col in ("D_n", "dists_n", "dists_tr_n", "D_m", "dists_m", "dists_tr_m"):
+            assert np.array_equal(np.stack(sub[col].values), ref[col]), (s, col)
+        assert np.array_equal(sub["d_1"].values.astype(np.float32), ref["d_1"])
+    # a second run re-uses the cache (no encoder) and reproduces the records bit for bit
+    out2 = str(tmp_path / "run2")
+    assert main([a if a != out else out2 for a in argv]) == 0
+    df2 = pickle.load(open(os.path.join(out2, "res.pkl"), "rb"))["df"]
+    assert all(np.array_equal(np.stack(df[c].values), np.stack(df2[c].values)) for c in ("D_n", "dists_m", "dists_tr_n"))

@@ -1,0 +1,59 @@
+"""GPU: the sharded PRODUCT path (HIP kernels, not the oracle) with two rank processes sharing cuda:0
+(LEMON_DIST_BACKEND=gloo; RCCL itself needs distinct devices, the driver's 8-GPU run covers that): run_lemon's
+WORLD_SIZE>1 branch -- contiguous shards, all_gather_rows of the DB shards / label ids / per-sample records, in_db offsets,
+all_gather_object of the metadata -- must reproduce the single-process run bit for bit, and both must match the
+REFERENCE's own run recorded in the loop fixture.  SURVEY 8e steps 1-4."""
+import os
+import pickle
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.loopfx import REC, LoopCase
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(case, out_dir, data_dir, world):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LEMON_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if world == 1:
+            for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k_)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), case, out_dir, data_dir],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+    return pickle.load(open(os.path.join(out_dir, "res.pkl"), "rb"))["df"]
+
+
+@pytest.mark.parametrize("case", ["c10_cos_k5_subset", "coco_l2_k5_random_discrete", "c10_l2_k50_subset_discrete"])
+def test_two_ranks_on_one_card_equal_one_rank_and_the_reference(hip, case, tmp_path):
+    c = LoopCase(case)
+    df1 = _launch(case, str(tmp_path / "w1"), str(tmp_path / "d1"), 1)
+    df2 = _launch(case, str(tmp_path / "w2"), str(tmp_path / "d2"), 2)
+    assert len(df1) == len(df2) and list(df1.columns) == list(df2.columns)
+    for col in ("sset", "idx", "is_mislabel", "noisy_label_text", "actual_label_text"):
+        assert (df1[col].values == df2[col].values).all(), col
+    assert np.array_equal(df1["d_1"].values, df2["d_1"].values)
+    for col in REC:
+        assert np.array_equal(np.stack(df1[col].values), np.stack(df2[col].values)), col   # bit-identical across shardings
+    for s in c.ssets:                                                                        # and == the reference's run
+        sub = df2[df2.sset == s]
+        exp = c.expected(s)
+        for col in REC + ("d_1",):
+            got = np.stack(sub[col].values) if col != "d_1" else sub[col].values
+            assert np.abs(got.astype(np.float64) - exp[col]).max() <= 2e-6, (s, col)

@@ -1,0 +1,171 @@
+"""GPU: the fused encoder path (lemon_linear_f32 epilogues, lemon_attention_f32, pooled-row last block, patch-embedding
+GEMM, QuickGELU composed from SiLU) at REAL widths against reference-side modules on the CPU:
+  * HF transformers CLIPModel -- the class the reference wraps (lib/models/downstream_models.py:30-41) -- with identical
+    seeded weights, for the three architectures BASELINE.json names (ViT-B/32, ViT-B/16, ViT-L/14);
+  * the reference's in-tree CLIP (lib/models/chexzero_clip.py) through tests/golden/encoder_chexzero.npz;
+  * tier B: CPU-HF embeddings -> oracle scores vs GPU embeddings -> HIP scores, AUROC to 3 decimals."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ARCH = {
+    "vit-b-32": dict(projection_dim=512, v=(768, 12, 12, 3072, 32), t=(512, 12, 8, 2048)),
+    "vit-b-16": dict(projection_dim=512, v=(768, 12, 12, 3072, 16), t=(512, 12, 8, 2048)),
+    "vit-l-14": dict(projection_dim=768, v=(1024, 24, 16, 4096, 14), t=(768, 12, 12, 3072)),
+}
+
+
+def hf_model(arch, seed=0):
+    from transformers import CLIPConfig, CLIPModel
+    a = ARCH[arch]
+    cfg = CLIPConfig(projection_dim=a["projection_dim"],
+                     vision_config=dict(hidden_size=a["v"][0], num_hidden_layers=a["v"][1], num_attention_heads=a["v"][2],
+                                        intermediate_size=a["v"][3], image_size=224, patch_size=a["v"][4]),
+                     text_config=dict(hidden_size=a["t"][0], num_hidden_layers=a["t"][1], num_attention_heads=a["t"][2],
+                                      intermediate_size=a["t"][3], vocab_size=49408, max_position_embeddings=77,
+                                      eos_token_id=2, bos_token_id=0, pad_token_id=1))     # legacy ids => argmax EOT pooling
+    torch.manual_seed(seed)
+    hf = CLIPModel(cfg).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for name, p in hf.named_parameters():
+            if p.dim() >= 2:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g) * (0.02 if "embedding" in name else fan_in ** -0.5))
+            elif "norm" in name and name.endswith("weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
+    return hf
+
+
+def _unwrap(o):
+    return o if torch.is_tensor(o) else o.pooler_output
+
+
+def ragged_ids(n, ctx, vocab, seed):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(1, vocab - 2, (n, ctx), generator=g)
+    lens = [ctx, 3, 8, 9] + [int(v) for v in torch.randint(4, ctx, (max(n - 4, 0),), generator=g)]
+    mask = torch.zeros(n, ctx, dtype=torch.long)
+    for i, L in enumerate(lens[:n]):
+        ids[i, 0] = vocab - 2
+        ids[i, L - 1] = vocab - 1
+        ids[i, L:] = 0
+        mask[i, :L] = 1
+    return ids, mask
+
+
+@pytest.mark.parametrize("arch", ["vit-b-32", "vit-b-16", "vit-l-14"])
+def test_fused_gpu_encoder_vs_hf_clip_at_full_size(hip, arch):
+    from lemon_amd.clip import ClipConfig, LemonCLIP
+    from lemon_amd.data import gpu_transform_batch
+    from lemon_amd.ops import normalize_vectors
+    hf = hf_model(arch)
+    cfg = ClipConfig.named(arch)
+    ours = LemonCLIP(cfg).load_hf_state_dict(hf.state_dict()).eval().cuda()
+    n_img = 3 if arch == "vit-l-14" else 6
+    u8 = torch.randint(0, 256, (n_img, 48, 40, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(5)).cuda()
+    px = gpu_transform_batch(u8, 224)                                  # NCHW float (bit-identical to PIL, tested elsewhere)
+    patches = gpu_transform_batch(u8, 224, patch=cfg.patch_size)       # patch-major: the bench / run_lemon input form
+    ids, mask = ragged_ids(7, 77, 49408, seed=3)
+    with torch.no_grad():
+        ref_img = _unwrap(hf.get_image_features(pixel_values=px.cpu()))
+        ref_txt = _unwrap(hf.get_text_features(input_ids=ids, attention_mask=mask))
+    got_nchw = ours.encode_image(px).cpu()
+    got_patch = ours.encode_image(patches).cpu()
+    got_txt = ours.encode_text(ids.cuda(), mask.cuda()).cpu()
+    scale_i, scale_t = float(ref_img.abs().max()), float(ref_txt.abs().max())
+    for name, got, ref, sc in (("nchw", got_nchw, ref_img, scale_i), ("patch-major", got_patch, ref_img, scale_i),
+                               ("text", got_txt, ref_txt, scale_t)):
+        d = float((got - ref).abs().max())
+        assert d <= 1e-4 * max(1.0, sc), f"{arch}/{name}: raw max abs diff {d} (scale {sc})"
+        dn = float((torch.nn.functional.normalize(got, dim=1) - torch.nn.functional.normalize(ref, dim=1)).abs().max())
+        assert dn <= 5e-6, f"{arch}/{name}: normalised max abs diff {dn}"
+    # the product's own normalisation kernel on the GPU embeddings
+    nn_ = normalize_vectors(ours.encode_text(ids.cuda())).cpu()
+    assert float((nn_ - torch.nn.functional.normalize(ref_txt, dim=1)).abs().max()) <= 5e-6
+
+
+@pytest.mark.parametrize("name", ["small_hd64", "scratch_b16_77"])
+def test_fused_gpu_encoder_vs_reference_in_tree_clip(hip, name):
+    from tests.encoder_recipe import CONFIGS, inputs, lemon_clip_from_recipe
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "encoder_chexzero.npz"))
+    m = lemon_clip_from_recipe(name).cuda()
+    px, ids = inputs(CONFIGS[name])
+    gi, gt = m.encode_image(px.cuda()).cpu().numpy(), m.encode_text(ids.cuda()).cpu().numpy()
+    ri, rt = fx[f"{name}_img"], fx[f"{name}_txt"]
+    assert np.abs(gi - ri).max() <= 1e-4 * max(1.0, np.abs(ri).max()), np.abs(gi - ri).max()
+    assert np.abs(gt - rt).max() <= 1e-4 * max(1.0, np.abs(rt).max()), np.abs(gt - rt).max()
+
+
+def test_tier_b_cpu_hf_embeddings_vs_gpu_pipeline(hip, oracle):
+    """2 048 planted CIFAR-shaped samples: HF CLIPModel (CPU) embeddings -> oracle neighbours/scores, against the same
+    images and prompts through the GPU pipeline (preprocess + fused encoder + HIP kNN/score).  Reports max |dscore| and
+    the fraction of samples whose neighbour set changed; AUROC must agree to 3 decimals for d_1 alone and for the fixed
+    hyper-parameters (SURVEY 8d metric (i), (ii))."""
+    from lemon_amd import datasets as ds
+    from lemon_amd.clip import ClipConfig, LemonCLIP, SyntheticTokenizer
+    from lemon_amd.data import gpu_transform_batch
+    from lemon_amd.pipeline import Embedder, FIXED_HPARAMS, run_hot_path
+    arch = "vit-b-32"
+    hf = hf_model(arch, seed=4)
+    cfg = ClipConfig.named(arch)
+    ours = LemonCLIP(cfg).load_hf_state_dict(hf.state_dict())
+    dev = torch.device("cuda", 0)
+    n_tr, n_q, C, k = 1792, 256, 10, 5
+    rng = np.random.default_rng(0)
+    pat = rng.integers(0, 256, (C, 32, 32, 3)).astype(np.int16)
+    tok = SyntheticTokenizer(cfg.vocab_size, cfg.context_length, cfg.eos_token_id)
+    class_ids = torch.tensor(tok(["A photo of a " + l for l in ds.cifar10_labels])["input_ids"])
+    data, clean_noisy = {}, {}
+    for name, n in (("train", n_tr), ("val", n_q)):
+        clean = rng.integers(0, C, n)
+        noisy = np.where(rng.random(n) < 0.4, (clean + 1) % C, clean)
+        u8 = np.clip(pat[clean] + rng.integers(-48, 49, (n, 32, 32, 3)), 0, 255).astype(np.uint8)
+        data[name] = dict(pixels=torch.from_numpy(u8).to(dev), ids=class_ids[torch.from_numpy(noisy)].to(dev),
+                          label_id=torch.from_numpy(noisy.astype(np.int32)).to(dev))
+        clean_noisy[name] = (clean, noisy)
+    # text_dedup: each distinct prompt is embedded once and gathered, as the CPU side below does.  (Without it the same
+    # prompt embedded in micro-batches of different row counts can differ in the last bit -- another GEMM solution --
+    # which changes WHICH of the tied text-side neighbours are picked; the reference's batch-of-128 loop has the
+    # same property.)
+    emb = Embedder(ours, dev, batch_size=256, text_dedup=True)
+    recs, db = run_hot_path(emb, data, k=k, dist_type="cosine", hparams=FIXED_HPARAMS)
+    torch.cuda.synchronize()
+
+    # reference side: HF on the CPU, same pixels (the GPU transform is bit-identical to PIL + torch), same prompts
+    ref = {}
+    with torch.no_grad():
+        cls_txt = _unwrap(hf.get_text_features(input_ids=class_ids, attention_mask=(class_ids != 0).long()))
+        for name in ("train", "val"):
+            outs = []
+            for i in range(0, data[name]["pixels"].shape[0], 128):
+                px = gpu_transform_batch(data[name]["pixels"][i:i + 128], 224).cpu()
+                outs.append(_unwrap(hf.get_image_features(pixel_values=px)))
+            img = oracle.normalize_rows(torch.cat(outs).numpy())
+            txt = oracle.normalize_rows(cls_txt[torch.from_numpy(clean_noisy[name][1])].numpy())
+            ref[name] = (img, txt)
+    out = oracle.neighbors("cosine", ref["train"][0], ref["train"][1], ref["val"][0], ref["val"][1], k)
+    s_ref = oracle.score(out, FIXED_HPARAMS)
+    s_gpu = recs["val"]["score"].cpu().numpy()
+    y = clean_noisy["val"][0] != clean_noisy["val"][1]
+    d_emb = np.abs(recs["val"]["emb_img"].cpu().numpy() - ref["val"][0]).max()
+    ch_n = (np.sort(recs["val"]["I_n"].cpu().numpy(), 1) != np.sort(out["I_n"], 1)).any(1)
+    ch_m = (np.sort(recs["val"]["I_m"].cpu().numpy(), 1) != np.sort(out["I_m"], 1)).any(1)
+    same = ~(ch_n | ch_m)
+    dscore = float(np.abs(s_gpu - s_ref).max())
+    dscore_same = float(np.abs(s_gpu - s_ref)[same].max())
+    print(f"tier-B: max|d emb|={d_emb:.2e}  max|d score|={dscore:.2e} (same neighbour sets: {dscore_same:.2e})  "
+          f"neighbour sets changed: image {ch_n.mean():.4f} text {ch_m.mean():.4f}")
+    assert d_emb <= 5e-6
+    assert dscore_same <= 1e-4                       # north_star: scores within 1e-4 where the index sets agree
+    assert ch_n.mean() <= 0.02 and ch_m.mean() <= 0.02
+    a = lambda s: round(oracle.auroc(y, s), 3)
+    assert a(recs["val"]["d_1"].cpu().numpy()) == a(out["d_1"])
+    assert a(s_gpu) == a(s_ref)
+    assert oracle.auroc(y, s_ref) > 0.6          # planted structure: the check is informative

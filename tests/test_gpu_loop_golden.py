@@ -1,0 +1,84 @@
+"""GPU: the HIP path against fixtures produced by the REFERENCE's own run_lemon.py loop (tools/make_golden_loop.py).
+
+  * lemon_neighbors (through LemonDB.neighbors / the C ABI) on the reference's normalised embeddings == the reference's
+    per-sample arrays: index sets and D bit-exact, torch-reduced floats within 1e-6;
+  * `lemon_amd.run_lemon.main` with the same CLI flags and the same planted model / data == the reference run's
+    DataFrame (split order, record schema, labels, is_mislabel, DB subset draw) and, where the hyper-parameter search
+    ran, its agg_results (AUROC to 3 decimals, north_star)."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from tests.loopfx import REC, LoopCase, assert_records_match, case_names
+
+pytestmark = pytest.mark.gpu
+CASES = case_names()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_lemon_neighbors_equals_reference_loop(hip, name):
+    from lemon_amd import ops
+    from lemon_amd.neighbors import LemonDB
+    c = LoopCase(name)
+    db_img, db_txt = c.db()
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for s in c.ssets:
+        q_img, q_txt = c.queries(s)
+        tr_lab, q_lab = c.label_ids(s) if c.discrete else (None, None)
+        db = LemonDB(t(db_img), t(db_txt), c.metric, tr_label_id=tr_lab)
+        rec = db.neighbors(t(q_img), t(q_txt), c.k, drop_self=(s == "train"), in_db=c.in_db(s), discrete=c.discrete,
+                           q_label_id=q_lab)
+        if c.normalize_d1:
+            rec["d_1"] = ops.d1_normalized(c.metric, t(q_img), t(c.fx["cls_txt"]), t(c.fx[f"{s}_noisy"].astype(np.int32)))
+        got = {k_: v.cpu().numpy() for k_, v in rec.items()}
+        assert_records_match(got, c, s)
+        assert np.abs(db.dists_tr.cpu().numpy() - c.fx["dists_tr"]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_run_lemon_cli_reproduces_reference_run(hip, name, monkeypatch, tmp_path):
+    from lemon_amd.run_lemon import main
+    from tests import planted
+    c = LoopCase(name)
+    extra = planted.install(c, monkeypatch, tmp_path)
+    out = str(tmp_path / "out")
+    np.random.seed(12345)                 # main() must reseed: the DB subset draw depends on it
+    assert main(["--output_dir", out] + c.argv + extra) == 0
+    assert sorted(f for f in os.listdir(out)) == sorted(str(f) for f in c.fx["out_files"])
+    res = pickle.load(open(os.path.join(out, "res.pkl"), "rb"))
+    df = res["df"]
+    assert list(df.sset.unique()) == c.ssets                                  # split order train -> val -> test
+    for s in c.ssets:
+        sub = df[df.sset == s]
+        n = len(c.fx[f"{s}_d_1"])
+        assert len(sub) == n and np.array_equal(sub["idx"].values, np.arange(n))
+        assert np.array_equal(sub["is_mislabel"].values.astype(np.int64), c.fx[f"{s}_is_mislabel"])
+        assert [str(v) for v in sub["noisy_label_text"]] == [str(v) for v in c.fx[f"{s}_noisy_text"]]
+        assert [str(v) for v in sub["actual_label_text"]] == [str(v) for v in c.fx[f"{s}_clean_text"]]
+        if not c.is_caption:
+            assert np.array_equal(np.array([int(v) for v in sub["noisy_label"]]), c.fx[f"{s}_noisy"])
+            assert np.array_equal(np.array([int(v) for v in sub["actual_label"]]), c.fx[f"{s}_clean"])
+        got = {col: np.stack(sub[col].values) for col in REC}
+        got["d_1"] = sub["d_1"].values
+        exp = c.expected(s)
+        # embeddings are normalised by OUR kernel here (float64 accumulation vs torch's float32 reduction: last-ulp
+        # differences in the DB rows), so everything is compared at 1e-6 and neighbour sets through dists_tr / D
+        for col in REC + ("d_1",):
+            assert got[col].shape == exp[col].shape and got[col].dtype == exp[col].dtype, (name, s, col)
+            d = np.abs(got[col].astype(np.float64) - exp[col]).max()
+            assert d <= 2e-6, f"{name}/{s}/{col}: {d}"
+    if c.agg is not None:
+        agg = res["agg_results"]["know_val_labels"]
+        for s in c.ssets:
+            assert abs(agg[s]["AUROC"] - c.agg[s]["AUROC"]) < 5e-4, (name, s, agg[s]["AUROC"], c.agg[s]["AUROC"])
+        if "selected_val" in c.agg:
+            assert abs(agg["selected_val"] - c.agg["selected_val"]) < 2e-3, (agg["selected_val"], c.agg["selected_val"])
+        ref_score = c.fx["pred_score"]
+        hp_same = all(abs(float(agg[h]) - c.agg[h]) < 1e-9 for h in ("beta", "gamma", "tau_1_n", "tau_2_n", "tau_1_m", "tau_2_m"))
+        if hp_same:
+            assert np.abs(df["know_val_labels_pred_score"].values - ref_score).max() < 1e-4

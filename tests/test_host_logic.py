@@ -134,16 +134,49 @@ def test_host_inputs_are_refused_without_gpu_fallback():
         ops.normalize_vectors(np.zeros((3, 4), np.float32))
 
 
-def test_gemm_tuning_results_file_is_well_formed():
-    # lemon_amd/tuning.py: recorded hipBLASLt solutions for the headline encoder shapes
-    from lemon_amd import tuning
-    lines = [l.strip().split(",") for l in open(tuning.RESULTS) if l.strip()]
-    validators = {l[1]: l[2] for l in lines if l[0] == "Validator"}
-    assert validators.get("GCN_ARCH_NAME", "").startswith("gfx950")
-    ops = [l for l in lines if l[0] != "Validator"]
-    assert ops and all(len(l) == 4 and l[0].startswith("Gemm") and float(l[3]) > 0 for l in ops)
-    keys = {l[1] for l in ops}
-    assert "tn_2304_50000_768_ld_768_768_2304" in keys      # ViT-B/32 QKV projection at encoder batch 1000
+def test_linear_results_file_is_stamped_and_well_formed():
+    # lemon_amd/data/linear_gfx950.csv: recorded hipBLASLt solutions (written by tools/tune_gemms.py on an MI355X).  The
+    # stamp line ties it to a hipBLASLt version + arch; lemon_linear_load_tuned ignores the file on a mismatch.
+    import re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lemon_amd", "data", "linear_gfx950.csv")
+    lines = [l.strip() for l in open(path) if l.strip()]
+    assert re.fullmatch(r"# lemon_linear hipblaslt=\d+ arch=gfx950", lines[0]), lines[0]
+    rows = [l.split(",") for l in lines if not l.startswith("#")]
+    assert rows and all(len(r) == 7 for r in rows)
+    keys = {tuple(int(v) for v in r[:5]) for r in rows}
+    assert len(keys) == len(rows)                                   # one solution per (m,n,k,epilogue,residual)
+    assert any(k[1:3] == (2304, 768) for k in keys)                 # ViT-B/32 QKV projection
+
+
+def test_maximize_metric_survives_a_diverging_lbfgs_candidate():
+    """On embeddings WITHOUT CLIP's modality gap (paired image-text cosine ~0.9, so dists_tr ~0.1 and D = -cos ~ -0.9) the
+    SoftMargin proxy of lib/metrics/utils.py:121-149 overflows from the start point [10]*6: LBFGS returns NaN and the
+    reference itself dies in fminbound ("Optimization bounds must be finite scalars" -- observed when
+    tools/make_golden_loop.py first ran the reference on such data).  Our search skips the non-finite candidate
+    (metrics.py, documented divergence) and still returns the grid / scipy optimum."""
+    import torch
+    from lemon_amd import metrics as M
+    rs = np.random.RandomState(0)
+    n, k = 120, 5
+    y = (rs.rand(n) < 0.4).astype(np.int64)
+    rec = {"d_1": (0.1 + 0.05 * rs.rand(n) + 0.05 * y).astype(np.float64),
+           "D_n": -(0.85 + 0.1 * rs.rand(n, k)).astype(np.float32), "dists_tr_n": (0.05 + 0.1 * rs.rand(n, k)).astype(np.float32),
+           "dists_n": (0.3 * rs.rand(n, k) + 0.3 * y[:, None]).astype(np.float32),
+           "D_m": -(0.85 + 0.1 * rs.rand(n, k)).astype(np.float32), "dists_tr_m": (0.05 + 0.1 * rs.rand(n, k)).astype(np.float32),
+           "dists_m": (0.3 * rs.rand(n, k) + 0.3 * y[:, None]).astype(np.float32)}
+    rec_t = {k_: torch.as_tensor(v, dtype=torch.float64 if k_ == "d_1" else torch.float32) for k_, v in rec.items()}
+    cand = M._torch_lbfgs(rec_t, y, [10.0] * 6, (), ())
+    assert not np.all(np.isfinite(cand))                            # the proxy really diverges on this frame
+
+    def score_fn(hp):
+        sn = np.exp(-hp["tau_1_n"] * rec["D_n"]) * np.exp(-hp["tau_2_n"] * rec["dists_tr_n"])
+        sm = np.exp(-hp["tau_1_m"] * rec["D_m"]) * np.exp(-hp["tau_2_m"] * rec["dists_tr_m"])
+        return rec["d_1"] + hp["beta"] * (sn * rec["dists_n"]).mean(1) + hp["gamma"] * (sm * rec["dists_m"]).mean(1)
+
+    grid = {"beta": [0, 5], "gamma": [0, 5], "tau_1": [0, 1], "tau_2": [0, 5]}
+    best_x, best_val, thres = M.maximize_metric(score_fn, y, grid, [[0] * 6, [10] * 6], M.optimize_f1_efficient, {},
+                                                scipy_methods=("Nelder-Mead",), rec_for_lbfgs=rec)
+    assert np.all(np.isfinite(best_x)) and np.isfinite(thres) and 0.5 < best_val <= 1.0
 
 
 @pytest.mark.parametrize("h,w,oh,ow", [(32, 32, 224, 224), (48, 64, 224, 298), (300, 200, 336, 224), (500, 375, 298, 224),

@@ -1,10 +1,12 @@
 """Regenerate lemon_amd/data/linear_gfx950.csv on an MI355X: one pass of the encoder workload with
-lemon_linear_f32 benchmarking every GEMM key it meets, then dump the winners.
+lemon_linear_f32 in tuning mode (benchmarking every GEMM key it meets), then dump the winners with the
+hipBLASLt-version / arch stamp the loader checks.
 Run via gpurun: python tools/tune_gemms.py [arch[:batch] ...] -> gpurun_out/linear_gfx950.csv"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("LEMON_LINEAR_TUNE_MS", "20000")
+os.environ.setdefault("LEMON_LINEAR_TUNE_MS", "6000")
 os.environ["LEMON_LINEAR_TUNED"] = ""          # start from scratch
+os.environ["LEMON_LINEAR_TUNE"] = "1"          # the explicit OFFLINE tuning mode (never on in the inference path)
 from lemon_amd import datasets as ds
 from lemon_amd.clip import ClipConfig, LemonCLIP, SyntheticTokenizer
 from lemon_amd.ops import linear_dump_tuned
