@@ -78,6 +78,13 @@ int lemon_d1_normalized(int metric, const float *q_img_dev, int64_t n, int d,
                         const float *cls_txt_dev, int C, const int32_t *noisy_label_dev,
                         float *d1_dev, void *stream);
 
+/* Zero-shot "CLIP logits" baseline, lib/baselines/train_zero_shot_clip_baseline.py:207-224: per image,
+ * conf[i] = softmax_c(1 - dist(cls_txt_c, img_i))[noisy_label[i]] with dist = DistanceEvaluator.our_metric
+ * (lib/metrics/distance_metrics.py:48-73) on UN-normalised embeddings: kind 0 = 1 - cosine similarity,
+ * 1 = euclidean (not squared), 2 = manhattan.  img_dev [n,d], cls_txt_dev [C,d], C <= 1024. */
+int lemon_class_confidence(int kind, const float *img_dev, int64_t n, int d, const float *cls_txt_dev, int C,
+                           const int32_t *noisy_label_dev, float *conf_dev, void *stream);
+
 /* generic_transform (lib/datasets/utils.py:159-170: Resize(224, BICUBIC) -> CenterCrop(224) -> ToTensor ->
  * Normalize) for a batch of equally sized uint8 HWC images, bit-identical to PIL + torch: the two integer
  * resampling passes of PIL (22-bit fixed-point taps, horizontal then vertical, clip8) and (v/255-mean)/std.

@@ -36,6 +36,24 @@ def clip_similarity(first_modality_embeddings, second_modality_embeddings, dist=
     return our_metric(first_modality_embeddings, second_modality_embeddings, dist)
 
 
+def clip_logits_confidence(img_embeds, class_text_embeds, noisy_label, dist="cosine"):
+    """Zero-shot CLIP-logits baseline (lib/baselines/train_zero_shot_clip_baseline.py:207-224): for every image the
+    softmax over ALL class prompts of 1 - our_metric(text_c, image), read at the image's noisy label -> confidence [n]
+    (float32 CUDA; low confidence = likely mislabelled).  Embeddings are taken un-normalised, as the baseline does."""
+    kind = {"cosine": 0, "euclidean": 1, "manhattan": 2}.get(dist)
+    if kind is None:
+        raise NotImplementedError(dist)
+    q, c = dev_f32(img_embeds, "img_embeds"), dev_f32(class_text_embeds, "class_text_embeds")
+    assert q.dim() == 2 and c.dim() == 2 and q.shape[1] == c.shape[1]
+    lab = torch.as_tensor(noisy_label).to(device=q.device, dtype=torch.int32).contiguous()
+    out = torch.empty(q.shape[0], dtype=torch.float32, device=q.device)
+    lib = _lib.load()
+    with torch.cuda.device(q.device):
+        _lib.check(lib.lemon_class_confidence(kind, ptr(q), q.shape[0], q.shape[1], ptr(c), c.shape[0], ptr(lab), ptr(out),
+                                              stream_ptr(q.device)), "lemon_class_confidence")
+    return out
+
+
 def cos_distance_topk(features, k):
     """values, indices of the k smallest cosine distances of every row to all rows (self included), as
     `cosDistance(features).topk(k, largest=False, sorted=True)` (lib/metrics/utils.py:198-212) without

@@ -144,6 +144,37 @@ struct PairSlots {
         }
         return t;
     }
+    // Maintenance only needs a LOWER BOUND of the kk-th key that keeps the list short: bisect the score word from the
+    // top and stop at the first prefix with kk <= #{score word >= prefix} <= kk + slack (typically ~14 of the 32 steps:
+    // sign + exponent are shared, a few mantissa bits separate ~150 candidates).  Everything >= the prefix survives.
+    // Only when the score word cannot separate them (exact duplicates at the kk-th score) the exact 64-bit key is found.
+    __device__ __forceinline__ u64 kth_loose(int kk, int slack) const {
+        u32 th_hi = 0;
+        int c_hi = 0x7fffffff;
+#pragma unroll 1
+        for (int bit = 31; bit >= 0; --bit) {
+            const u32 cand = th_hi | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) c += __builtin_popcountll(__ballot((u32)(v[i] >> 32) >= cand));
+            if (c >= kk) {                              // wave-uniform
+                th_hi = cand; c_hi = c;
+                if (c <= kk + slack) break;
+            }
+        }
+        u64 t = (u64)th_hi << 32;
+        if (c_hi > kk + slack) {                        // tie at the kk-th score word: refine on the index word
+#pragma unroll 1
+            for (int bit = 31; bit >= 0; --bit) {
+                const u64 cand = t | (1ull << bit);
+                int c = 0;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) c += __builtin_popcountll(__ballot(v[i] >= cand));
+                if (c >= kk) t = cand;
+            }
+        }
+        return t;
+    }
     // survivors (key >= t, non-empty) packed to dst[0..) in arbitrary order; returns their count
     __device__ __forceinline__ int compact(u64 *__restrict__ dst, u64 t, int lane) const {
         const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -159,22 +190,24 @@ struct PairSlots {
     }
 };
 
-// maintenance: keep the kk largest keys packed at the front of half-list 0; returns the kk-th largest.
-// Needs n0 + n1 >= kk.
+// maintenance: keep the best keys -- at least the kk largest, at most kk + SELECT_SLACK unless the kk-th score is
+// tied -- packed at the front of half-list 0; returns a lower bound t of the kk-th largest key (every key >= t was
+// kept) and the number kept in *kept.  Needs n0 + n1 >= kk.
+constexpr int SELECT_SLACK = 24;
 template <int NS>
-__device__ __forceinline__ u64 pair_select_ns(u64 *__restrict__ list, int n0, int n1, int s0, int kk, int lane) {
+__device__ __forceinline__ u64 pair_select_ns(u64 *__restrict__ list, int n0, int n1, int s0, int kk, int lane, int *kept) {
     PairSlots<NS> ps;
     ps.load(list, n0, n1, s0, lane);
-    const u64 t = ps.kth(kk);
-    ps.compact(list, t, lane);                          // all loads above precede these stores
+    const u64 t = ps.kth_loose(kk, SELECT_SLACK);
+    *kept = ps.compact(list, t, lane);                  // all loads above precede these stores
     return t;
 }
-__device__ __forceinline__ u64 pair_select_exact(u64 *__restrict__ list, int n0, int n1, int kk, int lane) {
+__device__ __forceinline__ u64 pair_select_loose(u64 *__restrict__ list, int n0, int n1, int kk, int lane, int *kept) {
     const int s0 = (n0 + 63) >> 6, ns = s0 + ((n1 + 63) >> 6);   // wave-uniform
-    if (ns <= 2) return pair_select_ns<2>(list, n0, n1, s0, kk, lane);
-    if (ns == 3) return pair_select_ns<3>(list, n0, n1, s0, kk, lane);
-    if (ns == 4) return pair_select_ns<4>(list, n0, n1, s0, kk, lane);
-    return pair_select_ns<8>(list, n0, n1, s0, kk, lane);
+    if (ns <= 2) return pair_select_ns<2>(list, n0, n1, s0, kk, lane, kept);
+    if (ns == 3) return pair_select_ns<3>(list, n0, n1, s0, kk, lane, kept);
+    if (ns == 4) return pair_select_ns<4>(list, n0, n1, s0, kk, lane, kept);
+    return pair_select_ns<8>(list, n0, n1, s0, kk, lane, kept);
 }
 
 // final: the best kk keys of a pair list, sorted: lane's return value is one surviving key (0 = none)

@@ -6,8 +6,9 @@
 // ascending k, which is bit-for-bit the float32 fmaf chain of the numeric contract, so the
 // scores (and therefore the selected sets, given the index tie rule) are identical to the CPU
 // oracle's.  Selection is fused into the tile epilogue: an accumulator element that beats the
-// query's current k-th best is appended to that query's candidate list (LDS counter, L2-resident
-// list); lists are compacted to the best k by one wavefront whenever they could overflow.
+// query's current admission threshold (a lower bound of its k-th best score, kept in a VGPR) is appended to the
+// owning lane's private half of that query's candidate list (count in a VGPR, list L2-resident: one predicated
+// global store, no atomics, no LDS); a list is re-selected by one wavefront when it has grown by ~96 entries.
 //
 // Roofline: dense contraction, 2*nq*n*d flop on the fp32 MFMA pipe (157 TFLOP/s dense peak);
 // HBM traffic is one database stream per resident "generation" of workgroups.
@@ -255,11 +256,12 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
                     todo &= todo - 1;
                     u64 *list = cand_panel + (int64_t)(32 * wave + r) * PAIR_CAP;
                     const int n0 = __builtin_amdgcn_readlane(ccnt, r), n1 = __builtin_amdgcn_readlane(ccnt, r + 32);
-                    const u64 kth = pair_select_exact(list, n0, n1, p.kk, lane);
+                    int kept;
+                    const u64 kth = pair_select_loose(list, n0, n1, p.kk, lane, &kept);
                     if (l31 == r) {                    // both lanes of the pair take the new state
-                        ccnt = h == 0 ? p.kk : 0;
-                        clast = p.kk;
-                        th = lemon_key_score(kth);
+                        ccnt = h == 0 ? kept : 0;
+                        clast = kept;
+                        th = lemon_key_score(kth);     // <= the exact kk-th best: a valid admission threshold
                     }
                 } while (todo);
             }

@@ -139,6 +139,58 @@ __global__ __launch_bounds__(64) void k_d1_normalized(int metric, const float *_
 }
 
 // ---------------------------------------------------------------------------------
+// Zero-shot "CLIP logits" confidence (lib/baselines/train_zero_shot_clip_baseline.py:207-224): for one image, the
+// distance of its UN-normalised embedding to every class-prompt embedding by DistanceEvaluator.our_metric
+// (lib/metrics/distance_metrics.py:48-73: 1 - cosine similarity | euclidean (not squared) | manhattan),
+// conf = softmax_c(1 - dist_c)[noisy label].  One wavefront per image; lane c walks class prompt c; float32 softmax.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_class_confidence(int kind, const float *__restrict__ img, int64_t n, int d,
+                                                         const float *__restrict__ cls, int C,
+                                                         const int32_t *__restrict__ lab, float *__restrict__ conf) {
+    const int lane = threadIdx.x;
+    const int64_t i = blockIdx.x;
+    if (i >= n) return;
+    const float *v = img + i * (int64_t)d;
+    const int mylab = lab[i];
+    float vv = 0.0f;
+    if (kind == 0) for (int k = 0; k < d; ++k) vv = __builtin_fmaf(v[k], v[k], vv);
+    float z[16];
+    float mx = -FLT_MAX, mine = 0.0f;
+    int nz = 0;
+    for (int c = lane; c < C && nz < 16; c += 64, ++nz) {
+        const float *t = cls + (int64_t)c * d;
+        float dist;
+        if (kind == 0) {
+            float dot = 0.0f, tt = 0.0f;
+            for (int k = 0; k < d; ++k) { dot = __builtin_fmaf(v[k], t[k], dot); tt = __builtin_fmaf(t[k], t[k], tt); }
+            dist = 1.0f - dot / (sqrtf(vv) * sqrtf(tt));
+        } else if (kind == 1) {
+            float acc = 0.0f;
+            for (int k = 0; k < d; ++k) { const float u = v[k] - t[k]; acc = __builtin_fmaf(u, u, acc); }
+            dist = sqrtf(acc);
+        } else {
+            float acc = 0.0f;
+            for (int k = 0; k < d; ++k) acc += fabsf(v[k] - t[k]);
+            dist = acc;
+        }
+        z[nz] = 1.0f - dist;
+        mx = fmaxf(mx, z[nz]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float s = 0.0f;
+    int j = 0;
+    for (int c = lane; c < C && j < 16; c += 64, ++j) {
+        const float e = expf(z[j] - mx);
+        s += e;
+        if (c == mylab) mine = e;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); mine += __shfl_xor(mine, off); }
+    if (lane == 0) conf[i] = mine / s;
+}
+
+// ---------------------------------------------------------------------------------
 // K5: score aggregation, one thread per sample, float64 like the oracle.
 // ---------------------------------------------------------------------------------
 struct ScoreHP { double beta, gamma, t1n, t2n, t1m, t2m; };
@@ -215,6 +267,18 @@ extern "C" int lemon_d1_normalized(int metric, const float *q_img_dev, int64_t n
     LEMON_REQUIRE(q_img_dev && cls_txt_dev && noisy_label_dev && d1_dev, "null pointer");
     hipLaunchKernelGGL(k_d1_normalized, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, metric,
                        q_img_dev, n, d, cls_txt_dev, C, noisy_label_dev, d1_dev);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}
+
+extern "C" int lemon_class_confidence(int kind, const float *img_dev, int64_t n, int d, const float *cls_txt_dev, int C,
+                                      const int32_t *noisy_label_dev, float *conf_dev, void *stream) {
+    LEMON_REQUIRE(kind >= 0 && kind <= 2, "kind: 0 cosine, 1 euclidean, 2 manhattan");
+    LEMON_REQUIRE(n >= 0 && d > 0 && C > 0 && C <= 1024, "n >= 0, d > 0, 0 < C <= 1024");
+    if (n == 0) return LEMON_OK;
+    LEMON_REQUIRE(img_dev && cls_txt_dev && noisy_label_dev && conf_dev, "null pointer");
+    hipLaunchKernelGGL(k_class_confidence, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, kind, img_dev, n, d,
+                       cls_txt_dev, C, noisy_label_dev, conf_dev);
     LEMON_HIP_CHECK(hipGetLastError());
     return LEMON_OK;
 }

@@ -10,20 +10,16 @@ per-sample record schema (:291-307).  Differences, all explicit:
   * under torchrun (WORLD_SIZE>1) samples are sharded over ranks, DB shards all-gathered over RCCL.
 """
 import argparse
-import json
 import os
 import pickle
-import random
-import socket
 import sys
 from datetime import datetime
-from pathlib import Path
 
 import numpy as np
 import pandas as pd
 import torch
 
-CLF_DATASETS = ["cifar10", "cifar100", "cifar10_full", "cifar100_full", "mini_imagenet", "stanford_cars"]
+from .cli_common import CLF_DATASETS, add_extension_flags  # noqa: F401  (CLF_DATASETS re-exported: run_lemon.py:32)
 
 
 def build_parser():
@@ -58,185 +54,32 @@ def build_parser():
     p.add_argument("--skip_train", action="store_true")
     p.add_argument("--skip_hparam_optim", action="store_true")
     # ---- extensions (not in the reference) ----
-    p.add_argument("--clip_path", default="random",
-                   help="local HF CLIP checkpoint dir (huggingface_clip), local OpenAI-format .pt (in-tree CLIP branches), or random[:arch]")
-    p.add_argument("--bpe_path", default=None,
-                   help="CLIP BPE merges file (bpe_simple_vocab_16e6.txt.gz / merges.txt) when the checkpoint has no tokenizer files")
-    p.add_argument("--data_root", default="./data", help="local dataset root, or synthetic:N")
-    p.add_argument("--algo", default="auto", choices=["auto", "f32", "bf16"], help="kNN scan algorithm")
-    p.add_argument("--encoder_batch", default=512, type=int, help="encoder micro-batch on the GPU")
+    add_extension_flags(p)
     p.add_argument("--lbfgs_device", default="cuda", choices=["cuda", "cpu"],
                    help="where the SoftMargin/LBFGS polish of the hyper-parameter search runs (lib/metrics/utils.py:121-149)")
-    p.add_argument("--no_text_dedup", action="store_true",
-                   help="encode every sample's prompt (the reference does) instead of each distinct prompt once")
-    p.add_argument("--embedding_cache", default=None,
-                   help="directory for per-split embedding caches (lemon_amd/cache.py): re-runs with another k / metric / "
-                        "ablation skip the encoder")
     p.add_argument("--hparam_grid", default="full", choices=["full", "small"],
                    help="'small' = 3x3x2x2 grid for smoke runs (reference grid is 21x21x4x4)")
     return p
 
 
-class Tee:
-    """lib/utils/utils.py:42-54"""
-
-    def __init__(self, fname, stream, mode="a"):
-        self.stream, self.file = stream, open(fname, mode)
-
-    def write(self, m):
-        self.stream.write(m); self.file.write(m); self.flush()
-
-    def flush(self):
-        self.stream.flush(); self.file.flush()
-
-
 def main(argv=None):
-    args = build_parser().parse_args(argv)
-    saved = (sys.stdout, sys.stderr)
-    try:
-        return _run(args)
-    finally:                      # the Tee objects are per run (the reference is a one-shot script; this is a function)
-        for cur, old in ((sys.stdout, saved[0]), (sys.stderr, saved[1])):
-            if isinstance(cur, Tee):
-                cur.file.close()
-        sys.stdout, sys.stderr = saved
+    from .cli_common import run_with_tee
+    return run_with_tee(_run, build_parser().parse_args(argv))
 
 
 def _run(args):
-    hparams = vars(args)
-    out_dir = Path(args.output_dir)
-    out_dir.mkdir(exist_ok=True, parents=True)
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not args.debug and rank == 0:
-        sys.stdout = Tee(os.path.join(args.output_dir, "out.txt"), sys.stdout)
-        sys.stderr = Tee(os.path.join(args.output_dir, "err.txt"), sys.stderr)
-
-    from . import _lib, datasets as ds, metrics as M, ops
-    from .clip import algorithm_class_from_scratch
-    from .data import get_dataset
+    from . import _lib, metrics as M, ops
+    from .cli_common import meta_columns, prepare
     from .neighbors import LemonDB
-    from .pipeline import Embedder, all_gather_rows, shard_bounds
+    from .pipeline import all_gather_rows
 
-    _lib.load()
-    if not torch.cuda.is_available():
-        raise _lib.LemonHipError("run_lemon needs a HIP device (no CPU fallback for the hot path)")
-    device = torch.device("cuda", local % max(torch.cuda.device_count(), 1))     # rehearsals: ranks may share one card
-    torch.cuda.set_device(device)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("LEMON_DIST_BACKEND", "nccl")   # nccl = RCCL over xGMI; gloo only to rehearse on one card
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    if rank == 0:
-        print("Environment:")
-        print("\tPython: {}".format(sys.version.split(" ")[0]))
-        print("\tPyTorch: {}".format(torch.__version__))
-        print("\tHIP: {}".format(torch.version.hip))
-        print("\tNumPy: {}".format(np.__version__))
-        print("\tNode: {}".format(socket.gethostname()))
-        print("\tDevice: {} x{}".format(torch.cuda.get_device_name(device), world))
-        print("Args:")
-        for k, v in sorted(hparams.items()):
-            print("\t{}: {}".format(k, v))
-
-    random.seed(args.seed)
-    np.random.seed(args.seed)
-    torch.manual_seed(args.seed)
-    if rank == 0:
-        with open(out_dir / "args.json", "w") as f:
-            json.dump(vars(args), f, default=str)
     if args.real_dataset:
         assert args.noise_level == 0.0
-
-    label_set = ds.LABEL_SETS.get(args.dataset)
-    is_clf = args.dataset in CLF_DATASETS
-    model, tokenizer = algorithm_class_from_scratch(args.clip_model, text_base_name=args.clip_path, img_base=None,
-                                                    return_tokenizer=True, bpe_path=args.bpe_path)
-    hf_style = args.clip_model == "huggingface_clip"      # the other branches' tokenizer returns a LongTensor (:148-154)
-    train_set, val_set, test_set = get_dataset(args.dataset, args.data_seed, percent_flips=args.noise_level,
-                                               flip_type=args.noise_type, data_root=args.data_root,
-                                               image_size=model.cfg.image_size)
-    if args.subset_val_set > 0:
-        rng = np.random.default_rng(args.data_seed)
-        val_set = val_set.subset(rng.choice(np.arange(len(val_set)), min(args.subset_val_set, len(val_set)), replace=False))
-
-    # identical prompts are embedded once and gathered (class datasets: C prompts for N samples): the same function
-    # of the input, independent of how samples fall into micro-batches; --no_text_dedup encodes every sample's prompt
-    embedder = Embedder(model, device, batch_size=args.encoder_batch, text_dedup=not args.no_text_dedup)
-    prefix = "A photo of a " if args.custom_cifar_prompt is None else args.custom_cifar_prompt
-    prompt_fn = lambda x: prefix + x
-
-    # DB subset: first consumer of the global numpy stream after seeding (run_lemon.py:81,121-127)
-    if len(train_set) > args.compr_dataset_size_limit:
-        train_indices_in_compr = np.random.choice(np.arange(len(train_set)), args.compr_dataset_size_limit, replace=False)
-    else:
-        train_indices_in_compr = np.arange(len(train_set))
-
-    def texts_of(noisy, clean):
-        if is_clf:
-            noisy_txt = label_set[np.asarray(noisy)].tolist()
-            clean_txt = label_set[np.asarray(clean)].tolist()
-            return noisy_txt, clean_txt, [prompt_fn(t) for t in noisy_txt]
-        return list(noisy), list(clean), list(noisy)
-
-    def tokenize(prompts):
-        if not hf_style:
-            return tokenizer(prompts)
-        enc = tokenizer(prompts, padding="max_length", truncation=True)
-        return torch.tensor(enc["input_ids"])
-
-    # int ids for the discrete text metric (it compares prompt STRINGS, :266-267).  Class datasets: the
-    # prompt is a bijection of the noisy label.  Captions: a dictionary built from the dataset itself,
-    # in a fixed order, so every rank derives the same ids.
-    text_ids = {}
-    if not is_clf:
-        for dset in (train_set, val_set, test_set):
-            for cap in dset.noisy:
-                text_ids.setdefault(cap, len(text_ids))
-
-    def ids_of(meta):
-        if is_clf:
-            return np.asarray(meta["noisy"], dtype=np.int32)
-        return np.array([text_ids[p] for p in meta["prompts"]], dtype=np.int32)
-
-    from .cache import EmbeddingCache
-    cache = EmbeddingCache(args.embedding_cache, dataset=args.dataset, noise_type=args.noise_type,
-                           noise_level=args.noise_level, data_seed=args.data_seed, clip_model=args.clip_model,
-                           clip_path=os.path.abspath(args.clip_path) if os.path.exists(str(args.clip_path)) else args.clip_path,
-                           data_root=args.data_root, prompt=args.custom_cifar_prompt, subset_val_set=args.subset_val_set)
-
-    def embed_split(dset, sname):
-        """this rank's contiguous shard of a split -> (emb_img, emb_txt, meta) on the device"""
-        lo, hi = shard_bounds(len(dset), world, rank)
-        if cache.root:
-            sl = slice(lo, hi)
-            key_prompts = texts_of(dset.noisy[sl], dset.clean[sl])[2]
-            hit = cache.load(sname, lo, hi, key_prompts, device)
-            if hit is not None:
-                return hit
-        imgs, toks, meta = [], [], dict(noisy=[], clean=[], noisy_txt=[], clean_txt=[], prompts=[])
-        # data chunks of the encoder micro-batch (the reference's --batch_size only sizes its DataLoader batches;
-        # per-sample results do not depend on it)
-        for px, clean, noisy in dset.batches(max(args.batch_size, args.encoder_batch), lo, hi, device=device):
-            noisy_txt, clean_txt, prompts = texts_of(noisy, clean)
-            imgs.append(embedder.embed_images(px))
-            toks.append(tokenize(prompts))
-            meta["noisy"] += list(noisy); meta["clean"] += list(clean)
-            meta["noisy_txt"] += noisy_txt; meta["clean_txt"] += clean_txt; meta["prompts"] += prompts
-        d = embedder.model.cfg.embed_dim
-        e_img = torch.cat(imgs) if imgs else torch.empty((0, d), device=device)
-        e_txt = embedder.embed_texts(torch.cat(toks)) if toks else torch.empty((0, d), device=device)
-        meta["lo"] = lo
-        if cache.root:
-            cache.store(sname, lo, hi, meta["prompts"], e_img, e_txt, meta)
-        return e_img, e_txt, meta
+    ctx = prepare(args)
+    out_dir, world, rank, device = ctx.out_dir, ctx.world, ctx.rank, ctx.device
+    is_clf, label_set, embedder = ctx.is_clf, ctx.label_set, ctx.embedder
+    embed_split, ids_of, sets = ctx.embed_split, ctx.ids_of, ctx.sets
+    train_set, train_indices_in_compr = sets["train"], ctx.train_indices_in_compr
 
     start_t = datetime.now()
     emb = {"train": embed_split(train_set, "train")}
@@ -253,12 +96,11 @@ def _run(args):
 
     cls_txt = None
     if is_clf:   # class-prompt embeddings, only used by --normalize_d1 (:180-190)
-        cls_txt = embedder.embed_texts(tokenize([prompt_fn(t) for t in label_set]))
+        cls_txt = embedder.embed_texts(ctx.tokenize([ctx.prompt_fn(t) for t in label_set]))
 
     in_db_mask = np.zeros(n_train, dtype=np.uint8)
     in_db_mask[train_indices_in_compr] = 1
     names = ["val", "test"] if (args.debug or args.skip_train) else ["train", "val", "test"]
-    sets = {"train": train_set, "val": val_set, "test": test_set}
     k = args.knn_k
     frames = []
     for sname in names:
@@ -276,19 +118,10 @@ def _run(args):
                                            torch.from_numpy(np.asarray(meta["noisy"], dtype=np.int32)))
         n_total = len(sets[sname])
         host = {key: all_gather_rows(v, n_total).cpu().numpy() for key, v in rec.items()}
-        flips = 1 - (np.array(meta["noisy_txt"]) == np.array(meta["clean_txt"]))
-        if world > 1:   # metadata to rank 0 (small python objects)
-            import torch.distributed as dist
-            gathered = [None] * world
-            dist.all_gather_object(gathered, (meta, flips))
-            meta = {key: sum((g[0][key] for g in gathered), []) for key in ("noisy", "clean", "noisy_txt", "clean_txt")}
-            flips = np.concatenate([g[1] for g in gathered])
+        meta, flips = ctx.gather_meta(meta)       # metadata to every rank (small python objects)
         if rank == 0:
             frames.append(pd.DataFrame({
-                "sset": sname, "idx": np.arange(n_total),
-                "actual_label": [c.item() if hasattr(c, "item") else c for c in meta["clean"]],
-                "actual_label_text": meta["clean_txt"], "noisy_label": list(meta["noisy"]),
-                "noisy_label_text": meta["noisy_txt"], "is_mislabel": flips, "is_correct_label": 1 - flips,
+                **meta_columns(sname, n_total, meta, flips),
                 "d_1": host["d_1"].astype(np.float64),
                 **{c: list(host[c]) for c in ("dists_n", "D_n", "dists_tr_n", "dists_m", "D_m", "dists_tr_m")},
             }))

@@ -564,3 +564,16 @@ def test_cos_distance_topk_matches_reference_golden(hip):
     assert np.abs(vals.cpu().numpy() - g["vals"]).max() < 5e-7
     prob = count_knn_distribution(4, 0.0, cu(g["feat"]), np.arange(64) % 4, 6)
     assert prob.shape == (64, 4) and torch.allclose(prob.norm(dim=1), torch.ones(64, device="cuda"), atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dist", ["cosine", "euclidean", "manhattan"])
+def test_clip_logits_confidence_matches_reference_golden(hip, dist):
+    """Zero-shot CLIP-logits baseline (lib/baselines/train_zero_shot_clip_baseline.py:207-224): golden produced with the
+    reference's own DistanceEvaluator.our_metric + scipy softmax (tools/make_golden.py -> zero_shot.npz)."""
+    import os
+    from lemon_amd.baselines import clip_logits_confidence
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "zero_shot.npz"))
+    got = clip_logits_confidence(torch.from_numpy(g["img"]).cuda(), torch.from_numpy(g["cls"]).cuda(), g["lab"], dist).cpu().numpy()
+    assert np.abs(got - g[f"conf_{dist}"]).max() <= 2e-6, np.abs(got - g[f"conf_{dist}"]).max()
+    assert np.all((got > 0) & (got < 1))

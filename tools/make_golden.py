@@ -226,3 +226,23 @@ np.savez_compressed(os.path.join(OUT, "cosdistance_topk.npz"), feat=feat, vals=v
 print("golden fixtures written to", OUT)
 for fn in sorted(os.listdir(OUT)):
     print(f"  {fn:32s} {os.path.getsize(os.path.join(OUT, fn)):8d} B")
+
+# ------------------------------------------------------------------ zero-shot CLIP-logits baseline
+# lib/baselines/train_zero_shot_clip_baseline.py:207-224 restated with the reference's OWN pieces: DistanceEvaluator.our_metric
+# (lib/metrics/distance_metrics.py:48-73) per image against all class prompts, scipy softmax(1 - dist), entry of the noisy label.
+from scipy.special import softmax as sp_softmax
+dm = importlib.import_module("lib.metrics.distance_metrics")
+rs = np.random.RandomState(11)
+zs = {"img": (rs.randn(40, 24) * rs.uniform(0.5, 3, (40, 1))).astype(np.float32),
+      "cls": (rs.randn(10, 24) * rs.uniform(0.5, 3, (10, 1))).astype(np.float32), "lab": rs.randint(0, 10, 40).astype(np.int64)}
+text_embeds = torch.from_numpy(zs["cls"])
+for dist_name in ("cosine", "euclidean", "manhattan"):
+    conf = []
+    for i in range(40):
+        rep = torch.from_numpy(zs["img"][i]).repeat(10, 1)
+        ev = dm.DistanceEvaluator(y_true=None, y_pred_proba=None, dist=dist_name, threshold=0.5, y_pred_prob_epochs=None, loss=None,
+                                  first_modality_embeddings=text_embeds, second_modality_embeddings=rep)
+        conf.append(sp_softmax(1 - ev.our_metric())[zs["lab"][i]])
+    zs[f"conf_{dist_name}"] = np.array(conf, dtype=np.float64)
+np.savez_compressed(os.path.join(OUT, "zero_shot.npz"), **zs)
+print("zero_shot.npz written")

@@ -184,12 +184,15 @@ def planted_caption_frame(seed, n, d, n_cat=12):
 
 # ------------------------------------------------------------------------------ stand-in modules
 class PlantedCLIP(torch.nn.Module):
-    def __init__(self, txt_table):
+    def __init__(self, txt_table, img_log=None):
         super().__init__()
         self.register_buffer("table", torch.from_numpy(txt_table))
         self.context_length = 8
+        self.img_log = img_log
 
     def encode_image(self, pixel_values=None):
+        if self.img_log is not None:
+            self.img_log.append(pixel_values.float().numpy().copy())
         return pixel_values.float().clone()
 
     def encode_text(self, input_ids=None, attention_mask=None):
@@ -244,7 +247,7 @@ def install_stubs(state):
     mu = types.ModuleType("lib.models.utils")
 
     def algorithm_class_from_scratch(name, text_base_name, img_base, return_tokenizer=False):
-        model = PlantedCLIP(state["txt_table"])
+        model = PlantedCLIP(state["txt_table"], state.get("img_log"))
         tok = PlantedTokenizer(state["prompt_ids"], hf=(name == "huggingface_clip"))
         return (model, tok) if return_tokenizer else model
 
@@ -384,6 +387,71 @@ def run_case(name, cfg, dsu, state, workdir):
     return fx
 
 
+def run_disc_case(name, cfg, dsu, state, workdir):
+    """lib/baselines/discrepancy_baseline.py (module-level script, :1-273) under the same stand-ins: stores the planted inputs,
+    the normalised DB / query embeddings it used and its pred_score column + agg_results AUROC."""
+    d = cfg["d"]
+    argv = ["--output_dir", os.path.join(workdir, name)] + cfg["argv"]
+    C = {"cifar10": 10, "cifar100": 100}[cfg["dataset"]]
+    img, y, txt_table = planted_class_data(cfg["seed"], cfg["n"], C, d)
+    labels = np.array(getattr(dsu, cfg["dataset"] + "_labels"))
+    state.update(img_all=img, y_all=y, txt_table=txt_table, prompt_ids={"A photo of a " + l: i for i, l in enumerate(labels)},
+                 img_log=[])
+    fx = {"argv": np.array(json.dumps(cfg["argv"])), "is_caption": np.array(False), "d": np.array(d), "img_all": img, "y_all": y,
+          "txt_table": txt_table, "prefix": np.array("A photo of a ")}
+    log = {"adds": [], "searches": []}
+    _FakeIndex.log = log
+    old = (sys.argv, sys.stdout, sys.stderr, os.getcwd())
+    script = os.path.join(REF, "lib", "baselines", "discrepancy_baseline.py")
+    sys.argv = [script] + argv
+    os.chdir(workdir)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            g = runpy.run_path(script, run_name="__main__")
+    finally:
+        so, se = sys.stdout, sys.stderr
+        sys.argv = old[0]
+        sys.stdout, sys.stderr = old[1], old[2]
+        for t in (so, se):
+            f = getattr(t, "file", None)
+            if f is not None and f is not old[1] and f is not old[2]:
+                with contextlib.suppress(Exception):
+                    f.close()
+        os.chdir(old[3])
+        img_log = state.pop("img_log")
+    df = g["df"]
+    (ix_txt, db_txt), (ix_img, db_img) = log["adds"]
+    fx["db_txt"], fx["db_img"] = db_txt, db_img
+    fx["train_indices_in_compr"] = np.asarray(g["train_indices_in_compr"], np.int64)
+    n_db_batches = -(-len(db_img) // g["bs"])
+    raw_q = np.concatenate(img_log[n_db_batches:])                     # image "embeddings" of the scored splits, in order
+    first = 1 if "dis" in g["args"].method else 0                      # 'dis_*' searches the DB against itself first (:165-166)
+    q_txt = np.concatenate([q for ix, q, k_, D, I in log["searches"][first:]])
+    lo = 0
+    for sname in df.sset.unique():
+        sub = df.loc[df.sset == sname]
+        n = len(sub)
+        fx[f"{sname}_q_img_raw"] = raw_q[lo:lo + n]
+        fx[f"{sname}_q_txt"] = q_txt[lo:lo + n]
+        fx[f"{sname}_pred_score"] = sub["pred_score"].values.astype(np.float64)
+        fx[f"{sname}_is_mislabel"] = sub["is_mislabel"].values.astype(np.int64)
+        fx[f"{sname}_noisy"] = np.array([int(v) for v in sub["noisy_label"]], np.int64)
+        lo += n
+    assert lo == len(raw_q) == len(q_txt)
+    fx["ssets"] = np.array(list(df.sset.unique()))
+    fx["auroc"] = np.array(json.dumps({s: float(g["selection_results"][s]["AUROC"]) for s in df.sset.unique()}))
+    fx["out_files"] = np.array(sorted(os.listdir(os.path.join(workdir, name))))
+    np.savez_compressed(os.path.join(OUT, f"disc_{name}.npz"), **fx)
+    return fx
+
+
+DISC_CASES = {
+    m: dict(dataset="cifar10", n=600, d=32, seed=30 + i,
+            argv=["--dataset", "cifar10", "--noise_type", "asymmetric", "--knn_k", "4", "--method", m] +
+                 (["--compr_dataset_size_limit", "300"] if m == "div_y" else []) + (["--skip_train"] if m == "dis_y" else []))
+    for i, m in enumerate(("dis_x", "dis_y", "div_x", "div_y"))
+}
+
 SKIP = ["--skip_hparam_optim"]
 CASES = {
     # class datasets: text rows are exact duplicates per class (all ties on the text side, as on CIFAR)
@@ -437,14 +505,20 @@ CASES = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
+    ap.add_argument("--disc", action="store_true", help="(re)generate only the discrepancy-baseline fixtures")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     state = {}
     dsu = install_stubs(state)
     work = tempfile.mkdtemp(prefix="lemon_loop_")
     try:
-        for name, cfg in CASES.items():
+        for name, cfg in DISC_CASES.items():
             if a.only and a.only != name:
+                continue
+            fx = run_disc_case(name, cfg, dsu, state, work)
+            print(f"disc_{name:31s} ssets={list(fx['ssets'])} n_db={len(fx['db_img'])} auroc={str(fx['auroc'])}", flush=True)
+        for name, cfg in CASES.items():
+            if a.disc or (a.only and a.only != name):
                 continue
             fx = run_case(name, cfg, dsu, state, work)
             nbytes = os.path.getsize(os.path.join(OUT, f"loop_{name}.npz"))
