@@ -110,6 +110,25 @@ int lemon_preprocess_u8(const uint8_t *img_dev, int64_t batch, int in_h, int in_
 int lemon_attention_f32(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
                         int causal, float *out_dev, void *stream);
 
+/* LayerNorm over the last dimension, float32: y = (x - mean) / sqrt(var + eps) * weight + bias (biased variance, like
+ * torch.nn.LayerNorm) -- layer_norm1/2, pre_layrnorm, post_layernorm, final_layer_norm of the towers behind
+ * encode_image / encode_text (lib/models/downstream_models.py:37-41; in-tree twin lib/models/chexzero_clip.py:177-183).
+ * x_dev, y_dev [rows, width] (y_dev may alias x_dev), width a multiple of 4 and <= 2048, pointers 16-byte aligned. */
+int lemon_layernorm_f32(const float *x_dev, const float *weight_dev, const float *bias_dev, float eps, int64_t rows,
+                        int width, float *y_dev, void *stream);
+
+/* Token assembly of the towers, one pass each instead of torch's cat / gather + add (+ LayerNorm):
+ *   vision (HF CLIPVisionEmbeddings + pre_layrnorm; lib/models/chexzero_clip.py:243-249):
+ *     y[b,0] = LN(cls + pos[0]),  y[b,1+p] = LN(patches[b,p] + pos[1+p]);  patches_dev [batch, n_tokens-1, width] is the
+ *     patch-embedding GEMM's output, y_dev [batch, n_tokens, width];
+ *   text (token + position embedding, chexzero_clip.py:363-365): y[b,t] = tok_emb[ids[b,t]] + pos[t] for t < seq_len;
+ *     ids_dev int64 with row pitch ids_pitch >= seq_len (the caller's [batch, context] id matrix, truncated in place). */
+int lemon_vision_tokens_ln(const float *patches_dev, const float *cls_dev, const float *pos_dev,
+                           const float *ln_weight_dev, const float *ln_bias_dev, float eps, int64_t batch,
+                           int n_tokens, int width, float *y_dev, void *stream);
+int lemon_text_tokens(const int64_t *ids_dev, int64_t ids_pitch, const float *tok_emb_dev, const float *pos_dev,
+                      int64_t batch, int seq_len, int width, int vocab, float *y_dev, void *stream);
+
 /* Linear layer of the CLIP towers with its element-wise tail fused into the GEMM:
  *   y[m,n] = act(alpha x[m,k] W[n,k]^T + bias[n]) (+ residual[m,n])         float32, row-major
  * (nn.Linear inside HF CLIPEncoderLayer / lib/models/chexzero_clip.py:191-212, driven by

@@ -124,7 +124,8 @@ class Block(nn.Module):
             # inference on the GPU: every GEMM of the block goes through lemon_linear_f32 (bias, QuickGELU
             # and the residual adds ride in the hipBLASLt epilogue), attention through lemon_attention_f32
             from . import ops
-            qkv = ops.linear(self.ln1(x), self.qkv.weight, self.qkv.bias)
+            ln = lambda m, t: ops.layer_norm(t, m.weight, m.bias, m.eps) if t.shape[-1] % 4 == 0 else m(t)
+            qkv = ops.linear(ln(self.ln1, x), self.qkv.weight, self.qkv.bias)
             if W == 64 * self.heads and L <= ops.ATTENTION_MAX_SEQ:
                 a = ops.attention(qkv, self.heads, causal)
             else:
@@ -134,7 +135,7 @@ class Block(nn.Module):
             x = ops.linear(a, self.out.weight, self.out.bias, residual=x)
             # QuickGELU(z) = silu(1.702 z) / 1.702: scale going in (alpha, bias), un-scale in fc2's alpha
             s = ops.QUICK_GELU_SCALE
-            h = ops.linear(self.ln2(x), self.fc1.weight, self.fc1.bias * s, act="silu", alpha=s)
+            h = ops.linear(ln(self.ln2, x), self.fc1.weight, self.fc1.bias * s, act="silu", alpha=s)
             return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=x, alpha=1.0 / s)
         a = self._sdpa(self.qkv(self.ln1(x)), B, L, W, causal)
         if rows is not None:
@@ -170,12 +171,19 @@ class VisionTower(nn.Module):
             x = ops.linear(pixel_values, self.patch.weight.reshape(self.patch.weight.shape[0], -1))
         else:
             x = self.patch(pixel_values.to(self.patch.weight.dtype)).flatten(2).transpose(1, 2)
-        x = torch.cat([self.cls.expand(x.shape[0], 1, -1), x], dim=1) + self.pos
-        x = self.pre_ln(x)
+        fused = x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.shape[-1] % 4 == 0
+        if fused:     # class token + position embedding + pre-LayerNorm in one pass over the token matrix
+            from . import ops
+            x = ops.vision_tokens_ln(x, self.cls, self.pos, self.pre_ln.weight, self.pre_ln.bias, self.pre_ln.eps)
+        else:
+            x = torch.cat([self.cls.expand(x.shape[0], 1, -1), x], dim=1) + self.pos
+            x = self.pre_ln(x)
         for b in self.blocks[:-1]:
             x = b(x, causal=False)
         batch = torch.arange(x.shape[0], device=x.device)
         x = self.blocks[-1](x, causal=False, rows=(batch, torch.zeros_like(batch)))   # CLS rows of the last block
+        if fused:
+            return ops.linear(ops.layer_norm(x, self.post_ln.weight, self.post_ln.bias, self.post_ln.eps), self.proj.weight)
         return self.proj(self.post_ln(x))
 
 
@@ -203,11 +211,18 @@ class TextTower(nn.Module):
         # seq_len: precomputed on the host by the caller (pipeline.Embedder) to avoid a device sync here.
         eot = input_ids.argmax(dim=-1)
         L = self.seq_len_for(eot.max().item()) if seq_len is None else int(seq_len)
-        ids = input_ids[:, :L]
-        x = self.tok(ids) + self.pos[:L]
+        fused = input_ids.is_cuda and self.pos.dtype == torch.float32 and not torch.is_grad_enabled() and self.pos.shape[-1] % 4 == 0
+        if fused:     # embedding lookup + position embedding in one pass, straight from the [B, ctx] id matrix
+            from . import ops
+            x = ops.text_tokens(input_ids if input_ids.dtype == torch.int64 and input_ids.stride(1) == 1 else input_ids.long().contiguous(),
+                                L, self.tok.weight, self.pos)
+        else:
+            x = self.tok(input_ids[:, :L]) + self.pos[:L]
         for b in self.blocks[:-1]:
             x = b(x, causal=True)
         x = self.blocks[-1](x, causal=True, rows=(torch.arange(x.shape[0], device=x.device), eot))   # EOT rows only
+        if fused:
+            return ops.linear(ops.layer_norm(x, self.final_ln.weight, self.final_ln.bias, self.final_ln.eps), self.proj.weight)
         return self.proj(self.final_ln(x))
 
 

@@ -1,0 +1,184 @@
+// encoder.hip -- row-wise pieces of the CLIP towers that sit between the library GEMMs (gfx950 only).
+//
+// LayerNorm of the pre-LN transformer blocks (HF CLIPEncoderLayer.layer_norm1/2, pre_layrnorm, post_layernorm,
+// final_layer_norm; lib/models/chexzero_clip.py:177-183,207-212): y = (x - mean) / sqrt(var + eps) * w + b over the last
+// dimension, float32.  HBM-bound: 8 bytes per element.  One wavefront per row, the row held in registers (16-B loads,
+// lane l owns chunks l, l+64, ...), mean and the centred second moment reduced across the wave with two butterfly
+// passes -- one read, one write, no LDS, no second pass over memory.
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+
+namespace {
+
+template <int CH>   // float4 chunks per lane: width <= 256*CH
+__global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ w,
+                                                   const float *__restrict__ b, float eps, int64_t rows, int width,
+                                                   float *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = width >> 2;
+    const float4 *xr = reinterpret_cast<const float4 *>(x + row * (int64_t)width);
+    float4 v[CH];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < nch ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)width;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        if (lane + 64 * i < nch) {
+            const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = rsqrtf(q / (float)width + eps);
+    const float4 *w4 = reinterpret_cast<const float4 *>(w);
+    const float4 *b4 = reinterpret_cast<const float4 *>(b);
+    float4 *yr = reinterpret_cast<float4 *>(y + row * (int64_t)width);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const float4 ww = w4[c], bb = b4[c];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * ww.x + bb.x;
+            o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
+            o.z = (v[i].z - mean) * rstd * ww.z + bb.z;
+            o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
+            yr[c] = o;
+        }
+    }
+}
+
+// Token assembly of the vision tower (HF CLIPVisionEmbeddings + pre_layrnorm; chexzero_clip.py:243-249): row 0 of every image
+// is the class embedding, rows 1.. are the patch-embedding GEMM's output; add the position embedding and apply the
+// pre-LayerNorm -- torch runs this as cat + add + layer_norm (three read+write passes); here it is one.
+template <int CH>
+__global__ __launch_bounds__(256) void k_vision_tokens_ln(const float *__restrict__ patches, const float *__restrict__ cls,
+                                                          const float *__restrict__ pos, const float *__restrict__ w,
+                                                          const float *__restrict__ b, float eps, int64_t batch, int n_tok,
+                                                          int width, float *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= batch * n_tok) return;
+    const int64_t img = row / n_tok;
+    const int t = (int)(row - img * n_tok);
+    const int nch = width >> 2;
+    const float4 *src = t == 0 ? reinterpret_cast<const float4 *>(cls)
+                               : reinterpret_cast<const float4 *>(patches + (img * (n_tok - 1) + (t - 1)) * (int64_t)width);
+    const float4 *pr = reinterpret_cast<const float4 *>(pos + (int64_t)t * width);
+    float4 v[CH];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const float4 a = src[c], p = pr[c];
+            v[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)width;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        if (lane + 64 * i < nch) {
+            const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = rsqrtf(q / (float)width + eps);
+    const float4 *w4 = reinterpret_cast<const float4 *>(w);
+    const float4 *b4 = reinterpret_cast<const float4 *>(b);
+    float4 *yr = reinterpret_cast<float4 *>(y + row * (int64_t)width);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const float4 ww = w4[c], bb = b4[c];
+            yr[c] = make_float4((v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y,
+                                (v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w);
+        }
+    }
+}
+
+// Token assembly of the text tower (token embedding lookup + position embedding; chexzero_clip.py:363-365): one pass.
+__global__ __launch_bounds__(256) void k_text_tokens(const int64_t *__restrict__ ids, int64_t ids_pitch, const float *__restrict__ tok,
+                                                     const float *__restrict__ pos, int64_t batch, int seq, int width, int vocab,
+                                                     float *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= batch * seq) return;
+    const int64_t bi = row / seq;
+    const int t = (int)(row - bi * seq);
+    int64_t id = ids[bi * ids_pitch + t];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const float4 *a = reinterpret_cast<const float4 *>(tok + id * (int64_t)width);
+    const float4 *p = reinterpret_cast<const float4 *>(pos + (int64_t)t * width);
+    float4 *o = reinterpret_cast<float4 *>(y + row * (int64_t)width);
+    for (int c = lane; c < (width >> 2); c += 64) {
+        const float4 u = a[c], v = p[c];
+        o[c] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    }
+}
+
+}  // namespace
+
+extern "C" int lemon_vision_tokens_ln(const float *patches_dev, const float *cls_dev, const float *pos_dev,
+                                      const float *ln_weight_dev, const float *ln_bias_dev, float eps, int64_t batch,
+                                      int n_tokens, int width, float *y_dev, void *stream_) {
+    LEMON_REQUIRE(batch >= 0 && n_tokens >= 2 && width > 0 && (width & 3) == 0 && width <= 2048, "batch >= 0, n_tokens >= 2, width % 4 == 0, <= 2048");
+    if (batch == 0) return LEMON_OK;
+    LEMON_REQUIRE(patches_dev && cls_dev && pos_dev && ln_weight_dev && ln_bias_dev && y_dev, "null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid((unsigned)((batch * n_tokens + 3) / 4)), block(256);
+#define LAUNCH(CH) hipLaunchKernelGGL(k_vision_tokens_ln<CH>, grid, block, 0, stream, patches_dev, cls_dev, pos_dev, ln_weight_dev, \
+                                      ln_bias_dev, eps, batch, n_tokens, width, y_dev)
+    if (width <= 512) LAUNCH(2); else if (width <= 1024) LAUNCH(4); else LAUNCH(8);
+#undef LAUNCH
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}
+
+extern "C" int lemon_text_tokens(const int64_t *ids_dev, int64_t ids_pitch, const float *tok_emb_dev, const float *pos_dev,
+                                 int64_t batch, int seq_len, int width, int vocab, float *y_dev, void *stream_) {
+    LEMON_REQUIRE(batch >= 0 && seq_len > 0 && width > 0 && (width & 3) == 0 && vocab > 0 && ids_pitch >= seq_len, "shapes");
+    if (batch == 0) return LEMON_OK;
+    LEMON_REQUIRE(ids_dev && tok_emb_dev && pos_dev && y_dev, "null pointer");
+    hipLaunchKernelGGL(k_text_tokens, dim3((unsigned)((batch * seq_len + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, ids_dev,
+                       ids_pitch, tok_emb_dev, pos_dev, batch, seq_len, width, vocab, y_dev);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}
+
+extern "C" int lemon_layernorm_f32(const float *x_dev, const float *weight_dev, const float *bias_dev, float eps,
+                                   int64_t rows, int width, float *y_dev, void *stream_) {
+    LEMON_REQUIRE(rows >= 0 && width > 0 && (width & 3) == 0 && width <= 2048, "rows >= 0, width a multiple of 4, <= 2048");
+    if (rows == 0) return LEMON_OK;
+    LEMON_REQUIRE(x_dev && weight_dev && bias_dev && y_dev, "null pointer");
+    LEMON_REQUIRE(((((uintptr_t)x_dev) | ((uintptr_t)y_dev) | ((uintptr_t)weight_dev) | ((uintptr_t)bias_dev)) & 15) == 0,
+                  "16-byte aligned pointers");
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (width <= 512) hipLaunchKernelGGL(k_layernorm<2>, grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
+    else if (width <= 1024) hipLaunchKernelGGL(k_layernorm<4>, grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
+    else hipLaunchKernelGGL(k_layernorm<8>, grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}

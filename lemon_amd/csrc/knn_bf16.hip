@@ -29,7 +29,7 @@ namespace {
 
 constexpr int BKH = 64;   // bf16 k-slice per LDS stage (128 B rows, like fp32 BK=32)
 constexpr int CAPH = 512; // candidate slots per query (approximate keys): 8 per lane in a light compaction
-constexpr int REFRESH = 64; // light-compact a list after this many new candidates: the admission bound then
+constexpr int REFRESH = 96; // light-compact a list after this many new candidates: the admission bound then
                             // tracks the running k-th best closely (appends ~ k ln(N/k) instead of 3-4x that)
 
 // f32 [n,d] -> bf16 [*, dpad_h] (RNE, zero padded columns), one wavefront per row, plus the row's
@@ -436,6 +436,8 @@ __device__ __forceinline__ void qs_filter_tile(f32x16 a, float th, int64_t jb, f
     const float m2 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11]));
     const float m3 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
     const float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    // (survivors are rare here -- a few per wave and tile -- so nested per-lane tests with their early outs beat the
+    // fp32 scan's "16 ballots + scalar branches per tile" form: measured 164 vs 177 ms at 262 144^2 x 768)
     if (m > th) {                                   // some lane of the wave has a survivor in this tile
         const float mq[4] = {m0, m1, m2, m3};
 #pragma unroll
@@ -471,6 +473,8 @@ __device__ __forceinline__ int qs_compact_light(u64 *__restrict__ list, int n0, 
     u32 o[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = (u32)(v[i] >> 32);
+    // t <= tau (the kk-th largest approximate score word): any lower bound of tau keeps the band a proof, so the
+    // bisection stops at the first prefix that at most kk + 8 keys reach (~14 of the 32 steps)
     u32 t = 0;
 #pragma unroll 1
     for (int bit = 31; bit >= 0; --bit) {
@@ -478,7 +482,10 @@ __device__ __forceinline__ int qs_compact_light(u64 *__restrict__ list, int n0, 
         int c = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) c += __builtin_popcountll(__ballot(o[i] >= cand));
-        if (c >= kk) t = cand;
+        if (c >= kk) {
+            t = cand;
+            if (c <= kk + 8) break;
+        }
     }
     const float lo = bound_from_tau(lemon_ord2f(t), eps);
     const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -626,6 +633,12 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
     }
 
     f32x16 acc0, acc1, acc2, acc3;
+    // LDS byte address (inside slot 0, slice 0) of this lane's 16-B fragment chunk for each of the 4 chunk pairs of a
+    // 64-wide k-slice; rows +32/+64/+96 and the second slice are immediate offsets (the swizzle term repeats every 16 rows)
+    unsigned frag_addr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        frag_addr[u] = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float *)(s_x + swz(l31, 2 * u + h));
 
     const float *xbase = reinterpret_cast<const float *>(p.xh + (int64_t)t_begin * BX * p.dpad_h);
     const int total = ntile * KT2;
@@ -652,25 +665,48 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
                 const int kn = kt + LA;
                 QS_ISSUE_STAGE(xt + (int64_t)(kn / KT2) * BX * dpad, kn % KT2, (t + LA) & (NB - 1));
             }
-#pragma unroll
-            for (int sbk = 0; sbk < SUB; ++sbk) {
-                const float *tx = s_x + (t & (NB - 1)) * STG + sbk * BX * BK;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bf16x8 a0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(l31, 2 * u + h)]));
-                    const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(32 + l31, 2 * u + h)]));
-                    const bf16x8 a2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(64 + l31, 2 * u + h)]));
-                    const bf16x8 a3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(96 + l31, 2 * u + h)]));
-                    constexpr int dummy = 0; (void)dummy;
-                    const int ks = 4 * (SUB * kt + sbk) + u;      // compile-time after unrolling
-                    if (ks == 0) {
-                        mfma_qs_init(acc0, a0, qf[0]); mfma_qs_init(acc1, a1, qf[0]);
-                        mfma_qs_init(acc2, a2, qf[0]); mfma_qs_init(acc3, a3, qf[0]);
-                    } else {
-                        mfma_qs(acc0, a0, qf[ks]); mfma_qs(acc1, a1, qf[ks]);
-                        mfma_qs(acc2, a2, qf[ks]); mfma_qs(acc3, a3, qf[ks]);
-                    }
-                }
+            // ---- the stage's 8 k-steps (SUB slices x 4 chunk pairs), software pipelined by hand ----
+            // One wave per SIMD: nothing else hides the LDS latency, and hipcc schedules every ds_read directly in
+            // front of the (inline-asm) MFMA that consumes it, with an lgkmcnt(0) in between -- 192 exposed LDS
+            // round trips per tile, loop-only 0.42 of the bf16 peak.  So the fragment reads are issued explicitly:
+            // two fragment sets, the reads of step s+1 go out before the four MFMAs of step s, and a counted
+            // lgkmcnt(4) (the four newest reads may still be in flight) replaces the drain.
+            {
+                const unsigned sbase = (unsigned)((t & (NB - 1)) * STG * 4);
+                const unsigned va0 = frag_addr[0] + sbase, va1 = frag_addr[1] + sbase, va2 = frag_addr[2] + sbase,
+                               va3 = frag_addr[3] + sbase;
+                bf16x8 fa0, fa1, fa2, fa3, fb0, fb1, fb2, fb3;
+#define QS_LOAD(S, VA, OFF)                                                                                              \
+                asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"                         \
+                             "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"                             \
+                             : "=&v"(f##S##0), "=&v"(f##S##1), "=&v"(f##S##2), "=&v"(f##S##3)                             \
+                             : "v"(VA), "n"(OFF), "n"((OFF) + 4096), "n"((OFF) + 8192), "n"((OFF) + 12288) : "memory")
+#define QS_WAIT(S, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f##S##0), "+v"(f##S##1), "+v"(f##S##2), "+v"(f##S##3))
+#define QS_STEP(S, KSV)                                                                                                  \
+                do {                                                                                                     \
+                    const int ks_ = (KSV);                       /* compile-time after unrolling */                      \
+                    if (ks_ == 0) {                                                                                      \
+                        mfma_qs_init(acc0, f##S##0, qf[0]); mfma_qs_init(acc1, f##S##1, qf[0]);                          \
+                        mfma_qs_init(acc2, f##S##2, qf[0]); mfma_qs_init(acc3, f##S##3, qf[0]);                          \
+                    } else {                                                                                             \
+                        mfma_qs(acc0, f##S##0, qf[ks_]); mfma_qs(acc1, f##S##1, qf[ks_]);                                \
+                        mfma_qs(acc2, f##S##2, qf[ks_]); mfma_qs(acc3, f##S##3, qf[ks_]);                                \
+                    }                                                                                                    \
+                } while (0)
+                static_assert(SUB == 2, "the k-step schedule below is written out for two 64-wide slices per stage");
+                const int ks0 = 4 * SUB * kt;
+                QS_LOAD(a, va0, 0);
+                QS_LOAD(b, va1, 0);     QS_WAIT(a, 4); QS_STEP(a, ks0 + 0);
+                QS_LOAD(a, va2, 0);     QS_WAIT(b, 4); QS_STEP(b, ks0 + 1);
+                QS_LOAD(b, va3, 0);     QS_WAIT(a, 4); QS_STEP(a, ks0 + 2);
+                QS_LOAD(a, va0, 16384); QS_WAIT(b, 4); QS_STEP(b, ks0 + 3);
+                QS_LOAD(b, va1, 16384); QS_WAIT(a, 4); QS_STEP(a, ks0 + 4);
+                QS_LOAD(a, va2, 16384); QS_WAIT(b, 4); QS_STEP(b, ks0 + 5);
+                QS_LOAD(b, va3, 16384); QS_WAIT(a, 4); QS_STEP(a, ks0 + 6);
+                                        QS_WAIT(b, 0); QS_STEP(b, ks0 + 7);
+#undef QS_STEP
+#undef QS_WAIT
+#undef QS_LOAD
             }
             if (kt == KT2 - 1 && !(p.ablate & 1)) {
                 PH_STAMP(ph0);
@@ -688,7 +724,7 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
                 // ---- maintenance: which queries need a (light) compaction? ----
                 const int pair = ccnt + __shfl_xor(ccnt, 32);
                 const bool warm = thkey == -INFINITY && pair >= p.b.kk;
-                const bool stale = pair >= p.b.kk && pair - clast >= REFRESH;
+                const bool stale = pair >= p.b.kk && pair - clast >= p.b.stale;
                 const bool full = ccnt > CAPH / 2 - BX / 2;           // my half could overflow on the next tile
                 u64 todo = __ballot(qvalid && (warm || stale || full));
                 todo = (todo | (todo >> 32)) & 0xffffffffull;          // one bit per query of this wave
@@ -847,6 +883,8 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
         p.q = q_dev + c0 * d; p.x = idx->x; p.qres2 = qres2; p.qhn2 = qhn2; p.xstat = idx->xn2max_dev;
         p.d = d; p.dpad_h = dpad_h; p.phase_dbg = nullptr;
         p.ablate = getenv("LEMON_ABLATE") ? atoi(getenv("LEMON_ABLATE")) : 0;
+        static const int refresh = [] { const char *e = getenv("LEMON_REFRESH"); return e && atoi(e) > 0 ? atoi(e) : REFRESH; }();
+        p.b.stale = refresh;                  // new candidates per query that trigger a light compaction (tuning knob)
         const unsigned grid = (unsigned)(panels * splits);
         const bool qs = dpad_h <= 768;
         // database chunks sized for the Infinity Cache (the chunk is re-read by every query panel)

@@ -147,6 +147,46 @@ def linear(x, weight, bias=None, residual=None, act=None, alpha=1.0):
     return y
 
 
+def layer_norm(x, weight, bias, eps=1e-5):
+    """nn.LayerNorm over the last dimension of a float32 CUDA tensor in one HIP pass (lemon_layernorm_f32)."""
+    assert x.is_cuda and x.dtype == torch.float32
+    x = x.contiguous()
+    width = x.shape[-1]
+    y = torch.empty_like(x)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.lemon_layernorm_f32(ptr(x), ptr(weight.contiguous()), ptr(bias.contiguous()), float(eps),
+                                           x.numel() // width, width, ptr(y), stream_ptr(x.device)), "lemon_layernorm_f32")
+    return y
+
+
+def vision_tokens_ln(patches, cls, pos, ln_weight, ln_bias, eps=1e-5):
+    """[B, nP, W] patch embeddings -> pre-LayerNormed token matrix [B, nP+1, W] (class token + positions) in one pass."""
+    assert patches.is_cuda and patches.dtype == torch.float32 and patches.dim() == 3
+    patches = patches.contiguous()
+    B, nP, W = patches.shape
+    y = torch.empty((B, nP + 1, W), dtype=torch.float32, device=patches.device)
+    lib = _lib.load()
+    with torch.cuda.device(patches.device):
+        _lib.check(lib.lemon_vision_tokens_ln(ptr(patches), ptr(cls.contiguous()), ptr(pos.contiguous()), ptr(ln_weight.contiguous()),
+                                              ptr(ln_bias.contiguous()), float(eps), B, nP + 1, W, ptr(y),
+                                              stream_ptr(patches.device)), "lemon_vision_tokens_ln")
+    return y
+
+
+def text_tokens(input_ids, seq_len, tok_weight, pos):
+    """tok_weight[ids[:, :seq_len]] + pos[:seq_len] -> [B, seq_len, W] in one pass (ids int64 CUDA [B, ctx])."""
+    assert input_ids.is_cuda and input_ids.dtype == torch.int64 and input_ids.dim() == 2 and input_ids.stride(1) == 1
+    B, W = input_ids.shape[0], tok_weight.shape[1]
+    y = torch.empty((B, seq_len, W), dtype=torch.float32, device=input_ids.device)
+    lib = _lib.load()
+    with torch.cuda.device(input_ids.device):
+        _lib.check(lib.lemon_text_tokens(ptr(input_ids), input_ids.stride(0), ptr(tok_weight.contiguous()), ptr(pos.contiguous()), B,
+                                         int(seq_len), W, tok_weight.shape[0], ptr(y), stream_ptr(input_ids.device)),
+                   "lemon_text_tokens")
+    return y
+
+
 def linear_dump_tuned(path):
     """Write the solution choices made so far in this process (tools/tune_gemms.py)."""
     return _lib.load().lemon_linear_dump_tuned(str(path).encode())
