@@ -40,7 +40,8 @@ extern "C" {
 #define LEMON_E_HIP (-2)     /* a HIP runtime call failed; see lemon_last_error()        */
 #define LEMON_E_NOMEM (-3)   /* device allocation failed                                 */
 
-#define LEMON_MAX_K 64 /* k + (sname == 'train') <= 64; the reference grid tops out at 50+1 (experiments.py:86) */
+#define LEMON_MAX_K 64 /* k + (sname == 'train') <= 64 in lemon_neighbors / one scan pass; the reference grid tops out at 50+1 (experiments.py:86) */
+#define LEMON_MAX_K_DEEP 2048 /* lemon_index_search accepts deeper lists (faiss has no limit): passes of LEMON_MAX_K */
 
 /* search algorithm selector for lemon_index_set_algo() */
 #define LEMON_ALGO_AUTO 0

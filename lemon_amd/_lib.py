@@ -10,7 +10,8 @@ SO_PATH = os.path.join(_HERE, "liblemon_hip.so")
 
 METRIC_IP = 0
 METRIC_L2 = 1
-MAX_K = 64
+MAX_K = 64            # per scan pass and in lemon_neighbors
+MAX_K_DEEP = 2048     # lemon_index_search (passes of MAX_K, include/lemon_hip.h)
 ALGO_AUTO, ALGO_F32_MFMA, ALGO_BF16_FILTER = 0, 1, 2
 
 # every symbol include/lemon_hip.h declares

@@ -236,7 +236,7 @@ int lemon_search_internal(lemon_index_t *idx, const float *q_dev, int64_t nq, in
                           int64_t *I_dev, hipStream_t stream) {
     LEMON_REQUIRE(idx != nullptr, "index handle");
     LEMON_REQUIRE(nq >= 0, "nq >= 0");
-    LEMON_REQUIRE(k >= 1 && k <= LEMON_MAX_K, "1 <= k <= LEMON_MAX_K");
+    LEMON_REQUIRE(k >= 1 && k <= LEMON_MAX_K_DEEP, "1 <= k <= LEMON_MAX_K_DEEP");
     if (nq == 0) return LEMON_OK;
     LEMON_REQUIRE(q_dev && D_dev && I_dev, "null pointer");
     // identical query rows (class prompts: 50 000 text queries, 100 distinct rows on CIFAR-100) are searched once
@@ -270,6 +270,7 @@ int lemon_search_internal(lemon_index_t *idx, const float *q_dev, int64_t nq, in
         }
     }
     int algo = idx->algo;
+    if (k > LEMON_MAX_K) algo = LEMON_ALGO_F32_MFMA;     // deep lists: key-bounded passes of the exact scan (knn_f32.hip)
     if (algo == LEMON_ALGO_AUTO) algo = lemon_auto_choose(idx, q_dev, nq, k, stream);
     int rc = (algo == LEMON_ALGO_BF16_FILTER) ? lemon_search_bf16(idx, q_dev, nq, k, D_dev, I_dev, stream)
                                               : lemon_search_f32(idx, q_dev, nq, k, D_dev, I_dev, stream);

@@ -55,6 +55,8 @@ struct ScanParams {
     int ablate;           // diagnostic instantiation only: 1 = no operand loads, 2 = no barriers (results invalid)
     int stale;            // new entries per query that trigger a re-selection (fp32 scan)
     int units_per_wg;     // > 0: balanced decomposition (see lemon_plan_balanced); splits = max pieces per panel
+    const u64 *ub;        // [nq_pad] exclusive upper bound on the key of an admissible row, or nullptr (k > 64: the
+                          // passes after the first only admit rows ranked behind the previous pass's last result)
 };
 
 __device__ __forceinline__ int swz(int r, int c) { return r * BK + 4 * (c ^ ((r >> 1) & 7)); }

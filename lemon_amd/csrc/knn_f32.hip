@@ -39,10 +39,10 @@ __global__ __launch_bounds__(256) void k_permute_rows(const float *__restrict__ 
 // survivors of one 32x32 accumulator tile: a[e] = exact score of (db row jb + (e&3) + 8(e>>2), this
 // lane's query); strict '>' against the query's k-th best (rows arrive in ascending index, so an equal
 // score with a later index loses).  Appends go to this lane's private half-list.
-template <bool L2>
+template <bool L2, bool UB>
 __device__ __forceinline__ void f32_filter_tile(f32x16 a, float th, int64_t jb, float qn,
                                                 const float *__restrict__ xnorm, int64_t n, int &ccnt,
-                                                u64 *__restrict__ mylist) {
+                                                u64 *__restrict__ mylist, u64 ub) {
     if (L2) {   // exact key of the numeric contract: -max(0, fma(-2, <q,x>, |q|^2 + |x|^2))
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -76,7 +76,10 @@ __device__ __forceinline__ void f32_filter_tile(f32x16 a, float th, int64_t jb, 
             if (hb[i]) {                                 // scalar branch on a value computed long ago
                 const int e = 8 * half + i;
                 const int64_t j = jb + (e & 3) + 8 * (e >> 2);
-                if (a[e] > th && j < n) mylist[ccnt++] = lemon_make_key(a[e], (u32)j);
+                if (a[e] > th && j < n) {
+                    const u64 key = lemon_make_key(a[e], (u32)j);
+                    if (!UB || key < ub) mylist[ccnt++] = key;
+                }
             }
         }
     }
@@ -85,7 +88,7 @@ __device__ __forceinline__ void f32_filter_tile(f32x16 a, float th, int64_t jb, 
 // One workgroup = 128 queries x a range of 128-row database tiles.  Wave w owns queries 32w..32w+31
 // (B operand, one query per lane pair) against all 128 rows of the tile (A operand, 4 row tiles):
 // acc_i[e] = <x_(32i + (e&3) + 8(e>>2) + 4h), q_(32w + lane&31)> accumulated in ascending k.
-template <bool L2, bool PROF>
+template <bool L2, bool PROF, bool UB = false>
 __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
     // diagnostic instantiation: per-phase cycle sums of wave 0 (loop incl. barriers, filter, maintenance, final)
     unsigned long long ts = 0, ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0;
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
     // lane-private candidate state (see knn_common.hpp "pair lists")
     const bool qvalid = q0 + qrow_l < p.nq;
     const float my_qn = L2 ? p.qnorm[q0 + qrow_l] : 0.0f;
+    const u64 my_ub = UB ? p.ub[q0 + qrow_l] : ~0ull;
     int ccnt = 0, clast = 0;
     float th = qvalid ? -INFINITY : INFINITY;    // exact score of the query's current k-th best
 
@@ -231,10 +235,10 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
                 PH_STAMP(ph3);                       // reported in the 'final' column
             }
             if (!(PROF && (p.ablate & 4) && jl > 4)) {     // diagnostic: bit 2 = skip the filter after 5 tiles
-            f32_filter_tile<L2>(acc0, th, jb, my_qn, p.xnorm, p.n, ccnt, mylist);
-            f32_filter_tile<L2>(acc1, th, jb + 32, my_qn, p.xnorm, p.n, ccnt, mylist);
-            f32_filter_tile<L2>(acc2, th, jb + 64, my_qn, p.xnorm, p.n, ccnt, mylist);
-            f32_filter_tile<L2>(acc3, th, jb + 96, my_qn, p.xnorm, p.n, ccnt, mylist);
+            f32_filter_tile<L2, UB>(acc0, th, jb, my_qn, p.xnorm, p.n, ccnt, mylist, my_ub);
+            f32_filter_tile<L2, UB>(acc1, th, jb + 32, my_qn, p.xnorm, p.n, ccnt, mylist, my_ub);
+            f32_filter_tile<L2, UB>(acc2, th, jb + 64, my_qn, p.xnorm, p.n, ccnt, mylist, my_ub);
+            f32_filter_tile<L2, UB>(acc3, th, jb + 96, my_qn, p.xnorm, p.n, ccnt, mylist, my_ub);
             }
             if (PROF && (p.ablate & 8) && jl > 4) ccnt = ccnt_in;   // diagnostic: bit 3 = appends land but are forgotten
 #pragma unroll
@@ -489,8 +493,62 @@ int lemon_ensure_search_ws(lemon_index_t *idx, int64_t nq_pad, int splits, int64
 // queries are processed in chunks so that the workspace stays bounded (1 GiB of candidates)
 static const int64_t QCHUNK = 1 << 19;
 
+namespace {
+// k > LEMON_MAX_K: one pass's [nq, kp] block goes to columns [col0, col0+kp) of the [nq, k] result, and the key of its
+// last entry becomes the query's exclusive upper bound for the next pass (0 = the database is exhausted)
+__global__ void k_place_pass(const float *__restrict__ Dp, const int64_t *__restrict__ Ip, int64_t nq, int kp, int k, int col0,
+                             int metric, float *__restrict__ D, int64_t *__restrict__ I, u64 *__restrict__ ub) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nq * kp) return;
+    const int64_t q = t / kp;
+    const int c = (int)(t - q * kp);
+    const float dv = Dp[t];
+    const int64_t iv = Ip[t];
+    D[q * k + col0 + c] = dv;
+    I[q * k + col0 + c] = iv;
+    if (c == kp - 1) ub[q] = iv < 0 ? 0ull : lemon_make_key(metric == LEMON_METRIC_L2 ? -dv : dv, (u32)iv);
+}
+__global__ void k_fill_u64(u64 *p, int64_t n, u64 v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+}  // namespace
+
+static int lemon_search_f32_pass(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, float *D_dev, int64_t *I_dev,
+                                 const u64 *ub_dev, hipStream_t stream);
+
 int lemon_search_f32(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, float *D_dev,
                      int64_t *I_dev, hipStream_t stream) {
+    if (k <= LEMON_MAX_K) return lemon_search_f32_pass(idx, q_dev, nq, k, D_dev, I_dev, nullptr, stream);
+    // faiss has no k limit: deeper lists are produced LEMON_MAX_K at a time, each pass admitting only rows whose key is
+    // below the last key of the previous pass (same order, same tie rule: the concatenation IS the sorted top-k)
+    const int kp_max = LEMON_MAX_K;
+    float *Dp = nullptr; int64_t *Ip = nullptr; u64 *ub = nullptr;
+    const int64_t nq_pad = round_up(nq, BQ);
+    if (hipMalloc((void **)&Dp, (size_t)nq * kp_max * 4) != hipSuccess || hipMalloc((void **)&Ip, (size_t)nq * kp_max * 8) != hipSuccess ||
+        hipMalloc((void **)&ub, (size_t)nq_pad * 8) != hipSuccess) {
+        if (Dp) (void)hipFree(Dp);
+        if (Ip) (void)hipFree(Ip);
+        lemon_set_error("deep search (k=%d) workspace allocation failed", k);
+        return LEMON_E_NOMEM;
+    }
+    hipLaunchKernelGGL(k_fill_u64, dim3((unsigned)((nq_pad + 255) / 256)), dim3(256), 0, stream, ub, nq_pad, ~0ull);
+    int rc = LEMON_OK;
+    for (int col0 = 0; col0 < k && rc == LEMON_OK; col0 += kp_max) {
+        const int kp = k - col0 < kp_max ? k - col0 : kp_max;
+        rc = lemon_search_f32_pass(idx, q_dev, nq, kp, Dp, Ip, col0 ? ub : nullptr, stream);
+        if (rc) break;
+        hipLaunchKernelGGL(k_place_pass, dim3((unsigned)((nq * kp + 255) / 256)), dim3(256), 0, stream, Dp, Ip, nq, kp, k, col0,
+                           idx->metric, D_dev, I_dev, ub);
+    }
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(Dp); (void)hipFree(Ip); (void)hipFree(ub);
+    idx->last.k = k;
+    return rc;
+}
+
+static int lemon_search_f32_pass(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, float *D_dev, int64_t *I_dev,
+                                 const u64 *ub_dev, hipStream_t stream) {
     const int d = idx->d, dpad = idx->dpad;
     if (idx->n == 0) return lemon_fill_empty(D_dev, I_dev, nq * k, idx->metric, stream);
     const int n_tiles = (int)((idx->n + BX - 1) / BX);
@@ -520,6 +578,7 @@ int lemon_search_f32(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, 
         p.nq = cn; p.n = idx->n; p.dpad = dpad; p.kk = k; p.metric = idx->metric;
         p.n_tiles = n_tiles; p.tiles_per_split = tiles_per_split; p.splits = splits; p.nq_pad = nq_pad;
         p.units_per_wg = units_per_wg; p.phase_dbg = nullptr;
+        p.ub = ub_dev ? ub_dev + c0 : nullptr;
         p.ablate = getenv("LEMON_ABLATE") ? atoi(getenv("LEMON_ABLATE")) : 0;   // diagnostic instantiation only
         static const int stale = [] { const char *e = getenv("LEMON_STALE"); return e && atoi(e) > 0 ? atoi(e) : 96; }();
         p.stale = stale;
@@ -527,7 +586,7 @@ int lemon_search_f32(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, 
             const double flops = 2.0 * (double)cn * (double)idx->n * (double)d;
             const double bytes = 4.0 * d * ((double)cn + (double)panels * (double)idx->n) + 12.0 * k * (double)cn;
             LemonProfScope prof(idx, stream, flops, bytes);
-            if (idx->metric == LEMON_METRIC_IP && getenv("LEMON_PHASE_PROF")) {   // diagnostic build: phase cycle sums
+            if (!ub_dev && idx->metric == LEMON_METRIC_IP && getenv("LEMON_PHASE_PROF")) {   // diagnostic build: phase cycle sums
                 static unsigned long long *dbg = nullptr;
                 if (!dbg) { (void)hipMalloc(&dbg, 64); (void)hipMemset(dbg, 0, 64); }
                 p.phase_dbg = dbg;
@@ -538,6 +597,9 @@ int lemon_search_f32(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, 
                 fprintf(stderr, "[phase f32] grid=%u loop=%.1f%% filter=%.1f%% maintain=%.1f%% final=%.1f%% cyc/WG=%.3g\n",
                         grid, 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, tot / grid);
                 (void)hipMemset(dbg, 0, 64);
+            } else if (ub_dev) {
+                if (idx->metric == LEMON_METRIC_L2) hipLaunchKernelGGL((k_scan_f32<true, false, true>), dim3(grid), dim3(NT), 0, stream, p);
+                else hipLaunchKernelGGL((k_scan_f32<false, false, true>), dim3(grid), dim3(NT), 0, stream, p);
             } else if (idx->metric == LEMON_METRIC_L2) hipLaunchKernelGGL((k_scan_f32<true, false>), dim3(grid), dim3(NT), 0, stream, p);
             else hipLaunchKernelGGL((k_scan_f32<false, false>), dim3(grid), dim3(NT), 0, stream, p);
         }

@@ -88,8 +88,8 @@ class _IndexFlat:
 
     def search(self, x, k):
         k = int(k)  # run_lemon.py passes k + (sname == 'train'), an int + bool
-        if not 1 <= k <= _lib.MAX_K:
-            raise ValueError(f"k must be in [1, {_lib.MAX_K}], got {k}")
+        if not 1 <= k <= _lib.MAX_K_DEEP:
+            raise ValueError(f"k must be in [1, {_lib.MAX_K_DEEP}], got {k}")
         t, was_numpy = self._to_dev(x, "search(x)")
         nq = t.shape[0]
         D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
@@ -102,8 +102,24 @@ class _IndexFlat:
         return D, I
 
     def data(self):
-        """Zero-copy view of the stored rows [ntotal, d] (valid until the next add)."""
-        raise NotImplementedError
+        """Zero-copy CUDA view [ntotal, d] of the stored rows (valid until the next add / until the index dies)."""
+        n = self.ntotal
+        if n == 0:
+            return torch.empty((0, self.d), dtype=torch.float32, device=self.device)
+
+        class _View:       # __cuda_array_interface__ v2: torch wraps the device pointer without copying
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = {"shape": (n, self.d), "typestr": "<f4", "data": (int(self._lib.lemon_index_data(self._h)), False),
+                                      "version": 2, "strides": None}
+        with torch.cuda.device(self.device):
+            return torch.as_tensor(v, device=self.device)
+
+    def reconstruct_n(self, i0=0, n=None):
+        """Rows [i0, i0+n) as stored (faiss `reconstruct_n`): a CUDA float32 copy [n, d]."""
+        n = self.ntotal - i0 if n is None else int(n)
+        assert 0 <= i0 and i0 + n <= self.ntotal
+        return self.data()[i0:i0 + n].clone()
 
 
 class IndexFlatIP(_IndexFlat):

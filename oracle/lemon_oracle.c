@@ -10,6 +10,13 @@
  *   - score aggregation, paired distances, normalisation, noise/splits: pinned
  *     by golden vectors generated from the importable reference modules
  *     (tests/golden/, tools/make_golden.py).
+ *   - the per-sample loop (lo_neighbors: self-exclusion, D_n / D_m sign quirk, discrete text metric,
+ *     --normalize_d1, DB subset with mixed in_db, record order) and the discrepancy baselines
+ *     (lo_discrepancy): pinned by fixtures produced by EXECUTING the reference's own scripts
+ *     (/root/reference/run_lemon.py and lib/baselines/discrepancy_baseline.py under runpy, with stand-ins for
+ *     faiss / the CLIP weights / the datasets: tools/make_golden_loop.py -> tests/golden/loop_*.npz,
+ *     disc_*.npz; tests/test_loop_golden.py, tests/test_disc_golden.py).  The faiss stand-in implements
+ *     THIS file's documented contract in numpy, so those fixtures pin the loop around the search, not:
  *   - kNN arithmetic (run_lemon.py:166-176,235-236): the reference delegates to
  *     the third-party package `faiss-gpu` (requirements.txt:21, version NOT
  *     pinned, source not under /root/reference, not installed here) and holds

@@ -1,7 +1,7 @@
 """Copy the judged summaries of a tools/gpu_profile.sh run from gpurun_out/ into profiles/<tag>/.
 python tools/collect_profiles.py [tag]"""
 import csv, glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles", tag)
 os.makedirs(P, exist_ok=True)
@@ -23,18 +23,31 @@ def pmc_rows(dirs):
     return rows
 
 def write_pmc(name, dirs):
+    """One row per (kernel, counter, launch geometry): launches, mean counter value (KB for FETCH_SIZE / WRITE_SIZE, raw
+    counts otherwise) and mean duration -- the per-launch rows of one bench run are ~10 000 lines of repeats."""
     rows = pmc_rows(dirs)
-    if rows:
-        with open(os.path.join(P, name), "w", newline="") as f:
-            w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
-        print(name, len(rows), "rows")
+    if not rows:
+        return
+    groups = {}
+    for r in rows:
+        key = (r["kernel"], r["counter"], r["grid"], r["wg"], r["vgpr"], r["agpr"], r["lds"])
+        groups.setdefault(key, []).append(r)
+    out = []
+    for key, rs in groups.items():
+        out.append(dict(kernel=key[0], counter=key[1], value_KB=sum(r["value_KB"] for r in rs) / len(rs),
+                        dur_ms=sum(r["dur_ms"] for r in rs) / len(rs), grid=key[2], wg=key[3], vgpr=key[4], agpr=key[5],
+                        lds=key[6], launches=len(rs)))
+    out.sort(key=lambda r: -r["dur_ms"] * r["launches"])
+    with open(os.path.join(P, name), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(out[0].keys())); w.writeheader(); w.writerows(out)
+    print(name, len(out), "rows (from", len(rows), "launch records)")
 
-for src, dst in ((f"bench_{tag}.json", "bench_default.json"), (f"prof_knn_{tag}.json", "knn_262144x768.json")):
+for src, dst in ((f"bench_{tag}.json", "bench_default.json"), (f"prof_knn_{tag}.json", "knn_1000000x768.json")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copyfile(os.path.join(G, src), os.path.join(P, dst)); print(dst)
-for d, dst in ((f"prof_bench_{tag}", "bench_default_kernel_stats.csv"), (f"prof_knn_{tag}", "knn_262144x768_kernel_stats.csv")):
+for d, dst in ((f"prof_bench_{tag}", "bench_default_kernel_stats.csv"), (f"prof_knn_{tag}", "knn_1000000x768_kernel_stats.csv")):
     f = one(f"{d}/**/*kernel_stats.csv")
     if f:
         shutil.copyfile(f, os.path.join(P, dst)); print(dst)
 write_pmc("bench_default_pmc.csv", [f"pmc_bench_fetch_{tag}", f"pmc_bench_write_{tag}", f"pmc_bench_mfma_{tag}"])
-write_pmc("knn_262144x768_pmc.csv", [f"pmc_fetch_{tag}", f"pmc_write_{tag}"])
+write_pmc("knn_1000000x768_pmc.csv", [f"pmc_fetch_{tag}", f"pmc_write_{tag}", f"pmc_mfma_{tag}"])
