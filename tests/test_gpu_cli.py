@@ -100,3 +100,35 @@ def test_cli_synthetic_mscoco_cat_noise_matches_oracle(hip, oracle, tmp_path, di
     assert main([a if a != out else out2 for a in argv]) == 0
     df2 = pickle.load(open(os.path.join(out2, "res.pkl"), "rb"))["df"]
     assert all(np.array_equal(np.stack(df[c].values), np.stack(df2[c].values)) for c in ("D_n", "dists_m", "dists_tr_n"))
+
+
+def test_cli_config0_shape_vit_b32_full_protocol_matches_oracle(hip, oracle, tmp_path):
+    """BASELINE configs[0]/[1] plumbing at the REAL encoder size: CIFAR-10 surface, pair-flip noise 0.4, ViT-B/32 (random
+    weights: no checkpoint offline), 3 000 synthetic images through the GPU preprocessing, k = 50, the full run incl. the
+    hyper-parameter search (small grid) and the output files; records == the oracle's on the cached embeddings."""
+    import glob
+    import pickle
+    from lemon_amd.run_lemon import main
+    out, cache = str(tmp_path / "run"), str(tmp_path / "cache")
+    assert main(["--output_dir", out, "--dataset", "cifar10", "--noise_type", "asymmetric", "--noise_level", "0.4", "--data_root",
+                 "synthetic:3000", "--clip_path", "random:vit-b-32", "--knn_k", "50", "--hparam_grid", "small", "--embedding_cache",
+                 cache, "--encoder_batch", "500"]) == 0
+    for f in ("args.json", "res.pkl", "know_val_labels_scores.csv", "done", "out.txt", "err.txt"):
+        assert os.path.exists(os.path.join(out, f)), f
+    res = pickle.load(open(os.path.join(out, "res.pkl"), "rb"))
+    df = res["df"]
+    assert (df.sset == "train").sum() == 2400 and set(df.sset.unique()) == {"train", "val", "test"}
+    emb = {}
+    for d_ in glob.glob(os.path.join(cache, "*")):
+        meta = pickle.load(open(os.path.join(d_, "meta.pkl"), "rb"))
+        emb[len(meta["prompts"])] = (np.load(os.path.join(d_, "img.npy")), np.load(os.path.join(d_, "txt.npy")), meta)
+    img_tr, txt_tr, _ = emb[2400]
+    assert img_tr.shape == (2400, 512) and np.abs(np.linalg.norm(img_tr, axis=1) - 1).max() < 1e-5
+    sub = df[df.sset == "train"]
+    ref = oracle.neighbors("cosine", img_tr, txt_tr, img_tr, txt_tr, 50, drop_self=True)
+    for col in ("D_n", "dists_n", "dists_tr_n", "D_m", "dists_m", "dists_tr_m"):
+        assert np.array_equal(np.stack(sub[col].values), ref[col]), col
+    agg = res["agg_results"]["know_val_labels"]
+    score = oracle.score({**ref, "d_1": ref["d_1"]}, {h: agg[h] for h in ("beta", "gamma", "tau_1_n", "tau_2_n", "tau_1_m", "tau_2_m")})
+    assert np.abs(sub["know_val_labels_pred_score"].values - score).max() < 1e-6
+    assert abs(oracle.auroc(sub["is_mislabel"].values, score) - agg["train"]["AUROC"]) < 1e-9

@@ -57,3 +57,25 @@ def test_two_ranks_on_one_card_equal_one_rank_and_the_reference(hip, case, tmp_p
         for col in REC + ("d_1",):
             got = np.stack(sub[col].values) if col != "d_1" else sub[col].values
             assert np.abs(got.astype(np.float64) - exp[col]).max() <= 2e-6, (s, col)
+
+
+def test_bench_self_launches_its_ranks(hip):
+    """`python bench.py --gpus 2` started by hand (no torchrun, no WORLD_SIZE): the parent spawns the two ranks itself before
+    touching the GPU and relays rank 0's JSON line; here both ranks share cuda:0 over gloo."""
+    import json
+    env = dict(os.environ, LEMON_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k_, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--arch",
+                          "tiny", "--n_train", "1500", "--n_val", "200", "--n_test", "200", "--knn_k", "5", "--encoder_batch", "256",
+                          "--no_cpu_baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert "knn_1m" not in line and "cpu_baseline" not in line          # N = 1 extras only
+    assert line["config"]["parallelism"] == "dp2+allgather"
+    # WORLD_SIZE that contradicts --gpus is an error, not a silent single-GPU run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"],
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0
