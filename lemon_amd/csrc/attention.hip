@@ -40,20 +40,18 @@ __global__ __launch_bounds__(576) void k_attention_hd64(const float *__restrict_
     const int64_t tok_stride = (int64_t)3 * H * HD;            // floats between consecutive tokens
     const float *base = qkv + b * L * tok_stride + head * HD;  // q of token 0; k at +H*HD, v at +2*H*HD
 
-    // ---- stage K and V (zero rows beyond L: masked scores give p = 0 and 0 * 0 stays 0) ----
-    for (int id = tid; id < 32 * TJ * 16; id += blockDim.x) {
-        const int r = id >> 4, c = id & 15;
-        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-        if (r < L) {
-            const float *src = base + (int64_t)r * tok_stride + 4 * c;
-            kv = *reinterpret_cast<const float4 *>(src + H * HD);
-            vv = *reinterpret_cast<const float4 *>(src + 2 * H * HD);
-        }
-        *reinterpret_cast<float4 *>(&sK[r * PITCH + 4 * c]) = kv;
-        *reinterpret_cast<float4 *>(&sV[r * PITCH + 4 * c]) = vv;
+    // ---- all global loads of the workgroup are issued up front: K, this lane's Q row, then V.  blockDim = 64*TJ, so every
+    //      thread owns exactly 8 16-B chunks of K and 8 of V.  K goes to LDS at once; V stays in registers while the first
+    //      score tile is being multiplied (its load latency hides behind those 32 MFMAs) and is parked in LDS just before
+    //      the first P.V product needs it.  (zero rows beyond L: masked scores give p = 0 and 0 * 0 stays 0) ----
+    float4 kreg[8], vreg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int id = tid + i * blockDim.x, r = id >> 4, c = id & 15;
+        kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < L) kreg[i] = *reinterpret_cast<const float4 *>(base + (int64_t)r * tok_stride + 4 * c + H * HD);
     }
-
-    // ---- this lane's query row, columns 32h..32h+31 (the k-index pairing of MFMA #1) ----
+    // this lane's query row, columns 32h..32h+31 (the k-index pairing of MFMA #1)
     const int qi = 32 * wave + l31;
     const int qrow = qi < L ? qi : L - 1;
     float q[32];
@@ -64,6 +62,17 @@ __global__ __launch_bounds__(576) void k_attention_hd64(const float *__restrict_
             const float4 t = *reinterpret_cast<const float4 *>(src + 4 * u);
             q[4 * u] = t.x; q[4 * u + 1] = t.y; q[4 * u + 2] = t.z; q[4 * u + 3] = t.w;
         }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int id = tid + i * blockDim.x, r = id >> 4, c = id & 15;
+        vreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < L) vreg[i] = *reinterpret_cast<const float4 *>(base + (int64_t)r * tok_stride + 4 * c + 2 * H * HD);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int id = tid + i * blockDim.x, r = id >> 4, c = id & 15;
+        *reinterpret_cast<float4 *>(&sK[r * PITCH + 4 * c]) = kreg[i];
     }
     __syncthreads();
 
@@ -109,6 +118,14 @@ __global__ __launch_bounds__(576) void k_attention_hd64(const float *__restrict_
         lt += __shfl_xor(lt, 32);
         l_run = l_run * alpha + lt;
         m_run = m_new;
+        if (tj == 0) {                                // every wave passes here exactly once (tj_end >= 1): V into LDS
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int id = tid + i * blockDim.x, r = id >> 4, c = id & 15;
+                *reinterpret_cast<float4 *>(&sV[r * PITCH + 4 * c]) = vreg[i];
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
         // O^T += V^T P^T : k-step m pairs keys (m&3) + 8(m>>2) + 4h of the tile, i.e. s[m] as it lies
