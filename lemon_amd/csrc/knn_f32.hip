@@ -39,10 +39,13 @@ __global__ __launch_bounds__(256) void k_permute_rows(const float *__restrict__ 
 // survivors of one 32x32 accumulator tile: a[e] = exact score of (db row jb + (e&3) + 8(e>>2), this
 // lane's query); strict '>' against the query's k-th best (rows arrive in ascending index, so an equal
 // score with a later index loses).  Appends go to this lane's private half-list.
+// (appends address the list as uniform base + 32-bit lane offset and compare row numbers in 32 bits: the 64-bit forms
+// cost ~8 more VALU instructions per survivor, and every VALU instruction of the epilogue issues at a fraction of its
+// normal rate against the co-resident workgroup's MFMA stream)
 template <bool L2, bool UB>
-__device__ __forceinline__ void f32_filter_tile(f32x16 a, float th, int64_t jb, float qn,
-                                                const float *__restrict__ xnorm, int64_t n, int &ccnt,
-                                                u64 *__restrict__ mylist, u64 ub) {
+__device__ __forceinline__ void f32_filter_tile(f32x16 a, float th, unsigned jb, float qn,
+                                                const float *__restrict__ xnorm, unsigned n, int &ccnt,
+                                                char *__restrict__ panel_bytes, unsigned my_off, u64 ub) {
     if (L2) {   // exact key of the numeric contract: -max(0, fma(-2, <q,x>, |q|^2 + |x|^2))
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -75,10 +78,13 @@ __device__ __forceinline__ void f32_filter_tile(f32x16 a, float th, int64_t jb, 
         for (int i = 0; i < 8; ++i) {
             if (hb[i]) {                                 // scalar branch on a value computed long ago
                 const int e = 8 * half + i;
-                const int64_t j = jb + (e & 3) + 8 * (e >> 2);
+                const unsigned j = jb + (e & 3) + 8 * (e >> 2);
                 if (a[e] > th && j < n) {
-                    const u64 key = lemon_make_key(a[e], (u32)j);
-                    if (!UB || key < ub) mylist[ccnt++] = key;
+                    const u64 key = lemon_make_key(a[e], j);
+                    if (!UB || key < ub) {
+                        *reinterpret_cast<u64 *>(panel_bytes + (my_off + 8u * (unsigned)ccnt)) = key;
+                        ++ccnt;
+                    }
                 }
             }
         }
@@ -120,7 +126,8 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
     const unsigned voff = (unsigned)(((tid >> 3) * dpad + 4 * (tid & 7)) * 4);
     u64 *cand_panel = p.cand + (int64_t)blockIdx.x * BQ * PAIR_CAP;
     const int qrow_l = 32 * wave + l31;
-    u64 *mylist = cand_panel + (int64_t)qrow_l * PAIR_CAP + h * (PAIR_CAP / 2);
+    char *panel_bytes = reinterpret_cast<char *>(cand_panel);
+    const unsigned my_off = (unsigned)(qrow_l * PAIR_CAP + h * (PAIR_CAP / 2)) * 8u;   // this lane's half-list, in bytes
 
     while (ub < ue) {                                   // workgroup-uniform
     const int panel = (int)(ub / p.n_tiles);
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
             // one, while the co-resident workgroup's waves keep the MFMA pipe busy either way)
             PH_STAMP(ph0);
             __builtin_amdgcn_s_setprio(3);
-            const int64_t jb = (int64_t)(t_begin + jl) * BX + 4 * h;
+            const unsigned jb = (unsigned)(t_begin + jl) * BX + 4 * h;
             const int ccnt_in = ccnt;
             if (PROF && (p.ablate & 16)) {           // diagnostic: bit 4 = time the bare accumulator read-out (64-value max)
                 float mx = acc0[0];
@@ -235,10 +242,10 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
                 PH_STAMP(ph3);                       // reported in the 'final' column
             }
             if (!(PROF && (p.ablate & 4) && jl > 4)) {     // diagnostic: bit 2 = skip the filter after 5 tiles
-            f32_filter_tile<L2, UB>(acc0, th, jb, my_qn, p.xnorm, p.n, ccnt, mylist, my_ub);
-            f32_filter_tile<L2, UB>(acc1, th, jb + 32, my_qn, p.xnorm, p.n, ccnt, mylist, my_ub);
-            f32_filter_tile<L2, UB>(acc2, th, jb + 64, my_qn, p.xnorm, p.n, ccnt, mylist, my_ub);
-            f32_filter_tile<L2, UB>(acc3, th, jb + 96, my_qn, p.xnorm, p.n, ccnt, mylist, my_ub);
+            f32_filter_tile<L2, UB>(acc0, th, jb, my_qn, p.xnorm, (unsigned)p.n, ccnt, panel_bytes, my_off, my_ub);
+            f32_filter_tile<L2, UB>(acc1, th, jb + 32, my_qn, p.xnorm, (unsigned)p.n, ccnt, panel_bytes, my_off, my_ub);
+            f32_filter_tile<L2, UB>(acc2, th, jb + 64, my_qn, p.xnorm, (unsigned)p.n, ccnt, panel_bytes, my_off, my_ub);
+            f32_filter_tile<L2, UB>(acc3, th, jb + 96, my_qn, p.xnorm, (unsigned)p.n, ccnt, panel_bytes, my_off, my_ub);
             }
             if (PROF && (p.ablate & 8) && jl > 4) ccnt = ccnt_in;   // diagnostic: bit 3 = appends land but are forgotten
 #pragma unroll
