@@ -418,9 +418,9 @@ __global__ __launch_bounds__(NT, 2) void k_scan_bf16(ScanParamsH p) {
 
 // one 32x32 accumulator tile: a[e] = s~(db row jb + (e&3) + 8(e>>2), this lane's query)
 template <bool l2>
-__device__ __forceinline__ void qs_filter_tile(f32x16 a, float th, int64_t jb, float qn,
-                                               const float *__restrict__ xnorm, int64_t n, int &ccnt,
-                                               u64 *__restrict__ mylist) {
+__device__ __forceinline__ void qs_filter_tile(f32x16 a, float th, unsigned jb, float qn,
+                                               const float *__restrict__ xnorm, unsigned n, int &ccnt,
+                                               char *__restrict__ panel_bytes, unsigned my_off) {
     if (l2) {   // monotone proxy of the key -D: 2 s~ - |x|^2 = key + |q|^2 (th carries the same offset)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -445,11 +445,12 @@ __device__ __forceinline__ void qs_filter_tile(f32x16 a, float th, int64_t jb, f
             if (mq[g] > th) {                       // ... in this quad of rows
 #pragma unroll
                 for (int e = 4 * g; e < 4 * g + 4; ++e) {
-                    const int64_t j = jb + (e & 3) + 8 * (e >> 2);
+                    const unsigned j = jb + (e & 3) + 8 * (e >> 2);
                     if (a[e] > th && j < n) {
                         // approximate key: for L2 the clamped -D~ = min(0, proxy - |q|^2)
                         const float s = l2 ? fminf(0.0f, a[e] - qn) : a[e];
-                        mylist[ccnt++] = lemon_make_key(s, (u32)j);
+                        *reinterpret_cast<u64 *>(panel_bytes + (my_off + 8u * (unsigned)ccnt)) = lemon_make_key(s, j);
+                        ++ccnt;
                     }
                 }
             }
@@ -611,7 +612,8 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
     const bool qvalid = q0 + qrow_l < p.b.nq;
     const float my_qn = p.b.qnorm[q0 + qrow_l];
     u64 *cand_panel = p.b.cand + (int64_t)blockIdx.x * BQ * CAPH;
-    u64 *mylist = cand_panel + (int64_t)qrow_l * CAPH + h * (CAPH / 2);
+    char *panel_bytes = reinterpret_cast<char *>(cand_panel);          // appends: uniform base + 32-bit lane offset
+    const unsigned my_off = (unsigned)(qrow_l * CAPH + h * (CAPH / 2)) * 8u;
     int ccnt = 0, clast = 0;                   // entries in my half-list; pair length right after the last compaction
     float thkey = qvalid ? -INFINITY : INFINITY;   // admission bound in key units (shared by the pair)
     if (p.b.splits == 1 && !p.first_chunk) {   // resume from the previous database chunk
@@ -714,11 +716,11 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
                 // 16-pass MFMA latency here (once per tile)
                 asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc0), "+a"(acc1), "+a"(acc2), "+a"(acc3));
                 // ---- epilogue: acc[ni][e] = s~(db row 32ni + (e&3) + 8(e>>2) + 4h, query lane&31) ----
-                const int64_t jb = (int64_t)(t_begin + jl) * BX + 4 * h;
-                qs_filter_tile<l2>(acc0, th, jb, my_qn, p.b.xnorm, p.b.n, ccnt, mylist);
-                qs_filter_tile<l2>(acc1, th, jb + 32, my_qn, p.b.xnorm, p.b.n, ccnt, mylist);
-                qs_filter_tile<l2>(acc2, th, jb + 64, my_qn, p.b.xnorm, p.b.n, ccnt, mylist);
-                qs_filter_tile<l2>(acc3, th, jb + 96, my_qn, p.b.xnorm, p.b.n, ccnt, mylist);
+                const unsigned jb = (unsigned)(t_begin + jl) * BX + 4 * h;
+                qs_filter_tile<l2>(acc0, th, jb, my_qn, p.b.xnorm, (unsigned)p.b.n, ccnt, panel_bytes, my_off);
+                qs_filter_tile<l2>(acc1, th, jb + 32, my_qn, p.b.xnorm, (unsigned)p.b.n, ccnt, panel_bytes, my_off);
+                qs_filter_tile<l2>(acc2, th, jb + 64, my_qn, p.b.xnorm, (unsigned)p.b.n, ccnt, panel_bytes, my_off);
+                qs_filter_tile<l2>(acc3, th, jb + 96, my_qn, p.b.xnorm, (unsigned)p.b.n, ccnt, panel_bytes, my_off);
                 PH_STAMP(ph1);
 
                 // ---- maintenance: which queries need a (light) compaction? ----
