@@ -55,6 +55,8 @@ struct ScanParams {
     int ablate;           // diagnostic instantiation only: 1 = no operand loads, 2 = no barriers (results invalid)
     int stale;            // new entries per query that trigger a re-selection (fp32 scan)
     int units_per_wg;     // > 0: balanced decomposition (see lemon_plan_balanced); splits = max pieces per panel
+    unsigned *th_pub;     // [nq_pad] order-encoded admission bounds the workgroups sharing a query panel publish to each
+                          // other (zero-initialised per launch), or nullptr: see k_scan_f32 "shared bounds"
     const u64 *ub;        // [nq_pad] exclusive upper bound on the key of an admissible row, or nullptr (k > 64: the
                           // passes after the first only admit rows ranked behind the previous pass's last result)
 };
@@ -123,7 +125,10 @@ struct PairSlots {
             int c = 0;
 #pragma unroll
             for (int i = 0; i < NS; ++i) c += __builtin_popcountll(__ballot((u32)(v[i] >> 32) >= cand));
-            if (c >= kk) { th_hi = cand; c_hi = c; }    // wave-uniform
+            if (c >= kk) {                              // wave-uniform
+                th_hi = cand; c_hi = c;
+                if (c == kk) break;                     // exactly kk keys reach this prefix: they ARE the top kk
+            }
         }
         u64 t = (u64)th_hi << 32;                       // all keys with a larger score word are in
         if (th_hi == 0 || c_hi != kk) {                 // tie at the kk-th score (or c_hi never set): refine

@@ -146,7 +146,15 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
     const float my_qn = L2 ? p.qnorm[q0 + qrow_l] : 0.0f;
     const u64 my_ub = UB ? p.ub[q0 + qrow_l] : ~0ull;
     int ccnt = 0, clast = 0;
-    float th = qvalid ? -INFINITY : INFINITY;    // exact score of the query's current k-th best
+    float th = qvalid ? -INFINITY : INFINITY;    // admission bound: max(own bound, bound imported from the other pieces)
+    // Shared bounds.  A query panel is scanned by 2-3 workgroups (stream-K pieces) or by `splits` of them, each over its
+    // own rows.  The k-th best score inside ANY subset of the rows is a lower bound of the k-th best over all of them, so
+    // a piece may drop every row that is strictly below another piece's bound.  Each workgroup publishes its own bound
+    // (order-encoded, atomicMax) after a re-selection and reads the panel's maximum once per tile; it uses the next lower
+    // float of what it reads, because a row that TIES the imported bound may still win on the index.  The pieces' cold
+    // starts then cost one warm-up in total instead of one each: at the headline shape ~35 % fewer admissions.
+    float th_own = th;                           // bound derived from this workgroup's own list (what gets published)
+    unsigned pub = 0;                            // last value read from th_pub (0 = nothing published yet)
 
     // Operand staging global -> registers -> LDS with TWO register sets: set (s & 1) carries stage s.
     // At step s the stage s+1 is committed to the other LDS buffer and the freed set is re-issued for
@@ -225,6 +233,8 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
         if (!abl_bar) __syncthreads();
         F32_STEP(1, a, it + 1);                  // odd stage: LDS buffer 1; set a holds stage it+2
         const bool tile_done = ((it + 2) % KT) == 0;
+        if (p.th_pub && (it % KT) == 0)              // first k-step pair of a tile: fetch the panel's published bound
+            pub = __atomic_load_n(&p.th_pub[q0 + qrow_l], __ATOMIC_RELAXED);
 
         if (tile_done) {
             // ---- epilogue: filter into the lane-private half-lists, then zero the accumulators ----
@@ -234,6 +244,7 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
             __builtin_amdgcn_s_setprio(3);
             const unsigned jb = (unsigned)(t_begin + jl) * BX + 4 * h;
             const int ccnt_in = ccnt;
+            if (p.th_pub && pub > 1u) th = fmaxf(th, lemon_ord2f(pub - 1u));   // strictly below the published bound
             if (PROF && (p.ablate & 16)) {           // diagnostic: bit 4 = time the bare accumulator read-out (64-value max)
                 float mx = acc0[0];
 #pragma unroll
@@ -241,6 +252,25 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
                 if (mx == 123.456f) ph3 += 1;       // keep it alive
                 PH_STAMP(ph3);                       // reported in the 'final' column
             }
+            if (PROF && (p.ablate & (32 | 128)) && jl > 4) {
+                // diagnostic: what does the co-resident MFMA stream cost an epilogue per instruction CLASS?  The filter is
+                // replaced by instructions of one kind: bit 5 = 512 VALU (4 independent chains; measured 12.7 cycles each
+                // instead of 4), bit 7 = 256 ballot + scalar-branch pairs (never taken)
+                float x0 = acc0[0], x1 = acc1[0], x2 = acc2[0], x3 = acc3[0];
+                                if (p.ablate & 32) {
+#pragma unroll 1
+                    for (int r = 0; r < 8; ++r)
+                        asm volatile(".rept 16\n\tv_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %4\n\tv_add_f32 %2, %2, %4\n\tv_add_f32 %3, %3, %4\n\t.endr"
+                                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(th));
+                } else {
+#pragma unroll 1
+                    for (int r = 0; r < 256; ++r) {
+                        if (__ballot(x0 > 3.0e38f)) x1 += 1.0f;     // v_cmp -> SGPR -> scalar branch, never taken
+                        asm volatile("" : "+v"(x0));
+                    }
+                }
+                if (x0 + x1 + x2 + x3 == 1.2345f) ph3 += 1;    // keep alive
+            } else
             if (!(PROF && (p.ablate & 4) && jl > 4)) {     // diagnostic: bit 2 = skip the filter after 5 tiles
             f32_filter_tile<L2, UB>(acc0, th, jb, my_qn, p.xnorm, (unsigned)p.n, ccnt, panel_bytes, my_off, my_ub);
             f32_filter_tile<L2, UB>(acc1, th, jb + 32, my_qn, p.xnorm, (unsigned)p.n, ccnt, panel_bytes, my_off, my_ub);
@@ -255,7 +285,7 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
             // ---- maintenance: select the exact top-kk of queries whose lists grew enough ----
             PH_STAMP(ph1);
             const int pair = ccnt + __shfl_xor(ccnt, 32);
-            const bool warm = th == -INFINITY && pair >= p.kk;
+            const bool warm = th_own == -INFINITY && pair >= p.kk;
             const bool stale = pair >= p.kk && pair - clast >= p.stale;
             const bool full = ccnt > PAIR_CAP / 2 - BX / 2;
             u64 todo = __ballot(qvalid && (warm || stale || full));
@@ -272,7 +302,9 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
                     if (l31 == r) {                    // both lanes of the pair take the new state
                         ccnt = h == 0 ? kept : 0;
                         clast = kept;
-                        th = lemon_key_score(kth);     // <= the exact kk-th best: a valid admission threshold
+                        th_own = lemon_key_score(kth); // <= the exact kk-th best: a valid admission threshold
+                        th = fmaxf(th, th_own);
+                        if (p.th_pub && h == 0) atomicMax(&p.th_pub[q0 + 32 * wave + r], lemon_f2ord(th_own));
                     }
                 } while (todo);
             }
@@ -586,6 +618,14 @@ static int lemon_search_f32_pass(lemon_index_t *idx, const float *q_dev, int64_t
         p.n_tiles = n_tiles; p.tiles_per_split = tiles_per_split; p.splits = splits; p.nq_pad = nq_pad;
         p.units_per_wg = units_per_wg; p.phase_dbg = nullptr;
         p.ub = ub_dev ? ub_dev + c0 : nullptr;
+        // shared admission bounds: one order-encoded float per query, in the tail of the norm workspace ([ws_q, 3] floats:
+        // norms, then two spare columns), zeroed per launch; only when a panel really is scanned by several workgroups
+        static const bool share = [] { const char *e = getenv("LEMON_SHARE_BOUNDS"); return !(e && e[0] == '0'); }();
+        p.th_pub = nullptr;
+        if (share && (units_per_wg > 0 || splits > 1)) {
+            p.th_pub = reinterpret_cast<unsigned *>(idx->ws_qnorm + 2 * idx->ws_q);
+            LEMON_HIP_CHECK(hipMemsetAsync(p.th_pub, 0, (size_t)nq_pad * sizeof(unsigned), stream));
+        }
         p.ablate = getenv("LEMON_ABLATE") ? atoi(getenv("LEMON_ABLATE")) : 0;   // diagnostic instantiation only
         static const int stale = [] { const char *e = getenv("LEMON_STALE"); return e && atoi(e) > 0 ? atoi(e) : 96; }();
         p.stale = stale;
