@@ -1,4 +1,5 @@
 #!/bin/bash
+# Round-end validation on the GPU box (via gpurun): the whole GPU test suite, then tools/gpu_profile.sh (bench + rocprofv3 summaries).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
