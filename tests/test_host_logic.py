@@ -199,3 +199,26 @@ def test_pil_bicubic_tables_reproduce_pil_resize(h, w, oh, ow):
     got = axis(axis(img, ow).transpose(1, 0, 2), oh).transpose(1, 0, 2)      # horizontal pass, then vertical
     ref = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BICUBIC))
     assert np.array_equal(got, ref)
+
+
+def test_embedding_cache_roundtrip_and_keying(tmp_path):
+    """lemon_amd/cache.py: an entry is found again only for the same dataset / noise / checkpoint / shard / prompts, and a
+    partially written entry (no `done` marker) is never read."""
+    import torch
+    from lemon_amd.cache import EmbeddingCache
+    c = EmbeddingCache(str(tmp_path), dataset="cifar10", noise_type="asymmetric", noise_level=0.4, data_seed=0, clip_path="random")
+    img, txt = torch.randn(5, 8), torch.randn(5, 8)
+    prompts = [f"A photo of a thing{i}" for i in range(5)]
+    meta = {"prompts": prompts, "lo": 0}
+    assert c.load("train", 0, 5, prompts, "cpu") is None
+    c.store("train", 0, 5, prompts, img, txt, meta)
+    hit = c.load("train", 0, 5, prompts, "cpu")
+    assert hit is not None and torch.equal(hit[0], img) and torch.equal(hit[1], txt) and hit[2]["prompts"] == prompts
+    assert c.load("val", 0, 5, prompts, "cpu") is None                         # other split
+    assert c.load("train", 0, 5, prompts[::-1], "cpu") is None                 # other noise realisation
+    other = EmbeddingCache(str(tmp_path), dataset="cifar10", noise_type="asymmetric", noise_level=0.2, data_seed=0, clip_path="random")
+    assert other.load("train", 0, 5, prompts, "cpu") is None
+    entry = [d for d in tmp_path.iterdir() if d.is_dir()][0]
+    (entry / "done").unlink()
+    assert c.load("train", 0, 5, prompts, "cpu") is None
+    assert EmbeddingCache(None).load("train", 0, 5, prompts, "cpu") is None    # disabled cache
