@@ -54,6 +54,7 @@ struct ScanParams {
     unsigned long long *phase_dbg;   // diagnostic instantiation only: 4 cycle sums
     int ablate;           // diagnostic instantiation only: 1 = no operand loads, 2 = no barriers (results invalid)
     int stale;            // new entries per query that trigger a re-selection (fp32 scan)
+    int fair;             // fp32 scan: the co-resident workgroups of a CU take turns at the higher issue priority
     int units_per_wg;     // > 0: balanced decomposition (see lemon_plan_balanced); splits = max pieces per panel
     unsigned *th_pub;     // [nq_pad] order-encoded admission bounds the workgroups sharing a query panel publish to each
                           // other (zero-initialised per launch), or nullptr: see k_scan_f32 "shared bounds"

@@ -15,6 +15,7 @@
 #include "knn_common.hpp"
 
 using namespace lemon_knn;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -42,6 +43,12 @@ __global__ __launch_bounds__(256) void k_permute_rows(const float *__restrict__ 
 // (appends address the list as uniform base + 32-bit lane offset and compare row numbers in 32 bits: the 64-bit forms
 // cost ~8 more VALU instructions per survivor, and every VALU instruction of the epilogue issues at a fraction of its
 // normal rate against the co-resident workgroup's MFMA stream)
+__device__ __forceinline__ float max3(float x, float y, float z) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+
 template <bool L2, bool UB>
 __device__ __forceinline__ void f32_filter_tile(f32x16 a, float th, unsigned jb, float qn,
                                                 const float *__restrict__ xnorm, unsigned n, int &ccnt,
@@ -63,11 +70,10 @@ __device__ __forceinline__ void f32_filter_tile(f32x16 a, float th, unsigned jb,
     // overlap) and each element is guarded by a SCALAR branch on its ballot -- the per-element
     // compare -> saveexec -> execz-branch chains of the straightforward form serialised those latencies
     // and cost ~10 % of the launch at N = 40 000, where ~35 rows per wave and tile pass.
-    const float m0 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
-    const float m1 = fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7]));
-    const float m2 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11]));
-    const float m3 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
-    const float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    // 16-value maximum in 8 v_max3_f32 (fmaxf() costs 23: hipcc quiets every input with v_max x, x first -- matrix-core
+    // results are never signalling, and a quiet NaN element is ignored here exactly as the per-element '>' ignores it)
+    const float m = max3(max3(max3(a[0], a[1], a[2]), max3(a[3], a[4], a[5]), max3(a[6], a[7], a[8])),
+                         max3(max3(a[9], a[10], a[11]), max3(a[12], a[13], a[14]), a[15]), a[15]);
     if (__ballot(m > th) == 0) return;                   // wave-uniform
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -79,7 +85,7 @@ __device__ __forceinline__ void f32_filter_tile(f32x16 a, float th, unsigned jb,
             if (hb[i]) {                                 // scalar branch on a value computed long ago
                 const int e = 8 * half + i;
                 const unsigned j = jb + (e & 3) + 8 * (e >> 2);
-                if (a[e] > th && j < n) {
+                if (a[e] > th) {                         // (rows >= n: masked to -inf by the caller, last tile only)
                     const u64 key = lemon_make_key(a[e], j);
                     if (!UB || key < ub) {
                         *reinterpret_cast<u64 *>(panel_bytes + (my_off + 8u * (unsigned)ccnt)) = key;
@@ -99,7 +105,8 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
     // diagnostic instantiation: per-phase cycle sums of wave 0 (loop incl. barriers, filter, maintenance, final)
     unsigned long long ts = 0, ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0;
 #define PH_STAMP(acc) do { if (PROF) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - ts; ts = now_; } } while (0)
-    if (PROF) ts = __builtin_amdgcn_s_memtime();
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (PROF) { ts = __builtin_amdgcn_s_memtime(); clk0 = ts; rt0 = __builtin_amdgcn_s_memrealtime(); }
     __shared__ __attribute__((aligned(16))) float s_tile[2][2][BQ * BK];  // [buf][Q|X][row*32+..] 64 KiB
     __shared__ __attribute__((aligned(16))) u64 s_keys[NT / 64][256];    // rank-merge scratch, one per wave
     const int tid = threadIdx.x;
@@ -121,9 +128,28 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
         ue = ub + p.tiles_per_split;
         if (ue > (int64_t)(pnl + 1) * p.n_tiles) ue = (int64_t)(pnl + 1) * p.n_tiles;
     }
+    // Fair shares of the matrix pipe.  The two wavefronts of a SIMD (one from each co-resident workgroup) both have MFMAs
+    // ready most of the time, and the issue arbiter prefers the OLDER one: measured at 131 072^2 x 512, the workgroups
+    // in the even wave slots lived 106 ms, those in the odd slots 130 ms -- for the last fifth of the launch half the
+    // waves ran alone, at little more than half the pipe's rate.  So the two take turns: issue priority 1 for the wave
+    // whose slot parity equals bit 13 of the chip-wide 100 MHz counter (82 us per turn, re-evaluated after every tile),
+    // 0 for the other.  (The epilogue raises itself to 3 either way.)
+    const unsigned slot_parity = __builtin_amdgcn_s_getreg((1 << 11) | (0 << 6) | 4) & 1u;   // HW_ID[0]: wave slot on this SIMD
+#define F32_BASE_PRIO()                                                                                \
+    do {                                                                                               \
+        if (p.fair >= 100) {       /* diagnostic: static priority by wave slot (100: even slots high, 101: odd) */ \
+            if ((slot_parity ^ (unsigned)p.fair ^ 1u) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); \
+        } else if (p.fair) {                                                                           \
+            if ((((unsigned)__builtin_amdgcn_s_memrealtime() >> p.fair) ^ slot_parity) & 1u) __builtin_amdgcn_s_setprio(1); \
+            else __builtin_amdgcn_s_setprio(0);                                                        \
+        } else __builtin_amdgcn_s_setprio(0);                                                          \
+    } while (0)
+    F32_BASE_PRIO();
     const int KT = p.dpad / BK;
     const int dpad = p.dpad;
-    const unsigned voff = (unsigned)(((tid >> 3) * dpad + 4 * (tid & 7)) * 4);
+    const unsigned voff = (unsigned)(((tid >> 3) * dpad + 4 * (tid & 7)) * 4);   // row tid>>3 (+ 32 i), chunk tid&7: bytes
+    const unsigned voff1 = voff + (unsigned)(NT / 8) * dpad * 4, voff2 = voff1 + (unsigned)(NT / 8) * dpad * 4,
+                   voff3 = voff2 + (unsigned)(NT / 8) * dpad * 4;
     u64 *cand_panel = p.cand + (int64_t)blockIdx.x * BQ * PAIR_CAP;
     const int qrow_l = 32 * wave + l31;
     char *panel_bytes = reinterpret_cast<char *>(cand_panel);
@@ -155,6 +181,10 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
     // starts then cost one warm-up in total instead of one each: at the headline shape ~35 % fewer admissions.
     float th_own = th;                           // bound derived from this workgroup's own list (what gets published)
     unsigned pub = 0;                            // last value read from th_pub (0 = nothing published yet)
+    // (hand-issued like the operand loads, device-coherent: hipcc does not see those, so its own wait for this value would
+    // be vmcnt(0) = drain the operand prefetch once per tile.  At least 16 operand loads follow every fetch before its use.)
+#define F32_PUB_FETCH() do { if (p.th_pub) asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 sc0 sc1" : "=v"(pub) : "v"(4u * (unsigned)qrow_l), "s"(p.th_pub + q0) : "memory"); } while (0)
+    F32_PUB_FETCH();
 
     // Operand staging global -> registers -> LDS with TWO register sets: set (s & 1) carries stage s.
     // At step s the stage s+1 is committed to the other LDS buffer and the freed set is re-issued for
@@ -162,31 +192,48 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
     // distance was one step and the wait for it cost ~18 % of the launch under the fabric load of 512
     // workgroups re-streaming their query panels.)  KT is even (dpad is a multiple of 64), so tiles
     // start on even stages and the register sets have static names.
-    float4 ra_q0, ra_q1, ra_q2, ra_q3, ra_x0, ra_x1, ra_x2, ra_x3;
-    float4 rb_q0, rb_q1, rb_q2, rb_q3, rb_x0, rb_x1, rb_x2, rb_x3;
+    f32x4 ra_q0, ra_q1, ra_q2, ra_q3, ra_x0, ra_x1, ra_x2, ra_x3;
+    f32x4 rb_q0, rb_q1, rb_q2, rb_q3, rb_x0, rb_x1, rb_x2, rb_x3;
     const float *qbase = p.qp + q0 * dpad;
     const float *xbase = p.xp + (int64_t)t_begin * BX * dpad;
     int lk = 0, lj = 0, ls = 0;                  // load cursor: next stage to issue = ls = lj * KT + lk
+    // The operand loads are issued by hand: `global_load_dwordx4 v, v_offset32, s[base]` with the wave-uniform row-block
+    // base in SGPRs, and ONE counted wait in front of a stage's LDS writes.  Left to hipcc each load costs a 64-bit VALU
+    // address add and each LDS write its own s_waitcnt; a stand-alone replica of this loop (tools/micro/scan_loop.hip)
+    // runs at 0.934 of the fp32 MFMA peak this way and at 0.894 the other.  Always eight loads per stage (past the end
+    // of the segment the first stage is fetched again and never consumed), so that the count is static:
+    // vmcnt(8) = "everything but the eight newest vector-memory operations has completed" = the other register set's
+    // loads (or, right after an epilogue, its appends) may still be in flight, this set's cannot.
+    // (s_nop 4: a VMEM instruction that reads an SGPR written by the SALU less than 5 wait states earlier sees the OLD
+    // value -- hipcc pads its own loads and does not look inside inline asm; all eight bases are inputs of ONE statement)
 #define F32_ISSUE(S)                                                                                   \
     do {                                                                                               \
-        if (ls < total) {                                                                              \
-            const float *qs_ = qbase + lk * BK;                                                        \
-            const float *xs_ = xbase + (int64_t)lj * BX * dpad + lk * BK;                              \
-            r##S##_q0 = stage_ld(qs_, dpad, voff, 0); r##S##_q1 = stage_ld(qs_, dpad, voff, 1);        \
-            r##S##_q2 = stage_ld(qs_, dpad, voff, 2); r##S##_q3 = stage_ld(qs_, dpad, voff, 3);        \
-            r##S##_x0 = stage_ld(xs_, dpad, voff, 0); r##S##_x1 = stage_ld(xs_, dpad, voff, 1);        \
-            r##S##_x2 = stage_ld(xs_, dpad, voff, 2); r##S##_x3 = stage_ld(xs_, dpad, voff, 3);        \
-        }                                                                                              \
+        const bool live_ = ls < total;                                                                 \
+        const float *qs_ = live_ ? qbase + lk * BK : qbase;                                            \
+        const float *xs_ = live_ ? xbase + (int64_t)lj * BX * dpad + lk * BK : xbase;                  \
+        asm volatile("s_nop 4\n\t"                                                                     \
+                     "global_load_dwordx4 %0, %8, %12\n\tglobal_load_dwordx4 %1, %9, %12\n\t"          \
+                     "global_load_dwordx4 %2, %10, %12\n\tglobal_load_dwordx4 %3, %11, %12\n\t"        \
+                     "global_load_dwordx4 %4, %8, %13\n\tglobal_load_dwordx4 %5, %9, %13\n\t"          \
+                     "global_load_dwordx4 %6, %10, %13\n\tglobal_load_dwordx4 %7, %11, %13"            \
+                     : "=&v"(r##S##_q0), "=&v"(r##S##_q1), "=&v"(r##S##_q2), "=&v"(r##S##_q3),         \
+                       "=&v"(r##S##_x0), "=&v"(r##S##_x1), "=&v"(r##S##_x2), "=&v"(r##S##_x3)          \
+                     : "v"(voff), "v"(voff1), "v"(voff2), "v"(voff3), "s"(qs_), "s"(xs_) : "memory");  \
         ++ls; if (++lk == KT) { lk = 0; ++lj; }                                                        \
     } while (0)
+#define F32_LANDED(S, N)                                                                               \
+    asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(r##S##_q0), "+v"(r##S##_q1), "+v"(r##S##_q2), "+v"(r##S##_q3), \
+                                             "+v"(r##S##_x0), "+v"(r##S##_x1), "+v"(r##S##_x2), "+v"(r##S##_x3))
+#define F32_ST(t_, i_, V) stage_st(t_, tid, i_, make_float4(V[0], V[1], V[2], V[3]))
 #define F32_COMMIT(S, BUF)                                                                             \
     do {                                                                                               \
-        stage_st(s_tile[BUF][0], tid, 0, r##S##_q0); stage_st(s_tile[BUF][0], tid, 1, r##S##_q1);      \
-        stage_st(s_tile[BUF][0], tid, 2, r##S##_q2); stage_st(s_tile[BUF][0], tid, 3, r##S##_q3);      \
-        stage_st(s_tile[BUF][1], tid, 0, r##S##_x0); stage_st(s_tile[BUF][1], tid, 1, r##S##_x1);      \
-        stage_st(s_tile[BUF][1], tid, 2, r##S##_x2); stage_st(s_tile[BUF][1], tid, 3, r##S##_x3);      \
+        F32_LANDED(S, 8);                                                                              \
+        F32_ST(s_tile[BUF][0], 0, r##S##_q0); F32_ST(s_tile[BUF][0], 1, r##S##_q1);                    \
+        F32_ST(s_tile[BUF][0], 2, r##S##_q2); F32_ST(s_tile[BUF][0], 3, r##S##_q3);                    \
+        F32_ST(s_tile[BUF][1], 0, r##S##_x0); F32_ST(s_tile[BUF][1], 1, r##S##_x1);                    \
+        F32_ST(s_tile[BUF][1], 2, r##S##_x2); F32_ST(s_tile[BUF][1], 3, r##S##_x3);                    \
     } while (0)
-#define F32_MFMA_U(BUF, U)                                                                             \
+#define F32_MFMA_U(BUF, U, INIT)                                                                       \
     do {                                                                                               \
         const float *tq_ = s_tile[BUF][0];                                                             \
         const float *tx_ = s_tile[BUF][1];                                                             \
@@ -199,26 +246,36 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
         const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};              \
         const float av2[4] = {a2.x, a2.y, a2.z, a2.w}, av3[4] = {a3.x, a3.y, a3.z, a3.w};              \
         _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                \
+            if ((INIT) && m == 0) {      /* first k of a tile: C = 0 (inline constant), nothing to zero */ \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[m], bv[m], zero16, 0, 0, 0);           \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], bv[m], zero16, 0, 0, 0);           \
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av2[m], bv[m], zero16, 0, 0, 0);           \
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(av3[m], bv[m], zero16, 0, 0, 0);           \
+                continue;                                                                              \
+            }                                                                                          \
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[m], bv[m], acc0, 0, 0, 0);                 \
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], bv[m], acc1, 0, 0, 0);                 \
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av2[m], bv[m], acc2, 0, 0, 0);                 \
             acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(av3[m], bv[m], acc3, 0, 0, 0);                 \
         }                                                                                              \
     } while (0)
-    // one k-step on LDS buffer BUF (stage `it_`); SET = the register set that holds stage it_+1
-#define F32_STEP(BUF, SET, it_)                                                                        \
+    // one k-step on LDS buffer BUF (stage `it_`); SET = the register set that holds stage it_+1; FIRST (uniform): this
+    // stage opens a tile
+#define F32_STEP(BUF, SET, it_, FIRST)                                                                 \
     do {                                                                                               \
-        F32_MFMA_U(BUF, 0); F32_MFMA_U(BUF, 1);                                                        \
+        if (FIRST) F32_MFMA_U(BUF, 0, true); else F32_MFMA_U(BUF, 0, false);                           \
+        F32_MFMA_U(BUF, 1, false);                                                                     \
         if (!abl_ld) {                                                                                 \
-            if ((it_) + 1 < total) F32_COMMIT(SET, (BUF) ^ 1);                                         \
+            F32_COMMIT(SET, (BUF) ^ 1);                                                                \
             F32_ISSUE(SET);                                                                            \
         }                                                                                              \
-        F32_MFMA_U(BUF, 2); F32_MFMA_U(BUF, 3);                                                        \
+        F32_MFMA_U(BUF, 2, false); F32_MFMA_U(BUF, 3, false);                                          \
     } while (0)
 
-    f32x16 acc0, acc1, acc2, acc3;
+    f32x16 acc0, acc1, acc2, acc3, zero16;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { acc0[e] = 0.0f; acc1[e] = 0.0f; acc2[e] = 0.0f; acc3[e] = 0.0f; }
+    for (int e = 0; e < 16; ++e) zero16[e] = 0.0f;
+    acc0 = zero16; acc1 = zero16; acc2 = zero16; acc3 = zero16;
 
     const bool abl_ld = PROF && (p.ablate & 1), abl_bar = PROF && (p.ablate & 2);
     F32_ISSUE(a);                                // stage 0
@@ -229,12 +286,10 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
 
     int jl = 0;                                  // tile of the stage pair being computed
     for (int it = 0; it < total; it += 2) {
-        F32_STEP(0, b, it);                      // even stage: LDS buffer 0; set b holds stage it+1
+        F32_STEP(0, b, it, (it % KT) == 0);      // even stage: LDS buffer 0; set b holds stage it+1
         if (!abl_bar) __syncthreads();
-        F32_STEP(1, a, it + 1);                  // odd stage: LDS buffer 1; set a holds stage it+2
+        F32_STEP(1, a, it + 1, false);           // odd stage: LDS buffer 1; set a holds stage it+2
         const bool tile_done = ((it + 2) % KT) == 0;
-        if (p.th_pub && (it % KT) == 0)              // first k-step pair of a tile: fetch the panel's published bound
-            pub = __atomic_load_n(&p.th_pub[q0 + qrow_l], __ATOMIC_RELAXED);
 
         if (tile_done) {
             // ---- epilogue: filter into the lane-private half-lists, then zero the accumulators ----
@@ -244,7 +299,20 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
             __builtin_amdgcn_s_setprio(3);
             const unsigned jb = (unsigned)(t_begin + jl) * BX + 4 * h;
             const int ccnt_in = ccnt;
-            if (p.th_pub && pub > 1u) th = fmaxf(th, lemon_ord2f(pub - 1u));   // strictly below the published bound
+            if (p.th_pub) {
+                asm volatile("s_waitcnt vmcnt(16)" : "+v"(pub));
+                if (pub > 1u) th = fmaxf(th, lemon_ord2f(pub - 1u));   // strictly below the published bound
+            }
+            if ((unsigned)(t_begin + jl + 1) * BX > (unsigned)p.n) {   // last tile of the database (uniform): padding rows never pass
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const unsigned j = jb + (e & 3) + 8 * (e >> 2);
+                    if (j >= (unsigned)p.n) acc0[e] = -INFINITY;
+                    if (j + 32 >= (unsigned)p.n) acc1[e] = -INFINITY;
+                    if (j + 64 >= (unsigned)p.n) acc2[e] = -INFINITY;
+                    if (j + 96 >= (unsigned)p.n) acc3[e] = -INFINITY;
+                }
+            }
             if (PROF && (p.ablate & 16)) {           // diagnostic: bit 4 = time the bare accumulator read-out (64-value max)
                 float mx = acc0[0];
 #pragma unroll
@@ -278,9 +346,7 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
             f32_filter_tile<L2, UB>(acc3, th, jb + 96, my_qn, p.xnorm, (unsigned)p.n, ccnt, panel_bytes, my_off, my_ub);
             }
             if (PROF && (p.ablate & 8) && jl > 4) ccnt = ccnt_in;   // diagnostic: bit 3 = appends land but are forgotten
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { acc0[e] = 0.0f; acc1[e] = 0.0f; acc2[e] = 0.0f; acc3[e] = 0.0f; }
-            ++jl;
+            ++jl;                                    // (the accumulators are not zeroed: the next tile's first MFMAs take C = 0)
 
             // ---- maintenance: select the exact top-kk of queries whose lists grew enough ----
             PH_STAMP(ph1);
@@ -308,7 +374,11 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
                     }
                 } while (todo);
             }
-            __builtin_amdgcn_s_setprio(0);
+            // the bound the other pieces of this panel have published by now, for the NEXT tile's epilogue: fetched here, a
+            // whole tile ahead of its use and in front of >= 16 operand loads (fetched at the top of the tile it was the
+            // NEWEST load at its use, and the wait for it, vmcnt(0), drained the operand prefetch once per tile)
+            F32_PUB_FETCH();
+            F32_BASE_PRIO();
             PH_STAMP(ph2);
         }
 
@@ -317,11 +387,15 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
 #undef F32_STEP
 #undef F32_MFMA_U
 #undef F32_COMMIT
+#undef F32_ST
 #undef F32_ISSUE
 
     // ---- final: sort every query's best kk, write the result rows ------------------------------
     PH_STAMP(ph0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    F32_LANDED(a, 0); F32_LANDED(b, 0);                 // the loads issued past the end of the segment, and the appends
+    asm volatile("" : "+v"(pub));
+#undef F32_LANDED
+#undef F32_PUB_FETCH
     for (int r = 0; r < 32; ++r) {
         const int row = 32 * wave + r;
         const int64_t q = q0 + row;
@@ -338,8 +412,21 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
     if (PROF && tid == 0) {
         atomicAdd(&p.phase_dbg[0], ph0); atomicAdd(&p.phase_dbg[1], ph1);
         atomicAdd(&p.phase_dbg[2], ph2); atomicAdd(&p.phase_dbg[3], ph3);
+        const unsigned long long rt = __builtin_amdgcn_s_memrealtime() - rt0;   // this workgroup's life, 100 MHz ticks
+        if (blockIdx.x == 0) {
+            p.phase_dbg[4] = __builtin_amdgcn_s_memtime() - clk0;
+            p.phase_dbg[5] = rt;
+        }
+        // spread of the workgroups' lives, overall and by the parity of the wave slot wave 0 sits in (HW_ID[3:0]): the two
+        // workgroups of a CU share the matrix pipe, and an arbiter that prefers one of them shows up here
+        const unsigned slot = slot_parity;
+        atomicMax(&p.phase_dbg[6], rt);
+        atomicMin(&p.phase_dbg[7], rt);
+        atomicAdd(&p.phase_dbg[8 + 2 * slot], rt);
+        atomicAdd(&p.phase_dbg[9 + 2 * slot], 1ull);
     }
 #undef PH_STAMP
+#undef F32_BASE_PRIO
 }
 
 // merge the per-split sorted lists of one query (one wavefront per query)
@@ -629,21 +716,37 @@ static int lemon_search_f32_pass(lemon_index_t *idx, const float *q_dev, int64_t
         p.ablate = getenv("LEMON_ABLATE") ? atoi(getenv("LEMON_ABLATE")) : 0;   // diagnostic instantiation only
         static const int stale = [] { const char *e = getenv("LEMON_STALE"); return e && atoi(e) > 0 ? atoi(e) : 96; }();
         p.stale = stale;
+        // fair-share turns (see k_scan_f32): about eight turns per launch, between 82 us and 5.2 ms each -- longer turns
+        // measured better (16.9 / 16.7 / 16.4 / 16.3 ms at the headline shape for no turns / 5 us / 82 us / 2.6 ms), a
+        // turn longer than the launch is no turn at all.  LEMON_FAIR = log2(turn in 10 ns ticks) overrides, 0 = off.
+        static const int fair_env = [] { const char *e = getenv("LEMON_FAIR"); return e ? atoi(e) : -1; }();
+        if (fair_env >= 0) p.fair = fair_env;
+        else {
+            const double ticks = 2.0 * (double)cn * (double)idx->n * (double)d / 1.25e14 * 1e8 / 8.0;   // launch / 8, in ticks
+            int bit = 13;
+            while (bit < 19 && (double)(2u << bit) <= ticks) ++bit;
+            p.fair = bit;
+        }
         {
             const double flops = 2.0 * (double)cn * (double)idx->n * (double)d;
             const double bytes = 4.0 * d * ((double)cn + (double)panels * (double)idx->n) + 12.0 * k * (double)cn;
             LemonProfScope prof(idx, stream, flops, bytes);
             if (!ub_dev && idx->metric == LEMON_METRIC_IP && getenv("LEMON_PHASE_PROF")) {   // diagnostic build: phase cycle sums
                 static unsigned long long *dbg = nullptr;
-                if (!dbg) { (void)hipMalloc(&dbg, 64); (void)hipMemset(dbg, 0, 64); }
+                if (!dbg) { (void)hipMalloc(&dbg, 128); (void)hipMemset(dbg, 0, 128); }
+                (void)hipMemset(dbg + 7, 0xff, 8);
                 p.phase_dbg = dbg;
                 hipLaunchKernelGGL((k_scan_f32<false, true>), dim3(grid), dim3(NT), 0, stream, p);
                 (void)hipStreamSynchronize(stream);
-                unsigned long long h[8]; (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
+                unsigned long long h[16]; (void)hipMemcpy(h, dbg, 128, hipMemcpyDeviceToHost);
                 const double tot = (double)(h[0] + h[1] + h[2] + h[3]);
                 fprintf(stderr, "[phase f32] grid=%u loop=%.1f%% filter=%.1f%% maintain=%.1f%% final=%.1f%% cyc/WG=%.3g\n",
                         grid, 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, tot / grid);
-                (void)hipMemset(dbg, 0, 64);
+                fprintf(stderr, "[clock f32] workgroup 0: %llu shader cycles in %llu ticks of the 100 MHz counter = %.0f MHz\n",
+                        h[4], h[5], h[5] ? 100.0 * (double)h[4] / (double)h[5] : 0.0);
+                fprintf(stderr, "[lives f32] workgroup life min %.2f ms  max %.2f ms;  wave-slot parity 0: %llu workgroups, mean %.2f ms;  parity 1: %llu, mean %.2f ms\n",
+                        h[7] / 1e5, h[6] / 1e5, h[9], h[9] ? h[8] / 1e5 / h[9] : 0.0, h[11], h[11] ? h[10] / 1e5 / h[11] : 0.0);
+                (void)hipMemset(dbg, 0, 128);
             } else if (ub_dev) {
                 if (idx->metric == LEMON_METRIC_L2) hipLaunchKernelGGL((k_scan_f32<true, false, true>), dim3(grid), dim3(NT), 0, stream, p);
                 else hipLaunchKernelGGL((k_scan_f32<false, false, true>), dim3(grid), dim3(NT), 0, stream, p);

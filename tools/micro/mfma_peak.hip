@@ -1,0 +1,76 @@
+// mfma_peak.hip -- what the matrix pipe of one MI355X sustains with NO memory traffic at all: every wave issues
+// back-to-back MFMAs on registers (4 or 8 independent accumulator tiles), 1..3 waves per SIMD.  The number DESIGN.md
+// quotes next to the data-sheet peak when it prices k_scan_f32 / k_scan_bf16_qs.
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_peak.hip -o .variants/mfma_peak && .variants/mfma_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int ACC>
+__global__ __launch_bounds__(256) void k_f32(float *out, int iters, float a, float b) {
+    f32x16 acc[ACC];
+    for (int i = 0; i < ACC; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+    float av = a + threadIdx.x, bv = b;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 16 / ACC * 4; ++r)
+#pragma unroll
+            for (int i = 0; i < ACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
+    }
+    float s = 0.0f;
+    for (int i = 0; i < ACC; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
+    if (s == 123.456f) out[0] = s;
+}
+
+template <int ACC>
+__global__ __launch_bounds__(256) void k_bf16(float *out, int iters, float a) {
+    f32x16 acc[ACC];
+    for (int i = 0; i < ACC; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+    bf16x8 av, bv;
+    for (int e = 0; e < 8; ++e) { av[e] = (__bf16)(a + e); bv[e] = (__bf16)(a - e); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 16 / ACC * 4; ++r)
+#pragma unroll
+            for (int i = 0; i < ACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i], 0, 0, 0);
+    }
+    float s = 0.0f;
+    for (int i = 0; i < ACC; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
+    if (s == 123.456f) out[0] = s;
+}
+
+template <typename F>
+static double time_ms(F launch) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    launch(); CHECK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+        CHECK(hipEventRecord(e0)); launch(); CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+    }
+    return best;
+}
+
+int main() {
+    int cus = 256;
+    CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+    float *out; CHECK(hipMalloc(&out, 64));
+    const int iters = 4000;                       // x 64 MFMAs per wave
+    for (int wg_per_cu = 1; wg_per_cu <= 3; ++wg_per_cu) {
+        const int grid = cus * wg_per_cu;
+        const double mf = (double)grid * 4 * iters * 64;     // MFMAs in the launch
+        double ms = time_ms([&] { hipLaunchKernelGGL(k_f32<4>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0f, 2.0f); });
+        printf("f32 32x32x2   4 acc tiles  %d wave(s)/SIMD  %8.3f ms  %7.1f TFLOP/s\n", wg_per_cu, ms, mf * 4096 / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL(k_f32<8>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0f, 2.0f); });
+        printf("f32 32x32x2   8 acc tiles  %d wave(s)/SIMD  %8.3f ms  %7.1f TFLOP/s\n", wg_per_cu, ms, mf * 4096 / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL(k_bf16<4>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0f); });
+        printf("bf16 32x32x16 4 acc tiles  %d wave(s)/SIMD  %8.3f ms  %7.1f TFLOP/s\n", wg_per_cu, ms, mf * 32768 / ms / 1e9);
+    }
+    return 0;
+}

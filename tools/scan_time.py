@@ -14,4 +14,7 @@ ts = []
 for _ in range(3):
     t0 = time.perf_counter(); idx.search(q, k); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 t = min(ts)
-print(f"nq={nq} n={n} d={d} k={k} algo={algo} best={t*1e3:.2f} ms  {2.0*nq*n*d/t/1e12:.1f} TFLOP/s", flush=True)
+D, I = idx.search(q, k); torch.cuda.synchronize()
+w = torch.arange(1, k + 1, device=dev, dtype=torch.int64)       # position-weighted: an order change shows too
+chk = f"I:{int(((I + 1) * w).sum()) & 0xffffffffffff:012x} D:{int((D.view(torch.int32).to(torch.int64) * w).sum()) & 0xffffffffffff:012x}"
+print(f"nq={nq} n={n} d={d} k={k} algo={algo} best={t*1e3:.2f} ms  {2.0*nq*n*d/t/1e12:.1f} TFLOP/s  checksum {chk}", flush=True)
