@@ -224,53 +224,64 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
 #define F32_LANDED(S, N)                                                                               \
     asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(r##S##_q0), "+v"(r##S##_q1), "+v"(r##S##_q2), "+v"(r##S##_q3), \
                                              "+v"(r##S##_x0), "+v"(r##S##_x1), "+v"(r##S##_x2), "+v"(r##S##_x3))
-#define F32_ST(t_, i_, V) stage_st(t_, tid, i_, make_float4(V[0], V[1], V[2], V[3]))
+#define F32_ST1(V, OFF) asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(wa), "v"(V), "n"(OFF) : "memory")
 #define F32_COMMIT(S, BUF)                                                                             \
     do {                                                                                               \
         F32_LANDED(S, 8);                                                                              \
-        F32_ST(s_tile[BUF][0], 0, r##S##_q0); F32_ST(s_tile[BUF][0], 1, r##S##_q1);                    \
-        F32_ST(s_tile[BUF][0], 2, r##S##_q2); F32_ST(s_tile[BUF][0], 3, r##S##_q3);                    \
-        F32_ST(s_tile[BUF][1], 0, r##S##_x0); F32_ST(s_tile[BUF][1], 1, r##S##_x1);                    \
-        F32_ST(s_tile[BUF][1], 2, r##S##_x2); F32_ST(s_tile[BUF][1], 3, r##S##_x3);                    \
+        F32_ST1(r##S##_q0, (BUF) * 32768); F32_ST1(r##S##_q1, (BUF) * 32768 + 4096);                   \
+        F32_ST1(r##S##_q2, (BUF) * 32768 + 8192); F32_ST1(r##S##_q3, (BUF) * 32768 + 12288);           \
+        F32_ST1(r##S##_x0, (BUF) * 32768 + 16384); F32_ST1(r##S##_x1, (BUF) * 32768 + 20480);          \
+        F32_ST1(r##S##_x2, (BUF) * 32768 + 24576); F32_ST1(r##S##_x3, (BUF) * 32768 + 28672);          \
     } while (0)
-#define F32_MFMA_U(BUF, U, INIT)                                                                       \
+#define F32_FRAG(F, BUF, U)                                                                            \
+    asm volatile("ds_read_b128 %0, %5 offset:%7\n\tds_read_b128 %1, %6 offset:%8\n\tds_read_b128 %2, %6 offset:%9\n\t" \
+                 "ds_read_b128 %3, %6 offset:%10\n\tds_read_b128 %4, %6 offset:%11"                     \
+                 : "=&v"(F##_b), "=&v"(F##_0), "=&v"(F##_1), "=&v"(F##_2), "=&v"(F##_3)                \
+                 : "v"(aq[U]), "v"(ax[U]), "n"((BUF) * 32768), "n"((BUF) * 32768 + 16384),             \
+                   "n"((BUF) * 32768 + 20480), "n"((BUF) * 32768 + 24576), "n"((BUF) * 32768 + 28672) : "memory")
+#define F32_WAIT(F, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F##_b), "+v"(F##_0), "+v"(F##_1), "+v"(F##_2), "+v"(F##_3))
+#define F32_MFMA_F(F, INIT)                                                                            \
     do {                                                                                               \
-        const float *tq_ = s_tile[BUF][0];                                                             \
-        const float *tx_ = s_tile[BUF][1];                                                             \
-        const float4 b4 = *reinterpret_cast<const float4 *>(&tq_[swz(qrow_l, 2 * (U) + h)]);           \
-        const float4 a0 = *reinterpret_cast<const float4 *>(&tx_[swz(l31, 2 * (U) + h)]);              \
-        const float4 a1 = *reinterpret_cast<const float4 *>(&tx_[swz(32 + l31, 2 * (U) + h)]);         \
-        const float4 a2 = *reinterpret_cast<const float4 *>(&tx_[swz(64 + l31, 2 * (U) + h)]);         \
-        const float4 a3 = *reinterpret_cast<const float4 *>(&tx_[swz(96 + l31, 2 * (U) + h)]);         \
-        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};                                                  \
-        const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};              \
-        const float av2[4] = {a2.x, a2.y, a2.z, a2.w}, av3[4] = {a3.x, a3.y, a3.z, a3.w};              \
         _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                \
-            if ((INIT) && m == 0) {      /* first k of a tile: C = 0 (inline constant), nothing to zero */ \
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[m], bv[m], zero16, 0, 0, 0);           \
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], bv[m], zero16, 0, 0, 0);           \
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av2[m], bv[m], zero16, 0, 0, 0);           \
-                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(av3[m], bv[m], zero16, 0, 0, 0);           \
+            if ((INIT) && m == 0) {                                                                    \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(F##_0[m], F##_b[m], zero16, 0, 0, 0);      \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(F##_1[m], F##_b[m], zero16, 0, 0, 0);      \
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(F##_2[m], F##_b[m], zero16, 0, 0, 0);      \
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(F##_3[m], F##_b[m], zero16, 0, 0, 0);      \
                 continue;                                                                              \
             }                                                                                          \
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[m], bv[m], acc0, 0, 0, 0);                 \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[m], bv[m], acc1, 0, 0, 0);                 \
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av2[m], bv[m], acc2, 0, 0, 0);                 \
-            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(av3[m], bv[m], acc3, 0, 0, 0);                 \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(F##_0[m], F##_b[m], acc0, 0, 0, 0);            \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(F##_1[m], F##_b[m], acc1, 0, 0, 0);            \
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(F##_2[m], F##_b[m], acc2, 0, 0, 0);            \
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(F##_3[m], F##_b[m], acc3, 0, 0, 0);            \
         }                                                                                              \
     } while (0)
-    // one k-step on LDS buffer BUF (stage `it_`); SET = the register set that holds stage it_+1; FIRST (uniform): this
-    // stage opens a tile
 #define F32_STEP(BUF, SET, it_, FIRST)                                                                 \
     do {                                                                                               \
-        if (FIRST) F32_MFMA_U(BUF, 0, true); else F32_MFMA_U(BUF, 0, false);                           \
-        F32_MFMA_U(BUF, 1, false);                                                                     \
+        F32_FRAG(fb, BUF, 1); F32_WAIT(fa, 5);                                                         \
+        if (FIRST) F32_MFMA_F(fa, true); else F32_MFMA_F(fa, false);                                   \
+        F32_FRAG(fa, BUF, 2); F32_WAIT(fb, 5); F32_MFMA_F(fb, false);                                  \
         if (!abl_ld) {                                                                                 \
             F32_COMMIT(SET, (BUF) ^ 1);                                                                \
             F32_ISSUE(SET);                                                                            \
+            F32_FRAG(fb, BUF, 3); F32_WAIT(fa, 13);                                                    \
+        } else {                                                                                       \
+            F32_FRAG(fb, BUF, 3); F32_WAIT(fa, 5);                                                     \
         }                                                                                              \
-        F32_MFMA_U(BUF, 2, false); F32_MFMA_U(BUF, 3, false);                                          \
+        F32_MFMA_F(fa, false);                                                                         \
+        if (!abl_bar) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3) : : "memory"); \
+        F32_FRAG(fa, (BUF) ^ 1, 0); F32_WAIT(fb, 5); F32_MFMA_F(fb, false);                            \
     } while (0)
+
+    f32x4 fa_b, fa_0, fa_1, fa_2, fa_3, fb_b, fb_0, fb_1, fb_2, fb_3;   // two fragment sets
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float *)&s_tile[0][0][0];
+    const unsigned wa = lds0 + 4u * (unsigned)swz(tid >> 3, tid & 7);
+    unsigned aq[4], ax[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        aq[u] = lds0 + 4u * (unsigned)swz(qrow_l, 2 * u + h);
+        ax[u] = lds0 + 4u * (unsigned)swz(l31, 2 * u + h);
+    }
 
     f32x16 acc0, acc1, acc2, acc3, zero16;
 #pragma unroll
@@ -282,12 +293,12 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
     F32_ISSUE(b);                                // stage 1
     F32_COMMIT(a, 0);
     F32_ISSUE(a);                                // stage 2
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    F32_FRAG(fa, 0, 0);
 
     int jl = 0;                                  // tile of the stage pair being computed
     for (int it = 0; it < total; it += 2) {
         F32_STEP(0, b, it, (it % KT) == 0);      // even stage: LDS buffer 0; set b holds stage it+1
-        if (!abl_bar) __syncthreads();
         F32_STEP(1, a, it + 1, false);           // odd stage: LDS buffer 1; set a holds stage it+2
         const bool tile_done = ((it + 2) % KT) == 0;
 
@@ -381,13 +392,14 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
             F32_BASE_PRIO();
             PH_STAMP(ph2);
         }
-
-        if (!abl_bar) __syncthreads();
     }
+    F32_WAIT(fa, 0);
 #undef F32_STEP
-#undef F32_MFMA_U
+#undef F32_MFMA_F
+#undef F32_WAIT
+#undef F32_FRAG
+#undef F32_ST1
 #undef F32_COMMIT
-#undef F32_ST
 #undef F32_ISSUE
 
     // ---- final: sort every query's best kk, write the result rows ------------------------------
