@@ -221,7 +221,8 @@ __device__ __forceinline__ u64 pair_select_loose(u64 *__restrict__ list, int n0,
 // final: the best kk keys of a pair list, sorted: lane's return value is one surviving key (0 = none)
 // and *pos its position in best-first order (keys are distinct, so ranks are a permutation); lanes
 // without a key get *pos = lane.  sk: >= 64-u64 per-wave LDS scratch.
-template <int NS>
+// SORT = false (a partial list that k_merge rank-selects anyway): the best kk in arbitrary order, *pos = lane.
+template <int NS, bool SORT>
 __device__ __forceinline__ u64 pair_final_ns(const u64 *__restrict__ list, int n0, int n1, int s0, int kk,
                                              int lane, u64 *__restrict__ sk, int *pos) {
     PairSlots<NS> ps;
@@ -232,6 +233,7 @@ __device__ __forceinline__ u64 pair_final_ns(const u64 *__restrict__ list, int n
     __builtin_amdgcn_wave_barrier();
     const u64 mine = lane < cnt ? sk[lane] : 0;
     __builtin_amdgcn_wave_barrier();
+    if (!SORT) { *pos = lane; return mine; }
     int r = 0;
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
@@ -241,12 +243,13 @@ __device__ __forceinline__ u64 pair_final_ns(const u64 *__restrict__ list, int n
     *pos = mine ? r : lane;
     return mine;
 }
+template <bool SORT>
 __device__ __forceinline__ u64 pair_final_topk(const u64 *__restrict__ list, int n0, int n1, int kk, int lane,
                                                u64 *__restrict__ sk, int *pos) {
     const int s0 = (n0 + 63) >> 6, ns = s0 + ((n1 + 63) >> 6);
-    if (ns <= 2) return pair_final_ns<2>(list, n0, n1, s0, kk, lane, sk, pos);
-    if (ns <= 4) return pair_final_ns<4>(list, n0, n1, s0, kk, lane, sk, pos);
-    return pair_final_ns<8>(list, n0, n1, s0, kk, lane, sk, pos);
+    if (ns <= 2) return pair_final_ns<2, SORT>(list, n0, n1, s0, kk, lane, sk, pos);
+    if (ns <= 4) return pair_final_ns<4, SORT>(list, n0, n1, s0, kk, lane, sk, pos);
+    return pair_final_ns<8, SORT>(list, n0, n1, s0, kk, lane, sk, pos);
 }
 
 // final write-out of a sorted per-row key list (lane < kk holds / reads entry `lane`)

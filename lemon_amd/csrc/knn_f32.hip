@@ -362,7 +362,7 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
             // ---- maintenance: select the exact top-kk of queries whose lists grew enough ----
             PH_STAMP(ph1);
             const int pair = ccnt + __shfl_xor(ccnt, 32);
-            const bool warm = th_own == -INFINITY && pair >= p.kk;
+            const bool warm = th == -INFINITY && pair >= p.kk;   // no bound at all yet, own or imported
             const bool stale = pair >= p.kk && pair - clast >= p.stale;
             const bool full = ccnt > PAIR_CAP / 2 - BX / 2;
             u64 todo = __ballot(qvalid && (warm || stale || full));
@@ -415,7 +415,9 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
         u64 *list = cand_panel + (int64_t)row * PAIR_CAP;
         const int n0 = __builtin_amdgcn_readlane(ccnt, r), n1 = __builtin_amdgcn_readlane(ccnt, r + 32);
         int pos;
-        const u64 key = pair_final_topk(list, n0, n1, p.kk, lane, s_keys[wave], &pos);
+        // (a piece of a panel only has to deliver its best kk: k_merge rank-selects the pieces' union, sorted or not)
+        const u64 key = p.splits > 1 ? pair_final_topk<false>(list, n0, n1, p.kk, lane, s_keys[wave], &pos)
+                                     : pair_final_topk<true>(list, n0, n1, p.kk, lane, s_keys[wave], &pos);
         write_out_row(p, split, q, pos, key);
     }
     PH_STAMP(ph3);

@@ -1,0 +1,198 @@
+// qs_loop.hip -- the main loop of k_scan_bf16_qs (d = 768: 48 stationary query fragments + 4 accumulator tiles in the
+// AccVGPR half, one workgroup of 4 waves per CU, 32 MFMAs per wave and stage) rebuilt ingredient by ingredient:
+//   bit 0  fragment reads from LDS (4 x ds_read_b128 per 4 MFMAs), issued one k-step ahead, counted lgkmcnt(4)
+//   bit 1  workgroup barrier per stage
+//   bit 2  the database tile by LDS-DMA (8 x global_load_lds_dwordx4 per wave and stage, three stages in flight)
+//   bit 3  the database tile through registers instead (8 x global_load_dwordx4 + 8 x ds_write_b128, hand-issued)
+//   bit 4  reads issued TWO k-steps ahead (three fragment sets)
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/qs_loop.hip -o .variants/qs_loop && .variants/qs_loop
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+constexpr int DW = 384;                    // row pitch in 4-byte words (768 bf16)
+constexpr int KT2 = 6;                     // stages per tile (2 x 64-wide k-slices each)
+constexpr int STG = 2 * 128 * 32;          // floats per stage (32 KB)
+
+__device__ __forceinline__ int swz(int r, int c) { return r * 32 + 4 * (c ^ ((r >> 1) & 7)); }
+__device__ __forceinline__ void mfma_qs(f32x16 &acc, bf16x8 a, const bf16x8 &bq) {
+    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(bq));
+}
+
+// random bf16 pairs of magnitude 0.03 .. 0.06, either sign (all-zero operands would understate the power the real data draws)
+__global__ void k_fill(unsigned *g, size_t n, int random) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned r = (unsigned)i * 2654435761u; r ^= r >> 15; r *= 2246822519u; r ^= r >> 13;
+        g[i] = random ? (((r & 0x807fu) | 0x3d00u) | ((((r >> 16) & 0x807fu) | 0x3d00u) << 16)) : 0u;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void k_loop(const float *__restrict__ g, float *out, int tiles, unsigned spread, int lockstep) {
+    __shared__ __attribute__((aligned(16))) float s_x[4 * STG];         // 128 KB ring, as the kernel
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h = lane >> 5;
+    constexpr bool RD = MODE & 1, BAR = (MODE & 2) != 0, DMA = (MODE & 4) != 0, REG = (MODE & 8) != 0, DEEP = (MODE & 16) != 0;
+    for (int i = tid; i < 4 * STG; i += 256) s_x[i] = 0.0f;
+    __syncthreads();
+    bf16x8 qf[48];
+#pragma unroll
+    for (int s = 0; s < 48; ++s) for (int e = 0; e < 8; ++e) qf[s][e] = (__bf16)(0.01f * (float)(((s * 8 + e) * 37 + lane * 11) % 23 - 11));
+    f32x16 acc0, acc1, acc2, acc3;
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0; acc1[e] = 0; acc2[e] = 0; acc3[e] = 0; }
+    unsigned frag_addr[4];
+    for (int u = 0; u < 4; ++u)
+        frag_addr[u] = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float *)(s_x + swz(l31, 2 * u + h));
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float *)s_x;
+    const unsigned wa = lds0 + 4u * (unsigned)swz(tid >> 3, tid & 7);
+    const unsigned voff = (unsigned)(((tid >> 3) * DW + 4 * (tid & 7)) * 4);
+    const unsigned voff1 = voff + 32u * DW * 4, voff2 = voff1 + 32u * DW * 4, voff3 = voff2 + 32u * DW * 4;
+    const int t0 = lockstep ? 0 : (int)((blockIdx.x * 61u) % spread);
+    const bf16x8 z8 = {};
+    bf16x8 fa0 = z8, fa1 = z8, fa2 = z8, fa3 = z8, fb0 = z8, fb1 = z8, fb2 = z8, fb3 = z8, fc0 = z8, fc1 = z8, fc2 = z8, fc3 = z8;
+    const f32x4 z4 = {0, 0, 0, 0};
+    f32x4 ra0 = z4, ra1 = z4, ra2 = z4, ra3 = z4, ra4 = z4, ra5 = z4, ra6 = z4, ra7 = z4;
+    f32x4 rb0 = z4, rb1 = z4, rb2 = z4, rb3 = z4, rb4 = z4, rb5 = z4, rb6 = z4, rb7 = z4;
+    // stage s: tile (t0 + s / KT2) % spread, k-slices 2 (s % KT2), 2 (s % KT2) + 1
+#define SRC(s_, sb_) (g + (size_t)((t0 + (s_) / KT2) % spread) * 128 * DW + (2 * ((s_) % KT2) + (sb_)) * 32)
+#define DMA1(src_, i_, dst_)                                                                           \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((src_) + (size_t)(32 * wave + 8 * (i_) + (lane >> 3)) * DW + \
+                                         4 * ((lane & 7) ^ (((8 * (i_) + (lane >> 3)) >> 1) & 7))),        \
+                                     (__attribute__((address_space(3))) void *)((dst_) + (32 * wave + 8 * (i_)) * 32), 16, 0, 0)
+#define DMA_STAGE(s_)                                                                                  \
+    do {                                                                                               \
+        float *d0_ = s_x + ((s_) & 3) * STG;                                                           \
+        DMA1(SRC(s_, 0), 0, d0_); DMA1(SRC(s_, 0), 1, d0_); DMA1(SRC(s_, 0), 2, d0_); DMA1(SRC(s_, 0), 3, d0_); \
+        DMA1(SRC(s_, 1), 0, d0_ + 4096); DMA1(SRC(s_, 1), 1, d0_ + 4096); DMA1(SRC(s_, 1), 2, d0_ + 4096); DMA1(SRC(s_, 1), 3, d0_ + 4096); \
+    } while (0)
+#define REG_ISSUE(S, s_)                                                                               \
+    asm volatile("s_nop 4\n\t"                                                                         \
+                 "global_load_dwordx4 %0, %8, %12\n\tglobal_load_dwordx4 %1, %9, %12\n\t"              \
+                 "global_load_dwordx4 %2, %10, %12\n\tglobal_load_dwordx4 %3, %11, %12\n\t"            \
+                 "global_load_dwordx4 %4, %8, %13\n\tglobal_load_dwordx4 %5, %9, %13\n\t"              \
+                 "global_load_dwordx4 %6, %10, %13\n\tglobal_load_dwordx4 %7, %11, %13"                \
+                 : "=&v"(r##S##0), "=&v"(r##S##1), "=&v"(r##S##2), "=&v"(r##S##3), "=&v"(r##S##4), "=&v"(r##S##5), "=&v"(r##S##6), "=&v"(r##S##7) \
+                 : "v"(voff), "v"(voff1), "v"(voff2), "v"(voff3), "s"(SRC(s_, 0)), "s"(SRC(s_, 1)) : "memory")
+#define ST1(V, OFF) asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(wsl), "v"(V), "n"(OFF) : "memory")
+#define REG_COMMIT(S, s_)                                                                              \
+    do {                                                                                               \
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(r##S##0), "+v"(r##S##1), "+v"(r##S##2), "+v"(r##S##3), "+v"(r##S##4), "+v"(r##S##5), "+v"(r##S##6), "+v"(r##S##7)); \
+        const unsigned wsl = wa + (unsigned)(((s_) & 3) * STG * 4);                                    \
+        ST1(r##S##0, 0); ST1(r##S##1, 4096); ST1(r##S##2, 8192); ST1(r##S##3, 12288);                  \
+        ST1(r##S##4, 16384); ST1(r##S##5, 20480); ST1(r##S##6, 24576); ST1(r##S##7, 28672);            \
+    } while (0)
+#define QS_LOAD(S, VA, OFF)                                                                            \
+    do { if (RD) asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"     \
+                 "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"                      \
+                 : "=&v"(f##S##0), "=&v"(f##S##1), "=&v"(f##S##2), "=&v"(f##S##3)                      \
+                 : "v"(VA), "n"(OFF), "n"((OFF) + 4096), "n"((OFF) + 8192), "n"((OFF) + 12288) : "memory"); } while (0)
+#define QS_WAIT(S, N) do { if (RD) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f##S##0), "+v"(f##S##1), "+v"(f##S##2), "+v"(f##S##3)); } while (0)
+#define QS_STEP(S, KSV) do { mfma_qs(acc0, f##S##0, qf[KSV]); mfma_qs(acc1, f##S##1, qf[KSV]); mfma_qs(acc2, f##S##2, qf[KSV]); mfma_qs(acc3, f##S##3, qf[KSV]); } while (0)
+    const int total = tiles * KT2;
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+    if (DMA) { DMA_STAGE(0); DMA_STAGE(1); DMA_STAGE(2); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    if (REG) { REG_ISSUE(a, 0); REG_ISSUE(b, 1); }
+    __syncthreads();
+    for (int jl = 0; jl < tiles; ++jl) {
+#pragma clang loop unroll(full)
+        for (int kt = 0; kt < KT2; ++kt) {
+            const int t = jl * KT2 + kt;
+            if (DMA) DMA_STAGE(t + 3);
+            const unsigned sbase = (unsigned)((t & 3) * STG * 4);
+            const unsigned va0 = frag_addr[0] + sbase, va1 = frag_addr[1] + sbase, va2 = frag_addr[2] + sbase, va3 = frag_addr[3] + sbase;
+            const int ks0 = 8 * kt;
+            if (!DEEP) {
+                QS_LOAD(a, va0, 0);
+                QS_LOAD(b, va1, 0);     QS_WAIT(a, 4); QS_STEP(a, ks0 + 0);
+                QS_LOAD(a, va2, 0);     QS_WAIT(b, 4); QS_STEP(b, ks0 + 1);
+                QS_LOAD(b, va3, 0);     QS_WAIT(a, 4); QS_STEP(a, ks0 + 2);
+                QS_LOAD(a, va0, 16384); QS_WAIT(b, 4); QS_STEP(b, ks0 + 3);
+                if (REG) { if (kt & 1) { REG_COMMIT(b, t + 1); REG_ISSUE(b, t + 3); } else { REG_COMMIT(a, t + 1); REG_ISSUE(a, t + 3); } }
+                if (REG) { QS_LOAD(b, va1, 16384); QS_WAIT(a, 12); } else { QS_LOAD(b, va1, 16384); QS_WAIT(a, 4); }
+                QS_STEP(a, ks0 + 4);
+                QS_LOAD(a, va2, 16384); QS_WAIT(b, 4); QS_STEP(b, ks0 + 5);
+                QS_LOAD(b, va3, 16384); QS_WAIT(a, 4); QS_STEP(a, ks0 + 6);
+                                        QS_WAIT(b, 0); QS_STEP(b, ks0 + 7);
+            } else {
+                QS_LOAD(a, va0, 0); QS_LOAD(b, va1, 0);
+                QS_LOAD(c, va2, 0);     QS_WAIT(a, 8); QS_STEP(a, ks0 + 0);
+                QS_LOAD(a, va3, 0);     QS_WAIT(b, 8); QS_STEP(b, ks0 + 1);
+                QS_LOAD(b, va0, 16384); QS_WAIT(c, 8); QS_STEP(c, ks0 + 2);
+                QS_LOAD(c, va1, 16384); QS_WAIT(a, 8); QS_STEP(a, ks0 + 3);
+                if (REG) { if (kt & 1) { REG_COMMIT(b, t + 1); REG_ISSUE(b, t + 3); } else { REG_COMMIT(a, t + 1); REG_ISSUE(a, t + 3); } }
+                if (REG) { QS_LOAD(a, va2, 16384); QS_WAIT(b, 15); } else { QS_LOAD(a, va2, 16384); QS_WAIT(b, 8); }
+                QS_STEP(b, ks0 + 4);
+                QS_LOAD(b, va3, 16384); QS_WAIT(c, 8); QS_STEP(c, ks0 + 5);
+                                        QS_WAIT(a, 4); QS_STEP(a, ks0 + 6);
+                                        QS_WAIT(b, 0); QS_STEP(b, ks0 + 7);
+            }
+            if (DMA) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if (BAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+    if (REG) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0), "+v"(ra7), "+v"(rb0), "+v"(rb7));
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" : "+a"(acc0), "+a"(acc1), "+a"(acc2), "+a"(acc3));
+    float s = 0.0f;
+    for (int e = 0; e < 16; ++e) s += acc0[e] + acc1[e] + acc2[e] + acc3[e];
+    if (s == 123.456f) out[0] = s;
+    if (blockIdx.x == 0 && tid == 0) {       // shader clock against the constant 100 MHz counter
+        reinterpret_cast<unsigned long long *>(out)[1] = __builtin_amdgcn_s_memtime() - clk0;
+        reinterpret_cast<unsigned long long *>(out)[2] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+}
+
+static int g_tiles = 1200;
+template <int MODE>
+static void run(const float *g, float *out, int cus, const char *what, unsigned spread = 300, int lockstep = 0) {
+    const int tiles = g_tiles, grid = cus;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_loop<MODE>), dim3(grid), dim3(256), 0, 0, g, out, tiles, spread, lockstep);
+    CHECK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_loop<MODE>), dim3(grid), dim3(256), 0, 0, g, out, tiles, spread, lockstep);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+    }
+    const double flop = (double)grid * 4 * tiles * KT2 * 32 * 32768.0;
+    unsigned long long h[3];
+    CHECK(hipMemcpy(h, out, 24, hipMemcpyDeviceToHost));
+    printf("mode %2d  %-72s %7.3f ms  %7.1f TFLOP/s  %.3f of 2500  shader clock %4.0f MHz\n", MODE, what, best, flop / best / 1e9,
+           flop / best / 1e9 / 2500.0, h[2] ? 100.0 * (double)h[1] / (double)h[2] : 0.0);
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1) g_tiles = atoi(argv[1]);      // 1200 tiles = ~5 ms per mode; 20000 = a sustained run
+    int cus = 256;
+    CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+    float *g, *out;
+    const size_t rows = 304 * 128;
+    CHECK(hipMalloc(&g, rows * DW * 4));
+    const int random = argc > 2 ? atoi(argv[2]) : 1;   // argv[2] = 0: all-zero database tiles
+    hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, 0, reinterpret_cast<unsigned *>(g), rows * DW, random);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMalloc(&out, 64));
+    run<0>(g, out, cus, "MFMAs on registers only");
+    run<1>(g, out, cus, "+ fragment reads one k-step ahead");
+    run<1 | 16>(g, out, cus, "+ fragment reads two k-steps ahead");
+    run<1 | 2>(g, out, cus, "+ reads + barrier");
+    run<1 | 2 | 4>(g, out, cus, "+ reads + barrier + LDS-DMA (= the kernel's loop)");
+    run<1 | 2 | 4 | 16>(g, out, cus, "+ reads two ahead + barrier + LDS-DMA");
+    run<1 | 2 | 8>(g, out, cus, "+ reads + barrier + tile through registers (hand-issued loads and LDS writes)");
+    run<1 | 2 | 8 | 16>(g, out, cus, "+ reads two ahead + barrier + tile through registers");
+    run<2 | 4>(g, out, cus, "no fragment reads: barrier + LDS-DMA");
+    run<2 | 8>(g, out, cus, "no fragment reads: barrier + tile through registers");
+    run<1 | 2 | 4>(g, out, cus, "the kernel's loop, every workgroup on the same 4 tiles", 4);
+    run<1 | 2 | 4>(g, out, cus, "the kernel's loop, all workgroups walk the same 300 tiles in step (the chunked scan)", 300, 1);
+    run<1 | 2 | 8>(g, out, cus, "tile through registers, all workgroups walk the same 300 tiles in step", 300, 1);
+    run<1 | 2 | 8 | 16>(g, out, cus, "tile through registers, reads two ahead, all workgroups in step", 300, 1);
+    run<1 | 2 | 4 | 16>(g, out, cus, "LDS-DMA, reads two ahead, all workgroups in step", 300, 1);
+    return 0;
+}
