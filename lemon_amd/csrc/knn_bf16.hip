@@ -431,11 +431,9 @@ __device__ __forceinline__ void qs_filter_tile(f32x16 a, float th, unsigned jb, 
             a[4 * g + 3] = __builtin_fmaf(2.0f, a[4 * g + 3], -xn4.w);
         }
     }
-    const float m0 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
-    const float m1 = fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7]));
-    const float m2 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11]));
-    const float m3 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
-    const float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    const float m0 = max3(max3(a[0], a[1], a[2]), a[3], a[3]), m1 = max3(max3(a[4], a[5], a[6]), a[7], a[7]);
+    const float m2 = max3(max3(a[8], a[9], a[10]), a[11], a[11]), m3 = max3(max3(a[12], a[13], a[14]), a[15], a[15]);
+    const float m = max3(max3(m0, m1, m2), m3, m3);      // 10 x v_max3_f32 (fmaxf: 19 instructions)
     // (survivors are rare here -- a few per wave and tile -- so nested per-lane tests with their early outs beat the
     // fp32 scan's "16 ballots + scalar branches per tile" form: measured 164 vs 177 ms at 262 144^2 x 768)
     if (m > th) {                                   // some lane of the wave has a survivor in this tile

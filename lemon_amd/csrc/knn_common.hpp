@@ -6,6 +6,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace lemon_knn {
 
+// three-input maximum in ONE instruction (fmaxf() makes hipcc quiet every input with `v_max x, x` first; matrix-core
+// results are never signalling NaNs, and a quiet NaN operand is ignored here exactly as a '>' test ignores it)
+__device__ __forceinline__ float max3(float x, float y, float z) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+
 constexpr int BQ = 128;  // query rows per workgroup
 constexpr int BX = 128;  // database rows per tile
 constexpr int BK = 32;   // k-slice per LDS stage

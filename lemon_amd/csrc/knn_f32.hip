@@ -43,12 +43,6 @@ __global__ __launch_bounds__(256) void k_permute_rows(const float *__restrict__ 
 // (appends address the list as uniform base + 32-bit lane offset and compare row numbers in 32 bits: the 64-bit forms
 // cost ~8 more VALU instructions per survivor, and every VALU instruction of the epilogue issues at a fraction of its
 // normal rate against the co-resident workgroup's MFMA stream)
-__device__ __forceinline__ float max3(float x, float y, float z) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
-    return r;
-}
-
 template <bool L2, bool UB>
 __device__ __forceinline__ void f32_filter_tile(f32x16 a, float th, unsigned jb, float qn,
                                                 const float *__restrict__ xnorm, unsigned n, int &ccnt,
