@@ -65,6 +65,9 @@ struct lemon_index {
     int64_t ws_state_elems;
     u64 *ws_part;         // [splits_cap, ws_q, LEMON_MAX_K]
     int64_t ws_part_elems;
+    int *ws_plan;         // fp32 scan: segment plan of (plan_panels, plan_tiles) on the device (knn_f32.hip)
+    int64_t ws_plan_ints;
+    int plan_panels, plan_tiles, plan_grid, plan_splits, plan_pieces_off, plan_segs_off;
     // neighbours workspace
     int64_t ws_nb;        // elements
     float *ws_D;          // [ws_nb]

@@ -950,7 +950,7 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
         }
         LEMON_HIP_CHECK(hipGetLastError());
         if (splits > 1) {
-            rc = lemon_launch_merge(idx->ws_part, splits, 0, 0, nq_pad, cn, k, idx->metric, p.b.D, p.b.I, stream);
+            rc = lemon_launch_merge(idx->ws_part, splits, nullptr, nq_pad, cn, k, idx->metric, p.b.D, p.b.I, stream);
             if (rc) return rc;
         }
         idx->last.algo = LEMON_ALGO_BF16_FILTER;

@@ -63,7 +63,10 @@ struct ScanParams {
     int ablate;           // diagnostic instantiation only: 1 = no operand loads, 2 = no barriers (results invalid)
     int stale;            // new entries per query that trigger a re-selection (fp32 scan)
     int fair;             // fp32 scan: the co-resident workgroups of a CU take turns at the higher issue priority
-    int units_per_wg;     // > 0: balanced decomposition (see lemon_plan_balanced); splits = max pieces per panel
+    const int *plan;      // planned decomposition (knn_f32.hip, lemon_plan_segments): [grid + 1] first segment of every
+                          // workgroup, ..., then at int offset plan_segs the segments (panel, first tile, tiles, piece);
+                          // nullptr: one (panel, split) rectangle per workgroup.  splits = max pieces per panel
+    int plan_segs;
     unsigned *th_pub;     // [nq_pad] order-encoded admission bounds the workgroups sharing a query panel publish to each
                           // other (zero-initialised per launch), or nullptr: see k_scan_f32 "shared bounds"
     const u64 *ub;        // [nq_pad] exclusive upper bound on the key of an admissible row, or nullptr (k > 64: the
@@ -286,10 +289,9 @@ inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
 // host helpers implemented in knn_f32.hip
 int lemon_permute_rows(const float *src, int64_t n, int d, float *dst, int dpad, hipStream_t s);
-int lemon_launch_merge(const u64 *part, int splits, int n_tiles, int units_per_wg, int64_t nq_pad, int64_t nq, int kk, int metric, float *D,
+int lemon_launch_merge(const u64 *part, int splits, const int *pieces, int64_t nq_pad, int64_t nq, int kk, int metric, float *D,
                        int64_t *I, hipStream_t stream);
 int lemon_fill_empty(float *D, int64_t *I, int64_t total, int metric, hipStream_t stream);
 void lemon_plan_splits(int panels, int n_tiles, int *splits, int *tiles_per_split);
-void lemon_plan_balanced(int panels, int n_tiles, unsigned *grid, int *units_per_wg, int *splits, int *tiles_per_split);
 int lemon_ensure_search_ws(lemon_index_t *idx, int64_t nq_pad, int splits, int64_t n_wg, int qp_row_bytes, int cand_cap,
                            hipStream_t stream);

@@ -13,6 +13,8 @@
 // Roofline: dense contraction, 2*nq*n*d flop on the fp32 MFMA pipe (157 TFLOP/s dense peak);
 // HBM traffic is one database stream per resident "generation" of workgroups.
 #include "knn_common.hpp"
+#include <algorithm>
+#include <vector>
 
 using namespace lemon_knn;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -108,20 +110,11 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
 
-    // work range in flattened (panel, tile) units: legacy = one (panel, split) per workgroup; balanced =
-    // equal unit counts per workgroup, a range may cross panel boundaries (one segment per panel touched)
-    int64_t ub, ue;
-    if (p.units_per_wg > 0) {
-        ub = (int64_t)blockIdx.x * p.units_per_wg;
-        ue = ub + p.units_per_wg;
-        const int64_t units = (p.nq_pad / BQ) * p.n_tiles;
-        if (ue > units) ue = units;
-    } else {
-        const int pnl = blockIdx.x / p.splits, spl = blockIdx.x % p.splits;
-        ub = (int64_t)pnl * p.n_tiles + (int64_t)spl * p.tiles_per_split;
-        ue = ub + p.tiles_per_split;
-        if (ue > (int64_t)(pnl + 1) * p.n_tiles) ue = (int64_t)(pnl + 1) * p.n_tiles;
-    }
+    // work of this workgroup: a run of SEGMENTS = (panel, first tile, tiles, piece number inside the panel).  With a plan
+    // (lemon_plan_segments: equal unit counts per workgroup, XCD-aware, see there) they come from a table; without one
+    // (LEMON_SPLITS) the workgroup is one (panel, split) rectangle.
+    int seg = 0, seg_end = 1;
+    if (p.plan) { seg = p.plan[blockIdx.x]; seg_end = p.plan[blockIdx.x + 1]; }
     // Fair shares of the matrix pipe.  The two wavefronts of a SIMD (one from each co-resident workgroup) both have MFMAs
     // ready most of the time, and the issue arbiter prefers the OLDER one: measured at 131 072^2 x 512, the workgroups
     // in the even wave slots lived 106 ms, those in the odd slots 130 ms -- for the last fifth of the launch half the
@@ -149,15 +142,18 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
     char *panel_bytes = reinterpret_cast<char *>(cand_panel);
     const unsigned my_off = (unsigned)(qrow_l * PAIR_CAP + h * (PAIR_CAP / 2)) * 8u;   // this lane's half-list, in bytes
 
-    while (ub < ue) {                                   // workgroup-uniform
-    const int panel = (int)(ub / p.n_tiles);
-    const int t_begin = (int)(ub - (int64_t)panel * p.n_tiles);
-    int t_end = t_begin + (int)(ue - ub);
-    if (t_end > p.n_tiles) t_end = p.n_tiles;
-    const int ntile = t_end - t_begin;           // >= 1 by construction
-    const int split = p.units_per_wg > 0 ? (int)(blockIdx.x - ((int64_t)panel * p.n_tiles) / p.units_per_wg)
-                                         : (int)(blockIdx.x % p.splits);
-    ub += ntile;
+    for (; seg < seg_end; ++seg) {                      // workgroup-uniform
+    int panel, t_begin, ntile, split;
+    if (p.plan) {
+        const int4 sg = reinterpret_cast<const int4 *>(p.plan + p.plan_segs)[seg];
+        panel = sg.x; t_begin = sg.y; ntile = sg.z; split = sg.w;
+    } else {
+        panel = blockIdx.x / p.splits; split = blockIdx.x % p.splits;
+        t_begin = split * p.tiles_per_split;
+        ntile = p.n_tiles - t_begin < p.tiles_per_split ? p.n_tiles - t_begin : p.tiles_per_split;
+    }
+    panel = __builtin_amdgcn_readfirstlane(panel); t_begin = __builtin_amdgcn_readfirstlane(t_begin);
+    ntile = __builtin_amdgcn_readfirstlane(ntile); split = __builtin_amdgcn_readfirstlane(split);
     const int64_t q0 = (int64_t)panel * BQ;
     const int total = ntile * KT;
 
@@ -206,8 +202,8 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
         const float *qs_ = live_ ? qbase + lk * BK : qbase;                                            \
         const float *xs_ = live_ ? xbase + (int64_t)lj * BX * dpad + lk * BK : xbase;                  \
         asm volatile("s_nop 4\n\t"                                                                     \
-                     "global_load_dwordx4 %0, %8, %12\n\tglobal_load_dwordx4 %1, %9, %12\n\t"          \
-                     "global_load_dwordx4 %2, %10, %12\n\tglobal_load_dwordx4 %3, %11, %12\n\t"        \
+                     "global_load_dwordx4 %0, %8, %12\n\tglobal_load_dwordx4 %1, %9, %12\n\t"    \
+                     "global_load_dwordx4 %2, %10, %12\n\tglobal_load_dwordx4 %3, %11, %12\n\t"  \
                      "global_load_dwordx4 %4, %8, %13\n\tglobal_load_dwordx4 %5, %9, %13\n\t"          \
                      "global_load_dwordx4 %6, %10, %13\n\tglobal_load_dwordx4 %7, %11, %13"            \
                      : "=&v"(r##S##_q0), "=&v"(r##S##_q1), "=&v"(r##S##_q2), "=&v"(r##S##_q3),         \
@@ -438,8 +434,8 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
 }
 
 // merge the per-split sorted lists of one query (one wavefront per query)
-__global__ __launch_bounds__(256) void k_merge(const u64 *__restrict__ part, int splits, int n_tiles,
-                                               int units_per_wg, int64_t nq_pad, int64_t nq, int kk, int metric,
+__global__ __launch_bounds__(256) void k_merge(const u64 *__restrict__ part, int splits, const int *__restrict__ pieces,
+                                               int64_t nq_pad, int64_t nq, int kk, int metric,
                                                float *__restrict__ D, int64_t *__restrict__ I) {
     __shared__ __attribute__((aligned(16))) u64 s_keys[4][256];
     __shared__ __attribute__((aligned(16))) u64 s_best[4][64];
@@ -447,10 +443,7 @@ __global__ __launch_bounds__(256) void k_merge(const u64 *__restrict__ part, int
     const int64_t q = (int64_t)blockIdx.x * 4 + wave;
     if (q >= nq) return;
     u64 best = 0;  // lane i: i-th best so far
-    if (units_per_wg > 0) {   // balanced decomposition: pieces of this query's panel = workgroups touching it
-        const int64_t u0 = (q / BQ) * n_tiles;
-        splits = (int)((u0 + n_tiles - 1) / units_per_wg - u0 / units_per_wg) + 1;
-    }
+    if (pieces) splits = pieces[q / BQ];      // planned decomposition: this panel's number of pieces
     const int total = splits * kk;
     for (int base = 0; base < total; base += 192) {
         u64 v[3];
@@ -509,10 +502,10 @@ int lemon_permute_rows(const float *src, int64_t n, int d, float *dst, int dpad,
     return LEMON_OK;
 }
 
-int lemon_launch_merge(const u64 *part, int splits, int n_tiles, int units_per_wg, int64_t nq_pad, int64_t nq,
+int lemon_launch_merge(const u64 *part, int splits, const int *pieces, int64_t nq_pad, int64_t nq,
                        int kk, int metric, float *D, int64_t *I, hipStream_t stream) {
-    hipLaunchKernelGGL(k_merge, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, part, splits, n_tiles,
-                       units_per_wg, nq_pad, nq, kk, metric, D, I);
+    hipLaunchKernelGGL(k_merge, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, part, splits, pieces,
+                       nq_pad, nq, kk, metric, D, I);
     LEMON_HIP_CHECK(hipGetLastError());
     return LEMON_OK;
 }
@@ -543,42 +536,141 @@ void lemon_plan_splits(int panels, int n_tiles, int *splits_out, int *tiles_per_
     *tiles_per_split_out = tiles_per_split;
 }
 
-// Balanced ("stream-K") decomposition of the fp32 scan.  One workgroup alone on a CU reaches only about
-// half the MFMA rate of two co-resident ones, so a grid that is not a multiple of 2 x CUs pays a whole
-// extra round (391 panels ran as slowly as 512).  Instead the panels x tiles unit space is cut into equal
-// contiguous ranges, one per resident slot; a range that crosses a panel boundary yields one partial list
-// per panel touched and k_merge combines the pieces.  *splits_out = max pieces per panel.
-void lemon_plan_balanced(int panels, int n_tiles, unsigned *grid_out, int *units_per_wg_out, int *splits_out,
-                         int *tiles_per_split_out) {
+// Planned ("stream-K", XCD-aware) decomposition of the fp32 scan.
+//
+// Balance.  One workgroup alone on a CU reaches well under the MFMA rate of two co-resident ones, so a grid that is not
+// a multiple of 2 x CUs pays a whole extra round (391 panels ran as slowly as 512).  Instead the panels x tiles unit
+// space is cut into equal shares, one per resident slot; a share that touches several panels yields one partial list per
+// panel touched and k_merge combines the pieces of a panel.
+//
+// Locality.  A workgroup re-streams its query panel (128 x d x 4 B) and streams a database tile of the same size per
+// unit; the 64 workgroups of an XCD move 32 MB per unit time through a 4 MB L2, so NOTHING hits unless workgroups read
+// the same tile at the same time.  With plain contiguous shares (round 1) the shares start at arbitrary tiles: at the
+// headline shape PMC FETCH_SIZE was 2.0 x the scan-model bytes and the launch ran at 0.80 of the MFMA peak, against
+// 0.89 at 262 144^2 where every share happens to be four whole panels walked from tile 0 in step.  So the shares are
+// built per XCD (workgroup b runs on XCD b % 8: round-robin dispatch; panel p belongs to XCD p % 8) and ALIGNED: with
+// u units per workgroup and T tiles per panel, T >= u: as many workgroups as the XCD has panels take tiles [0, u) of
+// one panel each -- they walk the same tiles in step -- and the other workgroups share the tails [u, T); T < u: every
+// workgroup first takes floor(u / T) whole panels (again from tile 0, in step), the rest is shared out.  A segment is
+// (panel, first tile, tiles, piece number in the panel); workgroup b owns segments plan[b] .. plan[b+1].
+struct LemonPlan {
+    std::vector<int> seg_begin;      // [grid + 1]
+    std::vector<int> pieces;         // [panels]
+    std::vector<int> segs;           // 4 ints per segment
+    int grid = 0, splits = 1;
+};
+
+// `c` = what a segment costs on top of its tiles (pipeline refill, the cold start of its candidate lists, the final
+// selection), in tile times: shares are equal in COST, not in tiles -- a workgroup that collects four tails would
+// otherwise finish 5 % after one that walks a single head (measured: lives 16.9 ms against 16.0-16.3 ms).
+static void plan_group(const std::vector<int> &wgs, const std::vector<int> &pnls, int T, int c, std::vector<std::vector<int>> &wg_segs,
+                       std::vector<int> &pieces) {
+    const int m = (int)wgs.size(), n = (int)pnls.size();
+    if (m == 0 || n == 0) return;
+    const int64_t total = (int64_t)n * T;
+    const int64_t u = (total + m - 1) / m;
+    // budget per workgroup: tiles + c per segment; about one segment per panel and one more per workgroup boundary
+    int64_t budget;
+    std::vector<int64_t> room;
+    auto put = [&](int w, int panel, int t0, int nt) {
+        std::vector<int> &v = wg_segs[wgs[w]];
+        v.push_back(panel); v.push_back(t0); v.push_back(nt); v.push_back(pieces[panel]++);
+        room[w] -= nt + c;
+    };
+    std::vector<std::pair<int, int>> pool;   // (panel, first tile) of what the aligned part leaves, panel-major
+    if ((int64_t)T >= u) {                   // heads [0, h) of one panel per workgroup, tails to the pool
+        int64_t h = (total + (int64_t)c * n + m - 1) / m;      // h + c = (n (T - h) + c m) / (m - n)
+        if (h > T || n == m) h = T;
+        budget = h + c;
+        room.assign(m, budget);
+        for (int i = 0; i < n; ++i) {
+            put(i, pnls[i], 0, (int)h);      // n <= m here (n T <= m u and T >= u)
+            if ((int64_t)T > h) pool.push_back(std::make_pair(pnls[i], (int)h));
+        }
+    } else {                                 // whole panels per workgroup while they fit the budget, the rest to the pool
+        budget = ((int64_t)n * (T + c) + m - 1) / m + c;
+        room.assign(m, budget);
+        const int a = (int)(budget / (T + c)) > 0 ? (int)(budget / (T + c)) : 1;
+        int next = 0;
+        for (int w = 0; w < m; ++w)
+            for (int j = 0; j < a && next < n; ++j) put(w, pnls[next++], 0, T);
+        for (; next < n; ++next) pool.push_back(std::make_pair(pnls[next], 0));
+    }
+    int w = 0;
+    for (auto &pt : pool) {                  // share the pool out in order: every workgroup is filled up to its budget
+        int t0 = pt.second;
+        while (t0 < T) {
+            while (w < m - 1 && room[w] <= c) ++w;
+            int64_t fit = room[w] - c;
+            if (fit < 1 || w == m - 1) fit = T;              // the last workgroup takes whatever is left
+            const int nt = (int)std::min<int64_t>(fit, T - t0);
+            put(w, pt.first, t0, nt);
+            t0 += nt;
+        }
+    }
+}
+
+static void lemon_plan_segments(int panels, int n_tiles, LemonPlan &plan) {
     static const int slots = [] {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         return 2 * (cus > 0 ? cus : 256);
     }();
-    static const bool legacy = getenv("LEMON_SPLITS") != nullptr;
+    static const int xcds = [] { const char *e = getenv("LEMON_XCDS"); return e && atoi(e) > 0 ? atoi(e) : 8; }();   // 1 = not XCD-aware
+    static const int seg_cost = [] { const char *e = getenv("LEMON_SEG_COST"); return e ? atoi(e) : 3; }();   // tile times per segment
     const int64_t units = (int64_t)panels * n_tiles;
-    if (legacy || units < 2) {
-        lemon_plan_splits(panels, n_tiles, splits_out, tiles_per_split_out);
-        *grid_out = (unsigned)(panels * *splits_out);
-        *units_per_wg_out = 0;
-        return;
-    }
     int64_t g = units / 8;                               // every workgroup keeps >= 8 tiles
     if (g < 1) g = 1;
-    static const int rounds = [] { const char *e = getenv("LEMON_ROUNDS"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
-    if (g > (int64_t)slots * rounds) g = (int64_t)slots * rounds;
-    const int64_t u = (units + g - 1) / g;
-    g = (units + u - 1) / u;
-    int pieces = 1;
-    for (int pnl = 0; pnl < panels; ++pnl) {
-        const int64_t u0 = (int64_t)pnl * n_tiles;
-        const int c = (int)((u0 + n_tiles - 1) / u - u0 / u) + 1;
-        if (c > pieces) pieces = c;
+    if (g > slots) g = slots;
+    const int X = (panels >= 8 * xcds && g >= 8 * xcds) ? xcds : 1;   // few panels: one group, still aligned
+    std::vector<std::vector<int>> wg_segs((size_t)g);
+    plan.pieces.assign((size_t)panels, 0);
+    for (int x = 0; x < X; ++x) {
+        std::vector<int> wgs, pnls;
+        for (int b = x; b < (int)g; b += X) wgs.push_back(b);
+        for (int q = x; q < panels; q += X) pnls.push_back(q);
+        plan_group(wgs, pnls, n_tiles, seg_cost, wg_segs, plan.pieces);
     }
-    *grid_out = (unsigned)g;
-    *units_per_wg_out = (int)u;
-    *splits_out = pieces;
-    *tiles_per_split_out = n_tiles;
+    plan.grid = (int)g;
+    plan.seg_begin.assign((size_t)g + 1, 0);
+    plan.segs.clear();
+    for (int b = 0; b < (int)g; ++b) {
+        plan.seg_begin[b] = (int)(plan.segs.size() / 4);
+        plan.segs.insert(plan.segs.end(), wg_segs[b].begin(), wg_segs[b].end());
+    }
+    plan.seg_begin[g] = (int)(plan.segs.size() / 4);
+    plan.splits = 1;
+    for (int c : plan.pieces) plan.splits = c > plan.splits ? c : plan.splits;
+}
+
+// the plan of (panels, n_tiles) on the device: [grid + 1] segment offsets | [panels] pieces | pad to 4 ints | segments
+static int lemon_upload_plan(lemon_index_t *idx, int panels, int n_tiles, hipStream_t stream, int *grid, int *splits, int *pieces_off,
+                             int *segs_off) {
+    if (!(idx->plan_panels == panels && idx->plan_tiles == n_tiles && idx->ws_plan)) {
+        LemonPlan plan;
+        lemon_plan_segments(panels, n_tiles, plan);
+        std::vector<int> buf(plan.seg_begin);
+        const int po = (int)buf.size();
+        buf.insert(buf.end(), plan.pieces.begin(), plan.pieces.end());
+        while (buf.size() % 4) buf.push_back(0);
+        const int so = (int)buf.size();
+        buf.insert(buf.end(), plan.segs.begin(), plan.segs.end());
+        LEMON_HIP_CHECK(hipStreamSynchronize(stream));                 // an earlier launch may still read the old plan
+        if ((int64_t)buf.size() > idx->ws_plan_ints) {
+            if (idx->ws_plan) (void)hipFree(idx->ws_plan);
+            idx->ws_plan = nullptr; idx->ws_plan_ints = 0;
+            if (hipMalloc((void **)&idx->ws_plan, buf.size() * sizeof(int)) != hipSuccess) {
+                lemon_set_error("scan plan allocation failed");
+                return LEMON_E_NOMEM;
+            }
+            idx->ws_plan_ints = (int64_t)buf.size();
+        }
+        LEMON_HIP_CHECK(hipMemcpy(idx->ws_plan, buf.data(), buf.size() * sizeof(int), hipMemcpyHostToDevice));
+        idx->plan_panels = panels; idx->plan_tiles = n_tiles; idx->plan_grid = plan.grid; idx->plan_splits = plan.splits;
+        idx->plan_pieces_off = po; idx->plan_segs_off = so;
+    }
+    *grid = idx->plan_grid; *splits = idx->plan_splits; *pieces_off = idx->plan_pieces_off; *segs_off = idx->plan_segs_off;
+    return LEMON_OK;
 }
 
 // qp_row_bytes: bytes of one staged query row (dpad*4 for the fp32 scan, dpad_h*2 for the bf16 one)
@@ -690,9 +782,19 @@ static int lemon_search_f32_pass(lemon_index_t *idx, const float *q_dev, int64_t
         const int64_t cn = (nq - c0) < QCHUNK ? (nq - c0) : QCHUNK;
         const int64_t nq_pad = round_up(cn, BQ);
         const int panels = (int)(nq_pad / BQ);
-        int splits, tiles_per_split, units_per_wg;
+        int splits, tiles_per_split = n_tiles, pieces_off = 0, segs_off = 0;
         unsigned grid;
-        lemon_plan_balanced(panels, n_tiles, &grid, &units_per_wg, &splits, &tiles_per_split);
+        static const bool legacy = getenv("LEMON_SPLITS") != nullptr;   // tuning knob: (panel, split) rectangles, no plan
+        const bool planned = !legacy && (int64_t)panels * n_tiles >= 2;
+        if (planned) {
+            int g = 0;
+            const int prc = lemon_upload_plan(idx, panels, n_tiles, stream, &g, &splits, &pieces_off, &segs_off);
+            if (prc) return prc;
+            grid = (unsigned)g;
+        } else {
+            lemon_plan_splits(panels, n_tiles, &splits, &tiles_per_split);
+            grid = (unsigned)(panels * splits);
+        }
 
         int rc = lemon_ensure_search_ws(idx, nq_pad, splits, grid, dpad * 4, PAIR_CAP, stream);
         if (rc) return rc;
@@ -711,13 +813,13 @@ static int lemon_search_f32_pass(lemon_index_t *idx, const float *q_dev, int64_t
         p.D = D_dev + c0 * k; p.I = I_dev + c0 * k;
         p.nq = cn; p.n = idx->n; p.dpad = dpad; p.kk = k; p.metric = idx->metric;
         p.n_tiles = n_tiles; p.tiles_per_split = tiles_per_split; p.splits = splits; p.nq_pad = nq_pad;
-        p.units_per_wg = units_per_wg; p.phase_dbg = nullptr;
+        p.plan = planned ? idx->ws_plan : nullptr; p.plan_segs = segs_off; p.phase_dbg = nullptr;
         p.ub = ub_dev ? ub_dev + c0 : nullptr;
         // shared admission bounds: one order-encoded float per query, in the tail of the norm workspace ([ws_q, 3] floats:
         // norms, then two spare columns), zeroed per launch; only when a panel really is scanned by several workgroups
         static const bool share = [] { const char *e = getenv("LEMON_SHARE_BOUNDS"); return !(e && e[0] == '0'); }();
         p.th_pub = nullptr;
-        if (share && (units_per_wg > 0 || splits > 1)) {
+        if (share && splits > 1) {
             p.th_pub = reinterpret_cast<unsigned *>(idx->ws_qnorm + 2 * idx->ws_q);
             LEMON_HIP_CHECK(hipMemsetAsync(p.th_pub, 0, (size_t)nq_pad * sizeof(unsigned), stream));
         }
@@ -763,7 +865,7 @@ static int lemon_search_f32_pass(lemon_index_t *idx, const float *q_dev, int64_t
         }
         LEMON_HIP_CHECK(hipGetLastError());
         if (splits > 1) {
-            rc = lemon_launch_merge(idx->ws_part, splits, n_tiles, units_per_wg, nq_pad, cn, k, idx->metric, p.D,
+            rc = lemon_launch_merge(idx->ws_part, splits, planned ? idx->ws_plan + pieces_off : nullptr, nq_pad, cn, k, idx->metric, p.D,
                                     p.I, stream);
             if (rc) return rc;
         }

@@ -167,9 +167,41 @@ __global__ __launch_bounds__(256, 2) void k_loop(const float *__restrict__ g, fl
     if (s == 123.456f) out[0] = s + s_pad[0];
 }
 
+// What does a co-resident wave's VALU work (a filter epilogue) cost the other wave's MFMA loop?  Workgroups in the odd
+// wave slot run `valu_per_mfma` dependent-free v_add_f32 per ... nothing else; those in the even slot run the loop.
+__global__ __launch_bounds__(256, 2) void k_valu_partner(float *out, unsigned long long *lives, int iters, int mfma_only) {
+    const unsigned slot = __builtin_amdgcn_s_getreg((1 << 11) | 4) & 1u;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+    float x0 = threadIdx.x, x1 = 1.0f, x2 = 2.0f, x3 = 3.0f;
+    f32x16 acc0, acc1, acc2, acc3;
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0; acc1[e] = 0; acc2[e] = 0; acc3[e] = 0; }
+    if (slot == 0 || mfma_only) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, x1, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, x1, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, x1, acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, x1, acc3, 0, 0, 0);
+            }
+        }
+    } else {
+        for (int it = 0; it < iters; ++it)       // 64 MFMAs = 4096 cycles on the other wave; 1024 VALU = 4096 issue cycles here
+            asm volatile(".rept 256\n\tv_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %4\n\tv_add_f32 %2, %2, %4\n\tv_add_f32 %3, %3, %4\n\t.endr"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(1.0f));
+    }
+    float s = x0 + x1 + x2 + x3;
+    for (int e = 0; e < 16; ++e) s += acc0[e] + acc1[e] + acc2[e] + acc3[e];
+    if (s == 123.456f) out[0] = s;
+    if (threadIdx.x == 0) {
+        atomicAdd(&lives[2 * slot], __builtin_amdgcn_s_memrealtime() - rt0);
+        atomicAdd(&lives[2 * slot + 1], 1ull);
+    }
+}
+
 template <int MODE, bool ACCA = false>
-static void run(const float *g, float *out, int cus, const char *what, unsigned spread = 300) {
-    const int tiles = 120, grid = 2 * cus;
+static void run(const float *g, float *out, int cus, const char *what, unsigned spread = 300, int wg_per_cu = 2) {
+    const int tiles = 120, grid = wg_per_cu * cus;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     hipLaunchKernelGGL((k_loop<MODE, ACCA>), dim3(grid), dim3(256), 0, 0, g, out, tiles, spread);
@@ -206,8 +238,25 @@ int main() {
     run<1 | 4 | 8 | 16>(g, out, cus, "the kernel's loop, every workgroup on the same 4 tiles (L2 hits)", 4);
     run<1 | 4 | 8 | 16>(g, out, cus, "the kernel's loop, 32 tiles (8 MB footprint)", 32);
     run<1 | 4 | 8 | 256>(g, out, cus, "the kernel's loop with hand-issued global loads and one counted vmcnt(8) per stage");
+    run<1 | 4 | 8 | 256>(g, out, cus, "the same with ONE workgroup per CU (what a wave achieves alone)", 300, 1);
+    run<2 | 4 | 8 | 16>(g, out, cus, "hipcc-style loop with ONE workgroup per CU", 300, 1);
+    run<0>(g, out, cus, "MFMAs on registers only, ONE workgroup per CU", 300, 1);
     run<1 | 8 | 32 | 64>(g, out, cus, "+ reads ahead + LDS-DMA never waited for + barrier");
     run<8 | 32 | 64>(g, out, cus, "no fragment reads: LDS-DMA never waited for + barrier");
     run<1 | 4 | 8 | 16, true>(g, out, cus, "AccVGPR accumulators: the kernel's loop");
+    {
+        unsigned long long *lives, h[4];
+        CHECK(hipMalloc(&lives, 32));
+        const int iters = 4000;
+        for (int mfma_only = 1; mfma_only >= 0; --mfma_only) {
+            CHECK(hipMemset(lives, 0, 32));
+            hipLaunchKernelGGL(k_valu_partner, dim3(2 * cus), dim3(256), 0, 0, out, lives, iters, mfma_only);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipMemcpy(h, lives, 32, hipMemcpyDeviceToHost));
+            printf("%s: even-slot workgroups (MFMA loop, %d x 64 MFMAs) live %.3f ms on average (%llu), odd-slot %.3f ms (%llu)\n",
+                   mfma_only ? "both workgroups of a CU run MFMAs        " : "odd-slot workgroups run v_add_f32 instead",
+                   iters, h[1] ? h[0] / 1e5 / h[1] : 0.0, h[1], h[3] ? h[2] / 1e5 / h[3] : 0.0, h[3]);
+        }
+    }
     return 0;
 }
