@@ -56,11 +56,13 @@ extern "C" int lemon_index_create(int metric, int d, lemon_index_t **out) {
 extern "C" int lemon_index_free(lemon_index_t *idx) {
     if (!idx) return LEMON_OK;
     void *ptrs[] = {idx->x, idx->xp, idx->xnorm, idx->xh, idx->xh_stats, idx->xn2max_dev, idx->ws_qp, idx->ws_qnorm,
-                    idx->ws_cand, idx->ws_part, idx->ws_state, idx->ws_D, idx->ws_I, idx->ws_dd, idx->ws_ddq, idx->ws_plan};
+                    idx->ws_cand, idx->ws_part, idx->ws_state, idx->ws_D, idx->ws_I, idx->ws_dd, idx->ws_ddq,
+                    idx->plan_slots[0].dev, idx->plan_slots[1].dev, idx->plan_slots[2].dev, idx->plan_slots[3].dev};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &e : *idx->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete idx->prof_events;
+    for (auto &slot : idx->plan_slots) delete slot.host;
     free(idx);
     return LEMON_OK;
 }

@@ -65,9 +65,13 @@ struct lemon_index {
     int64_t ws_state_elems;
     u64 *ws_part;         // [splits_cap, ws_q, LEMON_MAX_K]
     int64_t ws_part_elems;
-    int *ws_plan;         // fp32 scan: segment plan of (plan_panels, plan_tiles) on the device (knn_f32.hip)
-    int64_t ws_plan_ints;
-    int plan_panels, plan_tiles, plan_grid, plan_splits, plan_pieces_off, plan_segs_off;
+    // fp32 scan: segment plans on the device (knn_f32.hip), a few recent (panels, tiles) shapes -- a pipeline alternates
+    // between its train / val / test query counts.  `host` keeps the upload's source alive (stream-ordered copy).
+    struct PlanSlot {
+        int panels, tiles, grid, splits, pieces_off, segs_off;
+        int *dev; int64_t ints; unsigned long long stamp; std::vector<int> *host;
+    } plan_slots[4];
+    unsigned long long plan_clock;
     // neighbours workspace
     int64_t ws_nb;        // elements
     float *ws_D;          // [ws_nb]

@@ -643,33 +643,44 @@ static void lemon_plan_segments(int panels, int n_tiles, LemonPlan &plan) {
     for (int c : plan.pieces) plan.splits = c > plan.splits ? c : plan.splits;
 }
 
-// the plan of (panels, n_tiles) on the device: [grid + 1] segment offsets | [panels] pieces | pad to 4 ints | segments
-static int lemon_upload_plan(lemon_index_t *idx, int panels, int n_tiles, hipStream_t stream, int *grid, int *splits, int *pieces_off,
-                             int *segs_off) {
-    if (!(idx->plan_panels == panels && idx->plan_tiles == n_tiles && idx->ws_plan)) {
+// the plan of (panels, n_tiles) on the device: [grid + 1] segment offsets | [panels] pieces | pad to 4 ints | segments.
+// Four recent shapes are kept (least recently used slot replaced); the upload is ordered on the stream, so a launch
+// queued earlier that still reads the slot's old content finishes first, and the source vector lives in the slot.
+static int lemon_get_plan(lemon_index_t *idx, int panels, int n_tiles, hipStream_t stream, const lemon_index::PlanSlot **out) {
+    lemon_index::PlanSlot *hit = nullptr, *lru = &idx->plan_slots[0];
+    for (auto &sl : idx->plan_slots) {
+        if (sl.dev && sl.panels == panels && sl.tiles == n_tiles) hit = &sl;
+        if (sl.stamp < lru->stamp) lru = &sl;
+    }
+    if (!hit) {
         LemonPlan plan;
         lemon_plan_segments(panels, n_tiles, plan);
-        std::vector<int> buf(plan.seg_begin);
+        if (!lru->host) lru->host = new std::vector<int>();
+        else LEMON_HIP_CHECK(hipStreamSynchronize(stream));            // the previous upload from this vector has completed
+        std::vector<int> &buf = *lru->host;
+        buf.assign(plan.seg_begin.begin(), plan.seg_begin.end());
         const int po = (int)buf.size();
         buf.insert(buf.end(), plan.pieces.begin(), plan.pieces.end());
         while (buf.size() % 4) buf.push_back(0);
         const int so = (int)buf.size();
         buf.insert(buf.end(), plan.segs.begin(), plan.segs.end());
-        LEMON_HIP_CHECK(hipStreamSynchronize(stream));                 // an earlier launch may still read the old plan
-        if ((int64_t)buf.size() > idx->ws_plan_ints) {
-            if (idx->ws_plan) (void)hipFree(idx->ws_plan);
-            idx->ws_plan = nullptr; idx->ws_plan_ints = 0;
-            if (hipMalloc((void **)&idx->ws_plan, buf.size() * sizeof(int)) != hipSuccess) {
+        if ((int64_t)buf.size() > lru->ints) {
+            LEMON_HIP_CHECK(hipStreamSynchronize(stream));             // an earlier launch may still read the old buffer
+            if (lru->dev) (void)hipFree(lru->dev);
+            lru->dev = nullptr; lru->ints = 0;
+            if (hipMalloc((void **)&lru->dev, buf.size() * sizeof(int)) != hipSuccess) {
                 lemon_set_error("scan plan allocation failed");
                 return LEMON_E_NOMEM;
             }
-            idx->ws_plan_ints = (int64_t)buf.size();
+            lru->ints = (int64_t)buf.size();
         }
-        LEMON_HIP_CHECK(hipMemcpy(idx->ws_plan, buf.data(), buf.size() * sizeof(int), hipMemcpyHostToDevice));
-        idx->plan_panels = panels; idx->plan_tiles = n_tiles; idx->plan_grid = plan.grid; idx->plan_splits = plan.splits;
-        idx->plan_pieces_off = po; idx->plan_segs_off = so;
+        LEMON_HIP_CHECK(hipMemcpyAsync(lru->dev, buf.data(), buf.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        lru->panels = panels; lru->tiles = n_tiles; lru->grid = plan.grid; lru->splits = plan.splits;
+        lru->pieces_off = po; lru->segs_off = so;
+        hit = lru;
     }
-    *grid = idx->plan_grid; *splits = idx->plan_splits; *pieces_off = idx->plan_pieces_off; *segs_off = idx->plan_segs_off;
+    hit->stamp = ++idx->plan_clock;
+    *out = hit;
     return LEMON_OK;
 }
 
@@ -786,11 +797,11 @@ static int lemon_search_f32_pass(lemon_index_t *idx, const float *q_dev, int64_t
         unsigned grid;
         static const bool legacy = getenv("LEMON_SPLITS") != nullptr;   // tuning knob: (panel, split) rectangles, no plan
         const bool planned = !legacy && (int64_t)panels * n_tiles >= 2;
+        const lemon_index::PlanSlot *plan = nullptr;
         if (planned) {
-            int g = 0;
-            const int prc = lemon_upload_plan(idx, panels, n_tiles, stream, &g, &splits, &pieces_off, &segs_off);
+            const int prc = lemon_get_plan(idx, panels, n_tiles, stream, &plan);
             if (prc) return prc;
-            grid = (unsigned)g;
+            grid = (unsigned)plan->grid; splits = plan->splits; pieces_off = plan->pieces_off; segs_off = plan->segs_off;
         } else {
             lemon_plan_splits(panels, n_tiles, &splits, &tiles_per_split);
             grid = (unsigned)(panels * splits);
@@ -813,7 +824,7 @@ static int lemon_search_f32_pass(lemon_index_t *idx, const float *q_dev, int64_t
         p.D = D_dev + c0 * k; p.I = I_dev + c0 * k;
         p.nq = cn; p.n = idx->n; p.dpad = dpad; p.kk = k; p.metric = idx->metric;
         p.n_tiles = n_tiles; p.tiles_per_split = tiles_per_split; p.splits = splits; p.nq_pad = nq_pad;
-        p.plan = planned ? idx->ws_plan : nullptr; p.plan_segs = segs_off; p.phase_dbg = nullptr;
+        p.plan = planned ? plan->dev : nullptr; p.plan_segs = segs_off; p.phase_dbg = nullptr;
         p.ub = ub_dev ? ub_dev + c0 : nullptr;
         // shared admission bounds: one order-encoded float per query, in the tail of the norm workspace ([ws_q, 3] floats:
         // norms, then two spare columns), zeroed per launch; only when a panel really is scanned by several workgroups
@@ -865,7 +876,7 @@ static int lemon_search_f32_pass(lemon_index_t *idx, const float *q_dev, int64_t
         }
         LEMON_HIP_CHECK(hipGetLastError());
         if (splits > 1) {
-            rc = lemon_launch_merge(idx->ws_part, splits, planned ? idx->ws_plan + pieces_off : nullptr, nq_pad, cn, k, idx->metric, p.D,
+            rc = lemon_launch_merge(idx->ws_part, splits, planned ? plan->dev + pieces_off : nullptr, nq_pad, cn, k, idx->metric, p.D,
                                     p.I, stream);
             if (rc) return rc;
         }
