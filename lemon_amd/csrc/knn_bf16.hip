@@ -464,14 +464,23 @@ __device__ __forceinline__ u64 qs_load_slot(const u64 *__restrict__ list, int id
 
 // light compaction of one query (both half-lists): bisection for the k-th largest approximate score,
 // keep what can still matter, packed at the front of half-list 0 (then half-list 1).  Returns kept.
-__device__ __forceinline__ int qs_compact_light(u64 *__restrict__ list, int n0, int n1, int kk, float eps, int lane,
-                                                float *lo_out) {
-    u64 v[8];
+// The lists are read into NS register slots of 64 entries -- the occupied 64-blocks of half-list 0 first (s0 of them),
+// then those of half-list 1; typical lists fill 2-3 of the 8 possible blocks, and every bisection step costs one
+// compare + ballot + popcount per slot, so NS is specialised (as in the fp32 scan's PairSlots).
+template <int NS>
+__device__ __forceinline__ int qs_compact_light_ns(u64 *__restrict__ list, int n0, int n1, int s0, int kk, float eps, int lane,
+                                                   float *lo_out) {
+    u64 v[NS];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = qs_load_slot(list, lane + 64 * i, n0, n1);
-    u32 o[8];
+    for (int i = 0; i < NS; ++i) {
+        const bool lo_half = i < s0;
+        const int pos = lane + 64 * (lo_half ? i : i - s0);
+        const bool ok = lo_half ? pos < n0 : pos < n1;
+        v[i] = ok ? list[lo_half ? pos : CAPH / 2 + pos] : 0;
+    }
+    u32 o[NS];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (u32)(v[i] >> 32);
+    for (int i = 0; i < NS; ++i) o[i] = (u32)(v[i] >> 32);
     // t <= tau (the kk-th largest approximate score word): any lower bound of tau keeps the band a proof, so the
     // bisection stops at the first prefix that at most kk + 8 keys reach (~14 of the 32 steps)
     u32 t = 0;
@@ -480,7 +489,7 @@ __device__ __forceinline__ int qs_compact_light(u64 *__restrict__ list, int n0, 
         const u32 cand = t | (1u << bit);
         int c = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) c += __builtin_popcountll(__ballot(o[i] >= cand));
+        for (int i = 0; i < NS; ++i) c += __builtin_popcountll(__ballot(o[i] >= cand));
         if (c >= kk) {
             t = cand;
             if (c <= kk + 8) break;
@@ -490,14 +499,22 @@ __device__ __forceinline__ int qs_compact_light(u64 *__restrict__ list, int n0, 
     const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int base = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NS; ++i) {
         const bool keep = v[i] && lemon_key_score(v[i]) > lo;
         const u64 m = __ballot(keep);
-        if (keep) list[base + __builtin_popcountll(m & below)] = v[i];   // contiguous over both halves
+        if (keep) list[base + __builtin_popcountll(m & below)] = v[i];   // contiguous over both halves (all loads precede)
         base += __builtin_popcountll(m);
     }
     *lo_out = lo;
     return base;
+}
+__device__ __forceinline__ int qs_compact_light(u64 *__restrict__ list, int n0, int n1, int kk, float eps, int lane,
+                                                float *lo_out) {
+    const int s0 = (n0 + 63) >> 6, ns = s0 + ((n1 + 63) >> 6);   // wave-uniform
+    if (ns <= 2) return qs_compact_light_ns<2>(list, n0, n1, s0, kk, eps, lane, lo_out);
+    if (ns == 3) return qs_compact_light_ns<3>(list, n0, n1, s0, kk, eps, lane, lo_out);
+    if (ns == 4) return qs_compact_light_ns<4>(list, n0, n1, s0, kk, eps, lane, lo_out);
+    return qs_compact_light_ns<8>(list, n0, n1, s0, kk, eps, lane, lo_out);
 }
 
 // exact compaction of one query: re-score every entry of both half-lists with the fp32 chain, leave the

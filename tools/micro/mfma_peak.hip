@@ -75,6 +75,37 @@ __global__ __launch_bounds__(256) void k_bf16_random(float *out, int iters, unsi
     }
 }
 
+// the same with v_mfma_f32_16x16x32_bf16 (a quarter of the accumulator registers per instruction, half per flop)
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_bf16_random_16(float *out, int iters, unsigned seed, int zero) {
+    f32x4v acc[8];
+    for (int i = 0; i < 8; ++i) for (int e = 0; e < 4; ++e) acc[i][e] = 0.0f;
+    bf16x8 av[8], bv[4];
+    unsigned r = seed + threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+    for (int i = 0; i < 8; ++i) for (int e = 0; e < 8; ++e) {
+        r ^= r << 13; r ^= r >> 17; r ^= r << 5;
+        av[i][e] = zero ? (__bf16)0.0f : (__bf16)(((int)(r & 1023) - 512) * (1.0f / 4096.0f));
+    }
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 8; ++e) {
+        r ^= r << 13; r ^= r >> 17; r ^= r << 5;
+        bv[i][e] = zero ? (__bf16)0.0f : (__bf16)(((int)(r & 1023) - 512) * (1.0f / 4096.0f));
+    }
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[(rr + i) & 7], bv[(rr >> 2) & 3], acc[i], 0, 0, 0);
+    }
+    float s = 0.0f;
+    for (int i = 0; i < 8; ++i) for (int e = 0; e < 4; ++e) s += acc[i][e];
+    if (s == 123.456f) out[0] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        reinterpret_cast<unsigned long long *>(out)[1] = __builtin_amdgcn_s_memtime() - clk0;
+        reinterpret_cast<unsigned long long *>(out)[2] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+}
+
 template <typename F>
 static double time_ms(F launch) {
     hipEvent_t e0, e1;
@@ -111,6 +142,15 @@ int main() {
         CHECK(hipMemcpy(h, out, 24, hipMemcpyDeviceToHost));
         printf("bf16 32x32x16 sustained, %s operands, 1 wave/SIMD  %8.3f ms  %7.1f TFLOP/s  shader clock %4.0f MHz\n",
                zero ? "all-zero" : "random  ", ms, mf * 32768 / ms / 1e9, h[2] ? 100.0 * (double)h[1] / (double)h[2] : 0.0);
+    }
+    for (int zero = 1; zero >= 0; --zero) {
+        const int it2 = 60000;
+        const double mf = (double)cus * 4 * it2 * 128;       // 16x16x32 MFMAs: 16 384 flop each
+        const double ms = time_ms([&] { hipLaunchKernelGGL(k_bf16_random_16, dim3(cus), dim3(256), 0, 0, out, it2, 12345u, zero); });
+        unsigned long long h[3];
+        CHECK(hipMemcpy(h, out, 24, hipMemcpyDeviceToHost));
+        printf("bf16 16x16x32 sustained, %s operands, 1 wave/SIMD  %8.3f ms  %7.1f TFLOP/s  shader clock %4.0f MHz\n",
+               zero ? "all-zero" : "random  ", ms, mf * 16384 / ms / 1e9, h[2] ? 100.0 * (double)h[1] / (double)h[2] : 0.0);
     }
     return 0;
 }
