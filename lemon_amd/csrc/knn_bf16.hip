@@ -88,7 +88,7 @@ struct ScanParamsH {
     // HBM; per-query state (list length, admission bound) lives in `state` between launches
     int chunk_t0, chunk_t1, first_chunk, last_chunk;
     float *state;              // [grid*256 lanes][4]: {half-list count, last compacted length, thr_key, -}
-    int ablate;                // diagnostics only (LEMON_ABLATE): 1 = skip the filter epilogue, 2 = skip maintenance
+    int ablate;                // diagnostics only (LEMON_ABLATE): 1 = skip the filter epilogue, 4 = nothing passes the filter
     unsigned long long *phase_dbg;   // diagnostic builds only: [grid][4] cycle sums (loop, epilogue, sync, maintain)
 };
 
@@ -732,10 +732,14 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
                 asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc0), "+a"(acc1), "+a"(acc2), "+a"(acc3));
                 // ---- epilogue: acc[ni][e] = s~(db row 32ni + (e&3) + 8(e>>2) + 4h, query lane&31) ----
                 const unsigned jb = (unsigned)(t_begin + jl) * BX + 4 * h;
-                qs_filter_tile<l2>(acc0, th, jb, my_qn, p.b.xnorm, (unsigned)p.b.n, ccnt, panel_bytes, my_off);
-                qs_filter_tile<l2>(acc1, th, jb + 32, my_qn, p.b.xnorm, (unsigned)p.b.n, ccnt, panel_bytes, my_off);
-                qs_filter_tile<l2>(acc2, th, jb + 64, my_qn, p.b.xnorm, (unsigned)p.b.n, ccnt, panel_bytes, my_off);
-                qs_filter_tile<l2>(acc3, th, jb + 96, my_qn, p.b.xnorm, (unsigned)p.b.n, ccnt, panel_bytes, my_off);
+                // (diagnostic, results invalid: LEMON_ABLATE bit 2 = nothing passes the filter, i.e. accumulator read-out
+                // and maximum tree only: 97.0 ms at 262 144^2 x 768 against 91.2 with no epilogue at all and 145.8 whole --
+                // the appends and compactions, not the read-out, are what the epilogue costs)
+                const float th_f = (p.ablate & 4) ? INFINITY : th;
+                qs_filter_tile<l2>(acc0, th_f, jb, my_qn, p.b.xnorm, (unsigned)p.b.n, ccnt, panel_bytes, my_off);
+                qs_filter_tile<l2>(acc1, th_f, jb + 32, my_qn, p.b.xnorm, (unsigned)p.b.n, ccnt, panel_bytes, my_off);
+                qs_filter_tile<l2>(acc2, th_f, jb + 64, my_qn, p.b.xnorm, (unsigned)p.b.n, ccnt, panel_bytes, my_off);
+                qs_filter_tile<l2>(acc3, th_f, jb + 96, my_qn, p.b.xnorm, (unsigned)p.b.n, ccnt, panel_bytes, my_off);
                 PH_STAMP(ph1);
 
                 // ---- maintenance: which queries need a (light) compaction? ----
