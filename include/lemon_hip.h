@@ -217,6 +217,15 @@ int lemon_index_set_profiling(lemon_index_t *idx, int enabled);
 int lemon_index_profile_read(lemon_index_t *idx, int64_t *launches, double *kernel_ms,
                              double *algo_flops, double *algo_bytes);
 
+/* Host-only view of how the exact scan (LEMON_ALGO_F32_MFMA) decomposes `panels` query panels (128 queries each) x
+ * `n_tiles` database tiles (128 rows each) over its workgroups: for tests and tools, no device is touched.
+ *   seg_begin [*grid + 1]  first segment of every workgroup (cap_wgs + 1 ints of room)
+ *   pieces    [panels]     pieces the panel is scanned in (what the merge combines)
+ *   segs      [4 * *n_segs] (panel, first tile, tiles, piece number inside the panel) per segment (cap_segs segments of room)
+ * Returns LEMON_E_ARG when an output does not fit. */
+int lemon_debug_scan_plan(int panels, int n_tiles, int *grid, int *splits, int *seg_begin, int cap_wgs,
+                          int *pieces, int *segs, int cap_segs, int *n_segs);
+
 /* ---- multimodal neighbours (the per-sample loop run_lemon.py:238-307) ------------- */
 
 /*

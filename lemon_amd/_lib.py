@@ -21,7 +21,7 @@ EXPORTS = [
     "lemon_linear_dump_tuned", "lemon_linear_set_tuning", "lemon_linear_stamp", "lemon_index_create", "lemon_index_free", "lemon_index_add",
     "lemon_index_ntotal", "lemon_index_dim", "lemon_index_data", "lemon_index_search",
     "lemon_index_set_algo", "lemon_index_set_query_dedup", "lemon_index_last_search_info", "lemon_index_set_profiling",
-    "lemon_index_profile_read", "lemon_neighbors", "lemon_discrepancy", "lemon_score", "lemon_grid_f1",
+    "lemon_index_profile_read", "lemon_debug_scan_plan", "lemon_neighbors", "lemon_discrepancy", "lemon_score", "lemon_grid_f1",
 ]
 
 
@@ -87,6 +87,8 @@ def load():
     lib.lemon_index_last_search_info.argtypes = [vp, ctypes.POINTER(SearchInfo)]
     lib.lemon_index_set_profiling.argtypes = [vp, c_int]
     lib.lemon_index_profile_read.argtypes = [vp, ctypes.POINTER(c_i64)] + [ctypes.POINTER(ctypes.c_double)] * 3
+    ip = ctypes.POINTER(c_int)
+    lib.lemon_debug_scan_plan.argtypes = [c_int, c_int, ip, ip, ip, c_int, ip, ip, c_int, ip]
     lib.lemon_neighbors.argtypes = [vp, vp, vp, vp, vp, c_i64, c_int, c_int, vp, c_int, vp, vp] + [vp] * 9 + [vp]
     lib.lemon_discrepancy.argtypes = [c_int, vp, vp, vp, vp, c_i64, c_int, c_int, vp, vp]
     lib.lemon_score.argtypes = [vp] * 7 + [c_i64, c_int, ctypes.POINTER(ctypes.c_double), vp, vp, vp, vp]

@@ -643,6 +643,20 @@ static void lemon_plan_segments(int panels, int n_tiles, LemonPlan &plan) {
     for (int c : plan.pieces) plan.splits = c > plan.splits ? c : plan.splits;
 }
 
+extern "C" int lemon_debug_scan_plan(int panels, int n_tiles, int *grid, int *splits, int *seg_begin, int cap_wgs, int *pieces,
+                                     int *segs, int cap_segs, int *n_segs) {
+    LEMON_REQUIRE(panels > 0 && n_tiles > 0, "panels, n_tiles > 0");
+    LEMON_REQUIRE(grid && splits && seg_begin && pieces && segs && n_segs, "output pointers");
+    LemonPlan plan;
+    lemon_plan_segments(panels, n_tiles, plan);
+    LEMON_REQUIRE(plan.grid <= cap_wgs && (int)(plan.segs.size() / 4) <= cap_segs, "plan fits the output buffers");
+    *grid = plan.grid; *splits = plan.splits; *n_segs = (int)(plan.segs.size() / 4);
+    std::copy(plan.seg_begin.begin(), plan.seg_begin.end(), seg_begin);
+    std::copy(plan.pieces.begin(), plan.pieces.end(), pieces);
+    std::copy(plan.segs.begin(), plan.segs.end(), segs);
+    return LEMON_OK;
+}
+
 // the plan of (panels, n_tiles) on the device: [grid + 1] segment offsets | [panels] pieces | pad to 4 ints | segments.
 // Four recent shapes are kept (least recently used slot replaced); the upload is ordered on the stream, so a launch
 // queued earlier that still reads the slot's old content finishes first, and the source vector lives in the slot.

@@ -222,3 +222,35 @@ def test_embedding_cache_roundtrip_and_keying(tmp_path):
     (entry / "done").unlink()
     assert c.load("train", 0, 5, prompts, "cpu") is None
     assert EmbeddingCache(None).load("train", 0, 5, prompts, "cpu") is None    # disabled cache
+
+
+@pytest.mark.parametrize("panels,tiles", [(391, 313), (2048, 2048), (40, 313), (1, 1), (1, 313), (7, 5), (725, 391),
+                                          (157, 7813), (64, 10), (3, 2000), (8192, 3), (513, 129)])
+def test_scan_plan_covers_every_unit_once(panels, tiles):
+    """lemon_plan_segments (csrc/knn_f32.hip) through the host-only lemon_debug_scan_plan: the segments of all workgroups tile
+    the panels x tiles unit space exactly once, stay inside their panel, number a panel's pieces 0 .. pieces-1 without gaps
+    (k_merge reads exactly those slots), and no workgroup carries much more than its share."""
+    import ctypes
+    from lemon_amd import _lib
+    lib = _lib.load()
+    cap_wgs, cap_segs = 4096, panels * 8 + 8192
+    g, sp, ns = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    sb = np.zeros(cap_wgs + 1, np.int32); pc = np.zeros(panels, np.int32); sg = np.zeros(4 * cap_segs, np.int32)
+    ip = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+    rc = lib.lemon_debug_scan_plan(panels, tiles, ctypes.byref(g), ctypes.byref(sp), ip(sb), cap_wgs, ip(pc), ip(sg), cap_segs,
+                                   ctypes.byref(ns))
+    assert rc == 0
+    grid, segs = g.value, sg[:4 * ns.value].reshape(-1, 4)
+    assert sb[0] == 0 and sb[grid] == ns.value and (np.diff(sb[:grid + 1]) >= 0).all()
+    cover = np.zeros((panels, tiles), np.int32)
+    seen = [set() for _ in range(panels)]
+    for pnl, t0, nt, piece in segs:
+        assert 0 <= pnl < panels and t0 >= 0 and nt >= 1 and t0 + nt <= tiles
+        assert 0 <= piece < pc[pnl] and piece not in seen[pnl]
+        seen[pnl].add(piece)
+        cover[pnl, t0:t0 + nt] += 1
+    assert (cover == 1).all()
+    assert all(len(seen[p_]) == pc[p_] for p_ in range(panels)) and sp.value == pc.max()
+    work = np.array([segs[sb[b]:sb[b + 1], 2].sum() + 3 * (sb[b + 1] - sb[b]) for b in range(grid)])   # tiles + 3 per segment
+    share = (panels * tiles + 3 * len(segs)) / grid
+    assert work.max() <= 1.25 * share + tiles * 0 + 8, (work.max(), share)
