@@ -1,17 +1,20 @@
 // knn_f32.hip -- exact brute-force top-k scan on the fp32 matrix cores of gfx950.
 //
 // Stands in for faiss IndexFlat{IP,L2}.search as called at run_lemon.py:235-236.
-// One workgroup owns a panel of BQ=128 queries and streams a contiguous range of database
-// tiles (BX=128 rows) through LDS; S = Q.X^T is accumulated by v_mfma_f32_32x32x2_f32 in
+// A workgroup works through SEGMENTS (lemon_plan_segments): a panel of BQ=128 queries against a contiguous range of
+// database tiles (BX=128 rows) streamed through LDS; S = Q.X^T is accumulated by v_mfma_f32_32x32x2_f32 in
 // ascending k, which is bit-for-bit the float32 fmaf chain of the numeric contract, so the
 // scores (and therefore the selected sets, given the index tie rule) are identical to the CPU
 // oracle's.  Selection is fused into the tile epilogue: an accumulator element that beats the
 // query's current admission threshold (a lower bound of its k-th best score, kept in a VGPR) is appended to the
 // owning lane's private half of that query's candidate list (count in a VGPR, list L2-resident: one predicated
 // global store, no atomics, no LDS); a list is re-selected by one wavefront when it has grown by ~96 entries.
+// The main loop issues every memory instruction by hand (counted waits), the two workgroups of a CU take turns at
+// the higher issue priority, and the shares of work are aligned per XCD: DESIGN.md section 4 has the measurements.
 //
 // Roofline: dense contraction, 2*nq*n*d flop on the fp32 MFMA pipe (157 TFLOP/s dense peak);
-// HBM traffic is one database stream per resident "generation" of workgroups.
+// fabric traffic: one query-panel slice + one database tile per unit, shared through the L2 only between
+// workgroups that walk the same tiles in step.
 #include "knn_common.hpp"
 #include <algorithm>
 #include <vector>
