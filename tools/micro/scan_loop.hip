@@ -199,6 +199,104 @@ __global__ __launch_bounds__(256, 2) void k_valu_partner(float *out, unsigned lo
     }
 }
 
+// ---- the same loop with 16-wide stages (64-B LDS rows, 32 KB of tiles per workgroup): three workgroups per CU ----
+__device__ __forceinline__ int swz16(int r, int c) { return r * 16 + 4 * (c ^ ((r >> 2) & 3)); }
+template <int WGS>
+__global__ __launch_bounds__(256, WGS) void k_loop16(const float *__restrict__ g, float *out, int tiles, unsigned spread) {
+    __shared__ __attribute__((aligned(16))) float s_tile[2][2][2048];    // [buf][Q|X][128 rows x 16]
+    __shared__ float s_pad[WGS == 3 ? 2048 : 8192];                       // 40 KB (3 per CU) / 64 KB (2 per CU)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float *)&s_tile[0][0][0];
+    const unsigned wa = lds0 + 4u * (unsigned)swz16(tid >> 2, tid & 3);   // row tid>>2 (+64), chunk tid&3
+    unsigned aq[2], ax[2];
+    for (int u = 0; u < 2; ++u) {
+        aq[u] = lds0 + 4u * (unsigned)swz16(32 * wave + l31, 2 * u + h);
+        ax[u] = lds0 + 4u * (unsigned)swz16(l31, 2 * u + h);
+    }
+    for (int i = tid; i < 2 * 2 * 2048; i += 256) (&s_tile[0][0][0])[i] = 1.0f + i;
+    if (tid == 0) s_pad[0] = 0.0f;
+    __syncthreads();
+    f32x16 acc0, acc1, acc2, acc3;
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0; acc1[e] = 0; acc2[e] = 0; acc3[e] = 0; }
+    const f32x4 one = {1.0f, 2.0f, 3.0f, 4.0f};
+    f32x4 fa_b = one, fa_0 = one, fa_1 = one, fa_2 = one, fa_3 = one, fb_b = one, fb_0 = one, fb_1 = one, fb_2 = one, fb_3 = one;
+    f32x4 ra_0 = one, ra_1 = one, ra_2 = one, ra_3 = one, rb_0 = one, rb_1 = one, rb_2 = one, rb_3 = one;
+    const unsigned voff = (unsigned)(((tid >> 2) * DPAD + 4 * (tid & 3)) * 4), voffb = voff + 64u * DPAD * 4;
+    const float *qbase = g + (size_t)(blockIdx.x % spread) * 128 * DPAD;
+    const int t0 = (int)((blockIdx.x * 61u) % spread);
+    int lk = 0, lj = 0;
+    constexpr int KT16 = DPAD / 16;
+#define ISSUE16(S)                                                                                     \
+    do {                                                                                               \
+        const float *qs_ = qbase + lk * 16;                                                            \
+        const float *xs_ = g + (size_t)((t0 + lj) % spread) * 128 * DPAD + lk * 16;                    \
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %6\n\tglobal_load_dwordx4 %1, %5, %6\n\t"  \
+                     "global_load_dwordx4 %2, %4, %7\n\tglobal_load_dwordx4 %3, %5, %7"                \
+                     : "=&v"(r##S##_0), "=&v"(r##S##_1), "=&v"(r##S##_2), "=&v"(r##S##_3)              \
+                     : "v"(voff), "v"(voffb), "s"(qs_), "s"(xs_) : "memory");                          \
+        if (++lk == KT16) { lk = 0; ++lj; }                                                            \
+    } while (0)
+#define ST16(V, OFF) asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(wa), "v"(V), "n"(OFF) : "memory")
+#define COMMIT16(S, BUF)                                                                               \
+    do {                                                                                               \
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(r##S##_0), "+v"(r##S##_1), "+v"(r##S##_2), "+v"(r##S##_3)); \
+        ST16(r##S##_0, (BUF) * 16384); ST16(r##S##_1, (BUF) * 16384 + 4096);                           \
+        ST16(r##S##_2, (BUF) * 16384 + 8192); ST16(r##S##_3, (BUF) * 16384 + 12288);                   \
+    } while (0)
+#define FRAG16(F, BUF, U)                                                                              \
+    asm volatile("ds_read_b128 %0, %5 offset:%7\n\tds_read_b128 %1, %6 offset:%8\n\tds_read_b128 %2, %6 offset:%9\n\t" \
+                 "ds_read_b128 %3, %6 offset:%10\n\tds_read_b128 %4, %6 offset:%11"                    \
+                 : "=&v"(F##_b), "=&v"(F##_0), "=&v"(F##_1), "=&v"(F##_2), "=&v"(F##_3)                \
+                 : "v"(aq[U]), "v"(ax[U]), "n"((BUF) * 16384), "n"((BUF) * 16384 + 8192),              \
+                   "n"((BUF) * 16384 + 10240), "n"((BUF) * 16384 + 12288), "n"((BUF) * 16384 + 14336) : "memory")
+#define WAIT16(F, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F##_b), "+v"(F##_0), "+v"(F##_1), "+v"(F##_2), "+v"(F##_3))
+#define MFMA16(F)                                                                                      \
+    do {                                                                                               \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(F##_0[m], F##_b[m], acc0, 0, 0, 0);            \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(F##_1[m], F##_b[m], acc1, 0, 0, 0);            \
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(F##_2[m], F##_b[m], acc2, 0, 0, 0);            \
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(F##_3[m], F##_b[m], acc3, 0, 0, 0);            \
+        }                                                                                              \
+    } while (0)
+    // stage: fa holds k-group 0; reads of group 1 ahead; commit + issue; barrier; next stage's group 0
+#define STEP16(BUF, SET)                                                                               \
+    do {                                                                                               \
+        FRAG16(fb, BUF, 1); WAIT16(fa, 5); MFMA16(fa);                                                 \
+        COMMIT16(SET, (BUF) ^ 1); ISSUE16(SET);                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3) : : "memory"); \
+        FRAG16(fa, (BUF) ^ 1, 0); WAIT16(fb, 5); MFMA16(fb);                                           \
+    } while (0)
+    ISSUE16(a); ISSUE16(b);
+    FRAG16(fa, 0, 0);
+    for (int it = 0; it < tiles * KT16; it += 2) { STEP16(0, a); STEP16(1, b); }
+    WAIT16(fa, 0); WAIT16(fb, 0);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra_0), "+v"(ra_3), "+v"(rb_0), "+v"(rb_3));
+    float s = 0.0f;
+    for (int e = 0; e < 16; ++e) s += acc0[e] + acc1[e] + acc2[e] + acc3[e];
+    s += ra_0[0] + rb_0[0];
+    if (s == 123.456f) out[0] = s + s_pad[0];
+}
+
+template <int WGS>
+static void run16(const float *g, float *out, int cus, const char *what) {
+    const int tiles = 120, grid = WGS * cus;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_loop16<WGS>), dim3(grid), dim3(256), 0, 0, g, out, tiles, 300u);
+    CHECK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_loop16<WGS>), dim3(grid), dim3(256), 0, 0, g, out, tiles, 300u);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+    }
+    const double flop = (double)grid * 4 * tiles * (DPAD / 16) * 32 * 4096;
+    printf("16-wide stages, %d workgroups per CU: %-50s %7.3f ms  %6.1f TFLOP/s  %.3f of 157.3\n", WGS, what, best, flop / best / 1e9,
+           flop / best / 1e9 / 157.3);
+}
+
 template <int MODE, bool ACCA = false>
 static void run(const float *g, float *out, int cus, const char *what, unsigned spread = 300, int wg_per_cu = 2) {
     const int tiles = 120, grid = wg_per_cu * cus;
@@ -244,6 +342,8 @@ int main() {
     run<1 | 8 | 32 | 64>(g, out, cus, "+ reads ahead + LDS-DMA never waited for + barrier");
     run<8 | 32 | 64>(g, out, cus, "no fragment reads: LDS-DMA never waited for + barrier");
     run<1 | 4 | 8 | 16, true>(g, out, cus, "AccVGPR accumulators: the kernel's loop");
+    run16<2>(g, out, cus, "hand-issued loop");
+    run16<3>(g, out, cus, "hand-issued loop");
     {
         unsigned long long *lives, h[4];
         CHECK(hipMalloc(&lives, 32));
