@@ -80,3 +80,29 @@ def test_config4_cc3m_scale_self_join(hip, oracle):
     rows = sub[::128]
     Do, Io = oracle.knn("ip", X.cpu().numpy(), X[rows].cpu().numpy(), k)
     assert np.array_equal(I[rows].cpu().numpy(), Io) and np.array_equal(D[rows].cpu().numpy(), Do)
+
+
+@pytest.mark.parametrize("nq,n,d,k", [(70000, 1500, 64, 10),      # 547 panels x 12 tiles: whole panels per workgroup + a shared pool
+                                      (9000, 300, 32, 7),         # 71 panels x 3 tiles: fewer workgroups than slots
+                                      (33000, 9000, 128, 20),     # 258 panels x 71 tiles
+                                      (1000, 70000, 64, 10),      # 8 panels x 547 tiles: one group, many pieces per panel
+                                      (20000, 33000, 96, 33)])    # 157 panels x 258 tiles, d not a multiple of 64
+def test_exact_scan_plan_regimes_against_the_oracle_on_sampled_queries(hip, oracle, nq, n, d, k):
+    """The planned decomposition of the exact scan (lemon_plan_segments: heads / tails / whole panels / pool, pieces merged
+    by k_merge) at shapes that exercise every branch of the planner: the rows of 512 sampled queries are bit-identical
+    to the oracle's, every row is sorted, and nothing changes when the same queries are searched in a different batch
+    (another plan)."""
+    import lemon_amd
+    dev = torch.device("cuda", 0)
+    x, q = _unit(n, d, 11, dev), _unit(nq, d, 12, dev)
+    idx = lemon_amd.IndexFlatIP(d)
+    idx.set_algo(1)                                   # the exact fp32 scan
+    idx.add(x)
+    D, I = idx.search(q, k)
+    torch.cuda.synchronize()
+    assert (D[:, :-1] >= D[:, 1:]).all() and (I >= 0).all() and (I < n).all()
+    sel = torch.from_numpy(np.random.RandomState(3).choice(nq, 512, replace=False)).to(dev)
+    Do, Io = oracle.knn("ip", x.cpu().numpy(), q[sel].cpu().numpy(), k)
+    assert np.array_equal(I[sel].cpu().numpy(), Io) and np.array_equal(D[sel].cpu().numpy(), Do)
+    D2, I2 = idx.search(q[sel], k)                    # 4 panels: a different plan, same rows
+    assert torch.equal(I2, I[sel]) and torch.equal(D2, D[sel])
