@@ -431,6 +431,7 @@ __global__ __launch_bounds__(NT, 2) void k_scan_f32(ScanParams p) {
         atomicMin(&p.phase_dbg[7], rt);
         atomicAdd(&p.phase_dbg[8 + 2 * slot], rt);
         atomicAdd(&p.phase_dbg[9 + 2 * slot], 1ull);
+        if (blockIdx.x < 4096) p.phase_dbg[16 + blockIdx.x] = rt;
     }
 #undef PH_STAMP
 #undef F32_BASE_PRIO
@@ -871,7 +872,7 @@ static int lemon_search_f32_pass(lemon_index_t *idx, const float *q_dev, int64_t
             LemonProfScope prof(idx, stream, flops, bytes);
             if (!ub_dev && idx->metric == LEMON_METRIC_IP && getenv("LEMON_PHASE_PROF")) {   // diagnostic build: phase cycle sums
                 static unsigned long long *dbg = nullptr;
-                if (!dbg) { (void)hipMalloc(&dbg, 128); (void)hipMemset(dbg, 0, 128); }
+                if (!dbg) { (void)hipMalloc(&dbg, 128 + 8 * 4096); (void)hipMemset(dbg, 0, 128 + 8 * 4096); }
                 (void)hipMemset(dbg + 7, 0xff, 8);
                 p.phase_dbg = dbg;
                 hipLaunchKernelGGL((k_scan_f32<false, true>), dim3(grid), dim3(NT), 0, stream, p);
@@ -884,7 +885,12 @@ static int lemon_search_f32_pass(lemon_index_t *idx, const float *q_dev, int64_t
                         h[4], h[5], h[5] ? 100.0 * (double)h[4] / (double)h[5] : 0.0);
                 fprintf(stderr, "[lives f32] workgroup life min %.2f ms  max %.2f ms;  wave-slot parity 0: %llu workgroups, mean %.2f ms;  parity 1: %llu, mean %.2f ms\n",
                         h[7] / 1e5, h[6] / 1e5, h[9], h[9] ? h[8] / 1e5 / h[9] : 0.0, h[11], h[11] ? h[10] / 1e5 / h[11] : 0.0);
-                (void)hipMemset(dbg, 0, 128);
+                if (const char *dump = getenv("LEMON_LIVES_DUMP")) {      // per-workgroup lives (100 MHz ticks), one per line
+                    std::vector<unsigned long long> lv(grid < 4096 ? grid : 4096);
+                    (void)hipMemcpy(lv.data(), dbg + 16, lv.size() * 8, hipMemcpyDeviceToHost);
+                    if (FILE *f = fopen(dump, "w")) { for (auto v : lv) fprintf(f, "%llu\n", v); fclose(f); }
+                }
+                (void)hipMemset(dbg, 0, 128 + 8 * 4096);
             } else if (ub_dev) {
                 if (idx->metric == LEMON_METRIC_L2) hipLaunchKernelGGL((k_scan_f32<true, false, true>), dim3(grid), dim3(NT), 0, stream, p);
                 else hipLaunchKernelGGL((k_scan_f32<false, false, true>), dim3(grid), dim3(NT), 0, stream, p);
