@@ -51,6 +51,21 @@ def pmc_traffic(kernel_substr):
     return (2.0 * mean(acc["FETCH_SIZE"]) + mean(acc["WRITE_SIZE"])) * 1024.0, os.path.relpath(path, ROOT)
 
 
+def sustained_bf16_peak():
+    """(TFLOP/s, source): what bf16 MFMAs on RANDOM register operands sustain on this board with no memory traffic at all
+    (tools/micro/mfma_peak.hip; the board's power management lowers the shader clock), read from the COMMITTED output of
+    that micro-benchmark -- context for the bf16 scan's `frac` of the data-sheet peak, not a measurement of this run."""
+    import re
+    path = os.path.join(ROOT, "profiles", "r2", "micro_mfma_peak.txt")
+    if not os.path.exists(path):
+        return None, None
+    for ln in open(path):
+        m = re.search(r"bf16 32x32x16 sustained, random\s+operands.*?([0-9.]+) TFLOP/s", ln)
+        if m:
+            return float(m.group(1)), os.path.relpath(path, ROOT)
+    return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -404,6 +419,11 @@ def bench_knn(args, world, rank, dev):
                                         "note": "MODEL bytes (one DB stream per 128-query panel, SURVEY 8d), not measured "
                                                 "traffic: the kernel is MFMA-bound, `frac` above is the binding fraction"}},
     }
+    if not f32:
+        sus, src = sustained_bf16_peak()
+        if sus:
+            line["roofline"]["peak_sustained_random_operands"] = {"value": sus, "unit": "TFLOP/s", "source": src,
+                                                                  "frac": prof["algo_flops"] / sec / 1e12 / sus}
     if cpu is not None:
         line["cpu_baseline"] = cpu
     return line
