@@ -436,17 +436,27 @@ __device__ __forceinline__ void qs_filter_tile(f32x16 a, float th, unsigned jb, 
     const float m0 = max3(max3(a[0], a[1], a[2]), a[3], a[3]), m1 = max3(max3(a[4], a[5], a[6]), a[7], a[7]);
     const float m2 = max3(max3(a[8], a[9], a[10]), a[11], a[11]), m3 = max3(max3(a[12], a[13], a[14]), a[15], a[15]);
     const float m = max3(max3(m0, m1, m2), m3, m3);      // 10 x v_max3_f32 (fmaxf: 19 instructions)
-    // (survivors are rare here -- a few per wave and tile -- so nested per-lane tests with their early outs beat the
-    // fp32 scan's "16 ballots + scalar branches per tile" form: measured 164 vs 177 ms at 262 144^2 x 768)
-    if (m > th) {                                   // some lane of the wave has a survivor in this tile
-        const float mq[4] = {m0, m1, m2, m3};
+    // Survivors are rare (3-13 per wave and tile), and what the tests cost is not their instruction count but their
+    // DEPENDENT hops: a per-lane `if` is v_cmp -> s_and_saveexec -> s_cbranch_execz, each waiting for the one before
+    // (~17 such chains per entered tile in the nested per-lane form).  So the compares of a level are issued together as
+    // wave ballots and each level is guarded by SCALAR branches on them: quads first, the four elements only of a quad
+    // some lane passes in, the append itself under the per-lane test.  Three hops instead of seventeen.
+    const u64 bq0 = __ballot(m0 > th), bq1 = __ballot(m1 > th), bq2 = __ballot(m2 > th), bq3 = __ballot(m3 > th);
+    if ((bq0 | bq1 | bq2 | bq3) == 0) return;          // wave-uniform (m is what the quads' maxima fold to)
+    (void)m;
+    const u64 bq[4] = {bq0, bq1, bq2, bq3};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (mq[g] > th) {                       // ... in this quad of rows
+    for (int g = 0; g < 4; ++g) {
+        if (bq[g]) {                                    // scalar branch
+            u64 be[4];
 #pragma unroll
-                for (int e = 4 * g; e < 4 * g + 4; ++e) {
+            for (int i = 0; i < 4; ++i) be[i] = __ballot(a[4 * g + i] > th);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (be[i]) {                            // scalar branch
+                    const int e = 4 * g + i;
                     const unsigned j = jb + (e & 3) + 8 * (e >> 2);
-                    if (a[e] > th && j < n) {
+                    if (a[e] > th) {                    // (rows >= n: masked to -inf by the caller, last tile only)
                         // approximate key: for L2 the clamped -D~ = min(0, proxy - |q|^2)
                         const float s = l2 ? fminf(0.0f, a[e] - qn) : a[e];
                         *reinterpret_cast<u64 *>(panel_bytes + (my_off + 8u * (unsigned)ccnt)) = lemon_make_key(s, j);
@@ -737,6 +747,16 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
                 // (diagnostic, results invalid: LEMON_ABLATE bit 2 = nothing passes the filter, i.e. accumulator read-out
                 // and maximum tree only: 97.0 ms at 262 144^2 x 768 against 91.2 with no epilogue at all and 145.8 whole --
                 // the appends and compactions, not the read-out, are what the epilogue costs)
+                if ((unsigned)(t_begin + jl + 1) * BX > (unsigned)p.b.n) {   // last tile of the database (uniform): padding rows never pass
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const unsigned j = jb + (e & 3) + 8 * (e >> 2);
+                        if (j >= (unsigned)p.b.n) acc0[e] = -INFINITY;
+                        if (j + 32 >= (unsigned)p.b.n) acc1[e] = -INFINITY;
+                        if (j + 64 >= (unsigned)p.b.n) acc2[e] = -INFINITY;
+                        if (j + 96 >= (unsigned)p.b.n) acc3[e] = -INFINITY;
+                    }
+                }
                 const float th_f = (p.ablate & 4) ? INFINITY : th;
                 qs_filter_tile<l2>(acc0, th_f, jb, my_qn, p.b.xnorm, (unsigned)p.b.n, ccnt, panel_bytes, my_off);
                 qs_filter_tile<l2>(acc1, th_f, jb + 32, my_qn, p.b.xnorm, (unsigned)p.b.n, ccnt, panel_bytes, my_off);
