@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -151,6 +152,129 @@ __global__ __launch_bounds__(576) void k_attention_hd64(const float *__restrict_
     }
 }
 
+
+// Short sequences (L <= 64: the 50 tokens of a ViT-B/32 image, the 8..64 tokens of a prompt batch): ONE LDS buffer of
+// 32*TJ rows serves K first and V afterwards -- all score tiles of a query fit in registers, so the softmax is computed
+// on the complete row (no running rescale) and K is dead by the time V is needed.  Half the LDS of the general kernel
+// (17 KB at TJ = 2): the CU holds six workgroups instead of four, which is what this latency-bound shape was short of
+// (MFMA pipe busy 0.40, 3.6 TB/s with four).
+template <int TJ>
+__global__ __launch_bounds__(64 * TJ) void k_attention_hd64_short(const float *__restrict__ qkv, int L, int H, int causal,
+                                                                  float *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float sKV[32 * TJ * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int64_t b = blockIdx.x / H;
+    const int head = blockIdx.x % H;
+    const int64_t tok_stride = (int64_t)3 * H * HD;
+    const float *base = qkv + b * L * tok_stride + head * HD;
+    float4 kreg[8], vreg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int id = tid + i * 64 * TJ, r = id >> 4, c = id & 15;
+        kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < L) kreg[i] = *reinterpret_cast<const float4 *>(base + (int64_t)r * tok_stride + 4 * c + H * HD);
+    }
+    const int qi = 32 * wave + l31;
+    const int qrow = qi < L ? qi : L - 1;
+    float q[32];
+    {
+        const float *src = base + (int64_t)qrow * tok_stride + 32 * h;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 t = *reinterpret_cast<const float4 *>(src + 4 * u);
+            q[4 * u] = t.x; q[4 * u + 1] = t.y; q[4 * u + 2] = t.z; q[4 * u + 3] = t.w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int id = tid + i * 64 * TJ, r = id >> 4, c = id & 15;
+        vreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < L) vreg[i] = *reinterpret_cast<const float4 *>(base + (int64_t)r * tok_stride + 4 * c + 2 * H * HD);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int id = tid + i * 64 * TJ, r = id >> 4, c = id & 15;
+        *reinterpret_cast<float4 *>(&sKV[r * PITCH + 4 * c]) = kreg[i];
+    }
+    __syncthreads();
+
+    // all score tiles of this lane's query: S^T tile tj = K[32tj.., :] Q^T (two accumulators per tile: even / odd k-steps,
+    // so that consecutive MFMAs do not wait for each other)
+    f32x16 s[TJ];
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj) {
+        f32x16 sa, sb;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { sa[e] = 0.f; sb[e] = 0.f; }
+        const float *krow = &sKV[(32 * tj + l31) * PITCH + 32 * h];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 k4 = *reinterpret_cast<const float4 *>(krow + 4 * u);
+            sa = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, q[4 * u], sa, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, q[4 * u + 1], sb, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, q[4 * u + 2], sa, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, q[4 * u + 3], sb, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[tj][e] = sa[e] + sb[e];
+    }
+    // mask (padding keys, causal), row maximum, exponentials, row sum
+    const float c_exp = 0.125f * 1.44269504088896340736f;   // 1/sqrt(64) * log2(e)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int j = 32 * tj + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const bool ok = j < L && (!causal || j <= qi);
+            s[tj][e] = ok ? s[tj][e] : -INFINITY;
+            mx = fmaxf(mx, s[tj][e]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));           // finite: key 0 is visible to every query
+    float lsum = 0.f;
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            s[tj][e] = exp2f((s[tj][e] - mx) * c_exp);
+            lsum += s[tj][e];
+        }
+    lsum += __shfl_xor(lsum, 32);
+
+    __syncthreads();                                // every wave is done with K
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int id = tid + i * 64 * TJ, r = id >> 4, c = id & 15;
+        *reinterpret_cast<float4 *>(&sKV[r * PITCH + 4 * c]) = vreg[i];
+    }
+    __syncthreads();
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const float *vrow = &sKV[(32 * tj + (m & 3) + 8 * (m >> 2) + 4 * h) * PITCH + l31];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], s[tj][m], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], s[tj][m], o1, 0, 0, 0);
+        }
+    if (qi < L) {
+        const float inv = 1.0f / lsum;
+        float *dst = out + ((b * L + qi) * H + head) * HD;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = 8 * g + 4 * h;
+            *reinterpret_cast<float4 *>(dst + c0) =
+                make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            *reinterpret_cast<float4 *>(dst + 32 + c0) =
+                make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int lemon_attention_f32(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
@@ -163,6 +287,15 @@ extern "C" int lemon_attention_f32(const float *qkv_dev, int64_t batch, int seq_
     LEMON_REQUIRE((((uintptr_t)qkv_dev) & 15) == 0 && (((uintptr_t)out_dev) & 15) == 0, "16-byte alignment");
     LEMON_REQUIRE(batch * heads < (int64_t)1 << 31, "batch * heads < 2^31");
     const int tj = (seq_len + 31) / 32;
+    static const bool short_off = [] { const char *e = getenv("LEMON_ATTN_SHORT"); return e && e[0] == '0'; }();   // tuning knob
+    if (tj <= 2 && !short_off) {
+        if (tj == 1) hipLaunchKernelGGL(k_attention_hd64_short<1>, dim3((unsigned)(batch * heads)), dim3(64), 0, (hipStream_t)stream,
+                                        qkv_dev, seq_len, heads, causal, out_dev);
+        else hipLaunchKernelGGL(k_attention_hd64_short<2>, dim3((unsigned)(batch * heads)), dim3(128), 0, (hipStream_t)stream,
+                                qkv_dev, seq_len, heads, causal, out_dev);
+        LEMON_HIP_CHECK(hipGetLastError());
+        return LEMON_OK;
+    }
     const size_t lds = (size_t)2 * 32 * tj * PITCH * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
