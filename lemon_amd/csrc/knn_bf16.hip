@@ -29,6 +29,7 @@ namespace {
 
 constexpr int BKH = 64;   // bf16 k-slice per LDS stage (128 B rows, like fp32 BK=32)
 constexpr int CAPH = 512; // candidate slots per query (approximate keys): 8 per lane in a light compaction
+static_assert(CAPH == PAIR_CAP, "append_slot() clamps to the pair-list half capacity");
 constexpr int REFRESH = 96; // light-compact a list after this many new candidates: the admission bound then
                             // tracks the running k-th best closely (appends ~ k ln(N/k) instead of 3-4x that)
 
@@ -88,9 +89,13 @@ struct ScanParamsH {
     // HBM; per-query state (list length, admission bound) lives in `state` between launches
     int chunk_t0, chunk_t1, first_chunk, last_chunk;
     float *state;              // [grid*256 lanes][4]: {half-list count, last compacted length, thr_key, -}
-    int ablate;                // diagnostics only (LEMON_ABLATE): 1 = skip the filter epilogue, 4 = nothing passes the filter,
-                               // 8 (phase-stamped build) = the tile-end wait for the DMA is booked under "maintain", so that
-                               // "sync" is the barrier alone (measured: 2.6 % and 8.7 % of wave 0's cycles)
+    int ablate;                // diagnostics only (LEMON_ABLATE): 1 = skip the filter epilogue AND maintenance (nothing is
+                               // appended), 4 = nothing passes the filter, 8 (phase-stamped build) = the tile-end wait for
+                               // the DMA is booked under "maintain", so that "sync" is the barrier alone (measured: 2.6 %
+                               // and 8.7 % of wave 0's cycles).  There is deliberately NO "appends without maintenance"
+                               // mode: maintenance is what keeps the 256-entry half-lists in bounds (a working-tree
+                               // diagnostic of round 2 had one as value 2 and faulted the GPU; lemon_parse_ablate now
+                               // refuses unknown bits and append_slot() clamps the store)
     unsigned long long *phase_dbg;   // diagnostic builds only: [grid][4] cycle sums (loop, epilogue, sync, maintain)
 };
 
@@ -269,8 +274,8 @@ __device__ __forceinline__ void epilogue_tile_h(f32x16 &acc, int rtile, u32 j, b
             }
             if (jvalid && s > th[e]) {
                 const int row = rbase + e;
-                const int slot = atomicAdd(&s_cnt[row], 1);
-                cand_panel[(int64_t)row * CAPH + slot] = lemon_make_key(s, j);
+                const int slot = atomicAdd(&s_cnt[row], 1);     // (<= CAPH - 1: maintenance keeps c <= CAPH - BX before a tile)
+                cand_panel[(int64_t)row * CAPH + (slot < CAPH ? slot : CAPH - 1)] = lemon_make_key(s, j);
             }
         }
     }
@@ -459,7 +464,7 @@ __device__ __forceinline__ void qs_filter_tile(f32x16 a, float th, unsigned jb, 
                     if (a[e] > th) {                    // (rows >= n: masked to -inf by the caller, last tile only)
                         // approximate key: for L2 the clamped -D~ = min(0, proxy - |q|^2)
                         const float s = l2 ? fminf(0.0f, a[e] - qn) : a[e];
-                        *reinterpret_cast<u64 *>(panel_bytes + (my_off + 8u * (unsigned)ccnt)) = lemon_make_key(s, j);
+                        *reinterpret_cast<u64 *>(panel_bytes + (my_off + 8u * append_slot(ccnt))) = lemon_make_key(s, j);
                         ++ccnt;
                     }
                 }
@@ -926,7 +931,8 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
         p.qh = qh; p.xh = reinterpret_cast<const __bf16 *>(idx->xh);
         p.q = q_dev + c0 * d; p.x = idx->x; p.qres2 = qres2; p.qhn2 = qhn2; p.xstat = idx->xn2max_dev;
         p.d = d; p.dpad_h = dpad_h; p.phase_dbg = nullptr;
-        p.ablate = getenv("LEMON_ABLATE") ? atoi(getenv("LEMON_ABLATE")) : 0;
+        rc = lemon_parse_ablate("k_scan_bf16_qs", 1 | 4 | 8, &p.ablate);   // bit 1 (value 2) does not exist: see ScanParamsH
+        if (rc) return rc;
         static const int refresh = [] { const char *e = getenv("LEMON_REFRESH"); return e && atoi(e) > 0 ? atoi(e) : REFRESH; }();
         p.b.stale = refresh;                  // new candidates per query that trigger a light compaction (tuning knob)
         const unsigned grid = (unsigned)(panels * splits);

@@ -285,6 +285,14 @@ __device__ __forceinline__ void write_out_row(const ScanParams &p, int split, in
 
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
+// slot of the next append inside a lane's half-list.  The scans keep cnt <= PAIR_CAP/2 - BX/2 before a tile (the `full`
+// trigger) and a tile adds at most BX/2 entries per lane, so cnt < PAIR_CAP/2 holds at every append; the clamp makes a
+// broken invariant (a diagnostic build that skips maintenance did that once: DESIGN.md "The recorded GPU fault") overwrite
+// the half-list's last slot instead of leaving the candidate workspace.
+__device__ __forceinline__ unsigned append_slot(int cnt) {
+    return (unsigned)cnt < (unsigned)(PAIR_CAP / 2 - 1) ? (unsigned)cnt : (unsigned)(PAIR_CAP / 2 - 1);
+}
+
 }  // namespace lemon_knn
 
 // host helpers implemented in knn_f32.hip
@@ -295,3 +303,6 @@ int lemon_fill_empty(float *D, int64_t *I, int64_t total, int metric, hipStream_
 void lemon_plan_splits(int panels, int n_tiles, int *splits, int *tiles_per_split);
 int lemon_ensure_search_ws(lemon_index_t *idx, int64_t nq_pad, int splits, int64_t n_wg, int qp_row_bytes, int cand_cap,
                            hipStream_t stream);
+// LEMON_ABLATE (diagnostics): the value must be a combination of the bits `allowed` names for this kernel, anything else
+// is refused (LEMON_E_INVALID) instead of silently selecting whatever code a stray bit happens to reach
+int lemon_parse_ablate(const char *kernel, int allowed, int *out);

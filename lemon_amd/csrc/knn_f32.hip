@@ -87,7 +87,7 @@ __device__ __forceinline__ void f32_filter_tile(f32x16 a, float th, unsigned jb,
                 if (a[e] > th) {                         // (rows >= n: masked to -inf by the caller, last tile only)
                     const u64 key = lemon_make_key(a[e], j);
                     if (!UB || key < ub) {
-                        *reinterpret_cast<u64 *>(panel_bytes + (my_off + 8u * (unsigned)ccnt)) = key;
+                        *reinterpret_cast<u64 *>(panel_bytes + (my_off + 8u * append_slot(ccnt))) = key;
                         ++ccnt;
                     }
                 }
@@ -514,6 +514,20 @@ int lemon_launch_merge(const u64 *part, int splits, const int *pieces, int64_t n
     return LEMON_OK;
 }
 
+int lemon_parse_ablate(const char *kernel, int allowed, int *out) {
+    *out = 0;
+    const char *e = getenv("LEMON_ABLATE");
+    if (!e || !*e) return LEMON_OK;
+    char *end = nullptr;
+    const long v = strtol(e, &end, 0);
+    if (end == e || *end != '\0' || v < 0 || (v & ~(long)allowed)) {
+        lemon_set_error("LEMON_ABLATE=%s: %s accepts combinations of the bits 0x%x only", e, kernel, allowed);
+        return LEMON_E_INVALID;
+    }
+    *out = (int)v;
+    return LEMON_OK;
+}
+
 int lemon_fill_empty(float *D, int64_t *I, int64_t total, int metric, hipStream_t stream) {
     if (total <= 0) return LEMON_OK;
     hipLaunchKernelGGL(k_fill_empty, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, D, I, total, metric);
@@ -852,7 +866,10 @@ static int lemon_search_f32_pass(lemon_index_t *idx, const float *q_dev, int64_t
             p.th_pub = reinterpret_cast<unsigned *>(idx->ws_qnorm + 2 * idx->ws_q);
             LEMON_HIP_CHECK(hipMemsetAsync(p.th_pub, 0, (size_t)nq_pad * sizeof(unsigned), stream));
         }
-        p.ablate = getenv("LEMON_ABLATE") ? atoi(getenv("LEMON_ABLATE")) : 0;   // diagnostic instantiation only
+        // diagnostic instantiation only (LEMON_PHASE_PROF): 1 no operand loads, 2 no barriers, 4 filter off after 5 tiles,
+        // 8 appends forgotten, 16 bare read-out, 32 / 128 instruction-class probes.  None of them skips maintenance.
+        rc = lemon_parse_ablate("k_scan_f32", 1 | 2 | 4 | 8 | 16 | 32 | 128, &p.ablate);
+        if (rc) return rc;
         static const int stale = [] { const char *e = getenv("LEMON_STALE"); return e && atoi(e) > 0 ? atoi(e) : 96; }();
         p.stale = stale;
         // fair-share turns (see k_scan_f32): about eight turns per launch, between 82 us and 5.2 ms each -- longer turns

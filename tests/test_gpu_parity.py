@@ -323,6 +323,39 @@ def test_full_size_1m_self_join_bf16_rows_equal_f32_scan(hip):
     assert torch.equal(I[sub], Ir) and torch.equal(D[sub], Dr)
 
 
+@pytest.mark.parametrize("algo,bad", [(BF16, "2"), (BF16, "16"), (BF16, "junk"), (1, "64"), (1, "-1")])
+def test_unknown_ablate_bits_are_refused_before_any_launch(hip, monkeypatch, algo, bad):
+    # round 2's recorded GPU fault: a working-tree diagnostic skipped list maintenance on LEMON_ABLATE=2 and the
+    # lane-private half-lists (256 entries) ran 1 MiB past the candidate workspace.  Diagnostic knobs are now
+    # validated (no kernel is launched on an unknown bit) and the append slot is clamped (knn_common.hpp append_slot)
+    from lemon_amd._lib import LemonHipError
+    rng = np.random.default_rng(3)
+    X, Q = unit_rows(rng, 3000, 64), unit_rows(rng, 200, 64)
+    idx = hip.IndexFlatIP(64)
+    idx.set_algo(algo)
+    idx.add(cu(X))
+    monkeypatch.setenv("LEMON_ABLATE", bad)
+    with pytest.raises(LemonHipError, match="LEMON_ABLATE"):
+        idx.search(cu(Q), 10)
+    monkeypatch.delenv("LEMON_ABLATE")
+    D, I = idx.search(cu(Q), 10)                      # the index is still usable afterwards
+    assert I.shape == (200, 10) and int(I.min()) >= 0
+
+
+@pytest.mark.parametrize("algo", [1, BF16])
+def test_half_lists_at_capacity_ascending_scores_every_row_admitted(hip, oracle, algo):
+    # the append-pressure worst case: scores ascend with the row index, so EVERY row beats the running k-th best and each
+    # lane appends its full 64 entries per tile -- the half-lists sit exactly at their `full` bound (192 + 64 = 256)
+    # tile after tile; D / I stay bit-exact and nothing is written beyond a list
+    n, d, k = 128 * 40, 64, 51
+    rng = np.random.default_rng(5)
+    base = unit_rows(rng, 1, d)[0]
+    X = (base[None, :] * np.linspace(0.2, 1.0, n, dtype=np.float32)[:, None]).astype(np.float32)
+    Q = (base[None, :] * np.linspace(0.5, 1.5, 300, dtype=np.float32)[:, None]).astype(np.float32)
+    D, I, _ = _search(hip, "ip", X, Q, k, algo=algo)
+    _assert_knn_equal((D, I), oracle.knn("ip", X, Q, k))
+
+
 def test_neighbors_record_bf16_algo(hip, oracle):
     s = planted(seed=1, n_tr=3000, n_q=300, d=64, C=16)
     img_tr, txt_tr, _, noisy_tr = s["train"]
