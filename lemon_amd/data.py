@@ -270,13 +270,13 @@ def get_dataset(name, data_seed, percent_flips=0.40, flip_type="real", data_root
             if os.path.exists(os.path.join(data_root, "pixels.npy")):
                 pixels = np.load(os.path.join(data_root, "pixels.npy"), mmap_mode="r")
                 assert len(pixels) == len(df), "pixels.npy must have one entry per frame row"
+        if pixels is not None:         # position in pixels.npy = position in the frame AS LOADED (before any row is dropped)
+            df = df.assign(_row=np.arange(len(df)))
         if "restval" in df.split:      # quirk kept: tests the Series INDEX
             df.loc[df.split == "restval", "split"] = "train"
         if name == "mimiccxr_caption":
             df = df[df.sentence.str.len() > 0]       # lib/datasets/utils.py:293
-        if pixels is not None:
-            df = df.assign(_row=np.arange(len(df)))
-        elif "path" not in df:
+        if pixels is None and "path" not in df:
             df["path"] = [os.path.join(data_root, *(p for p in (r.get("filepath", ""), r["filename"]) if p))
                           for _, r in df.iterrows()]
         out = []

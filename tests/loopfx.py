@@ -30,6 +30,7 @@ class LoopCase:
         self.discrete = "--use_discrete_for_text" in a
         self.normalize_d1 = "--normalize_d1" in a
         self.dataset = opt("--dataset", "cifar100")
+        self.ablation = opt("--ablation", "none")         # 'd1' zeroes the d_1 column of the reference's frame (run_lemon.py:316-317)
         self.is_caption = bool(self.fx["is_caption"])
         self.ssets = [str(s) for s in self.fx["ssets"]]
         self.n_train = int(self.fx["n_train"])
@@ -86,6 +87,8 @@ def assert_records_match(got, case, s, float_tol=1e-6):
     """Index sets bit-exact; D_n / D_m (search output, chain arithmetic on both sides) bit-exact; the quantities the
     reference computes with torch reductions (d_1, dists_*, dists_tr) within float_tol (north_star: scores 1e-4)."""
     exp, expI = case.expected(s), case.expected_I(s)
+    if "d1" in case.ablation:
+        got = dict(got, d_1=np.zeros_like(np.asarray(got["d_1"])))
     for key in ("I_n", "I_m"):
         if key in got:
             assert np.array_equal(np.asarray(got[key]), expI[key]), f"{case.name}/{s}/{key}"

@@ -69,6 +69,24 @@ def install(case, monkeypatch, tmp_path):
                            "nouns_int": unflat(fx["frame_noun_flat"], fx["frame_noun_len"])}, index=fx["frame_index"])
         df.to_pickle(os.path.join(root, "multimodal_mislabel_split.pkl"))
         np.save(os.path.join(root, "pixels.npy"), fx["img_all"])
+    elif case.dataset in ("stanford_cars", "mini_imagenet"):
+        # the CSV + image files the reference's get_large_scale_dataset / LargeScaleDataset read (lib/datasets/utils.py:325-347,
+        # dataloader.py:113-133): lossless PNGs whose pixel bytes carry the planted vector, decoded by the same stand-in
+        # transform the reference run was given
+        from PIL import Image
+        d = int(fx["d"])
+        for vec, fn in zip(fx["img_all"], fx["csv_filename"]):
+            path = os.path.join(root, str(fn))
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            raw = np.asarray(vec, np.float32).tobytes()
+            w = -(-len(raw) // 12)
+            buf = np.zeros(4 * w * 3, np.uint8)
+            buf[:len(raw)] = np.frombuffer(raw, np.uint8)
+            Image.fromarray(buf.reshape(4, w, 3), "RGB").save(path, format="PNG")
+        pd.DataFrame({"filename": fx["csv_filename"].astype(object), "label": fx["csv_label"],
+                      "is_clean": fx["csv_is_clean"].astype(bool)}).to_csv(os.path.join(root, "multimodal_mislabel_split.csv"), index=False)
+        monkeypatch.setattr(data, "generic_transform", lambda img, size=224: torch.from_numpy(
+            np.frombuffer(np.asarray(img, np.uint8).tobytes()[:4 * d], np.float32).copy()))
     else:
         monkeypatch.setattr(data, "_read_cifar", lambda r, n: (fx["img_all"], fx["y_all"]))
     return ["--data_root", root, "--clip_path", "planted"]

@@ -23,6 +23,10 @@ What is a stand-in (modules absent from this image, or weights/data that need a 
   netcal, lib.datasets.clustering   unused on this path.
   DataLoader             num_workers forced to 0 (same batches, no fork).
   caption data           a synthetic multimodal_mislabel_split.pkl under a temp PATHS['mscoco'].
+  stanford_cars          a synthetic multimodal_mislabel_split.csv + REAL image files (lossless PNG, a few pixels each) under
+                         a temp PATHS['stanford_cars']: get_large_scale_dataset (lib/datasets/utils.py:325-347) and
+                         LargeScaleDataset incl. its PIL Image.open / `real_label = noisy - 1` (lib/datasets/dataloader.py:
+                         113-133) run for real; generic_transform = "the planted vector whose float32 bytes ARE the pixels".
 
 Outputs are DATA (inputs + expected outputs); no reference source text is stored.
 Run:  python tools/make_golden_loop.py [--only NAME]
@@ -182,6 +186,35 @@ def planted_caption_frame(seed, n, d, n_cat=12):
     return df, img, uniq, sid, txt_table
 
 
+def vec_to_png(vec, path):
+    """float32 vector -> lossless RGB PNG whose raw pixel bytes start with the vector's bytes (d = 32: 128 of 132 bytes)."""
+    from PIL import Image
+    raw = np.asarray(vec, np.float32).tobytes()
+    w = -(-len(raw) // 12)
+    buf = np.zeros(4 * w * 3, np.uint8)
+    buf[:len(raw)] = np.frombuffer(raw, np.uint8)
+    Image.fromarray(buf.reshape(4, w, 3), "RGB").save(path, format="PNG")
+
+
+def png_to_vec(img, d):
+    return np.frombuffer(np.asarray(img, np.uint8).tobytes()[:4 * d], np.float32).copy()
+
+
+def planted_large_scale(seed, n, C, d):
+    """multimodal_mislabel_split.csv of a 'real noise' dataset: filename, label (the possibly wrong web label), is_clean."""
+    rs = np.random.RandomState(seed)
+    proto = rs.randn(C, d).astype(np.float32)
+    g_img, g_txt = modality_gap(rs, d)
+    true = rs.randint(0, C, n).astype(np.int64)
+    is_clean = rs.rand(n) > 0.3
+    label = np.where(is_clean, true, (true + rs.randint(1, C, n)) % C).astype(np.int64)
+    scale = rs.uniform(0.5, 3.0, (n, 1)).astype(np.float32)
+    img = ((proto[true] + 0.5 * rs.randn(n, d) + g_img) * scale).astype(np.float32)
+    txt_table = ((proto + 0.3 * rs.randn(C, d) + g_txt) * rs.uniform(0.5, 3.0, (C, 1))).astype(np.float32)
+    files = np.array([f"car_images/{i:05d}.png" for i in range(n)])
+    return img, label, is_clean, files, txt_table
+
+
 # ------------------------------------------------------------------------------ stand-in modules
 class PlantedCLIP(torch.nn.Module):
     def __init__(self, txt_table, img_log=None):
@@ -298,6 +331,21 @@ def run_case(name, cfg, dsu, state, workdir):
                   frame_noun_flat=np.array([c for row in df["nouns_int"] for c in row], np.int64),
                   frame_noun_len=np.array([len(r) for r in df["nouns_int"]], np.int64),
                   img_all=img, captions=np.array(uniq), txt_table=txt_table)
+    elif cfg["dataset"] in ("stanford_cars", "mini_imagenet"):
+        labels = np.array(getattr(dsu, cfg["dataset"] + "_labels"))
+        img, label, is_clean, files, txt_table = planted_large_scale(cfg["seed"], cfg["n"], len(labels), d)
+        root = os.path.join(workdir, name + "_" + cfg["dataset"])
+        os.makedirs(os.path.join(root, "car_images"), exist_ok=True)
+        for v, f in zip(img, files):
+            vec_to_png(v, os.path.join(root, f))
+        pd.DataFrame({"filename": files, "label": label, "is_clean": is_clean}).to_csv(
+            os.path.join(root, "multimodal_mislabel_split.csv"), index=False)
+        dsu.PATHS[cfg["dataset"]] = root
+        dsu.generic_transform = lambda im: torch.from_numpy(png_to_vec(im, d))      # (restored below)
+        prefix = "A photo of a "
+        state.update(txt_table=txt_table, prompt_ids={prefix + l: i for i, l in enumerate(labels)})
+        fx.update(img_all=img, csv_filename=files.astype(str), csv_label=label, csv_is_clean=is_clean.astype(np.int64),
+                  txt_table=txt_table, prefix=np.array(prefix))
     else:
         C = {"cifar10": 10, "cifar100": 100}[cfg["dataset"]]
         img, y, txt_table = planted_class_data(cfg["seed"], cfg["n"], C, d)
@@ -326,6 +374,7 @@ def run_case(name, cfg, dsu, state, workdir):
                 with contextlib.suppress(Exception):
                     f.close()
         os.chdir(old[3])
+        dsu.generic_transform = dsu.transform
 
     df = g["df"]
     fx["train_indices_in_compr"] = np.asarray(g["train_indices_in_compr"], np.int64)
@@ -363,7 +412,7 @@ def run_case(name, cfg, dsu, state, workdir):
         fx[f"{sname}_is_mislabel"] = sub["is_mislabel"].values.astype(np.int64)
         fx[f"{sname}_noisy_text"] = sub["noisy_label_text"].values.astype(str)
         fx[f"{sname}_clean_text"] = sub["actual_label_text"].values.astype(str)
-        if not is_caption:
+        if not is_caption:      # (LargeScaleDataset yields numpy ints: run_lemon.py:291-307 stores them as they come)
             fx[f"{sname}_noisy"] = np.array([int(v) for v in sub["noisy_label"]], np.int64)
             fx[f"{sname}_clean"] = np.array([int(v) for v in sub["actual_label"]], np.int64)
     assert pos["img"] == len(per["img"]) and pos["txt"] == len(per["txt"])
@@ -488,6 +537,15 @@ CASES = {
     "c10_cos_k5_openclip_branch": dict(dataset="cifar10", n=600, d=32, seed=20,
                                        argv=["--dataset", "cifar10", "--noise_type", "asymmetric", "--knn_k", "5",
                                              "--clip_model", "cc3m_clip_from_scratch"] + SKIP),
+    # the remaining ablation branches of run_lemon.py:341-384, full protocol (hyper-parameter search with force_zero /
+    # force_one, d_1 zeroed for 'd1')
+    **{f"c10_cos_k5_abl_{a}": dict(dataset="cifar10", n=500, d=32, seed=40 + i,
+                                   argv=["--dataset", "cifar10", "--noise_type", "asymmetric", "--knn_k", "5", "--ablation", a])
+       for i, a in enumerate(("d1", "tau_1_2", "beta", "tau_1", "tau_2", "gamma"))},
+    # 'real noise' CSV dataset through the real get_large_scale_dataset / LargeScaleDataset + image files on disk
+    "cars_cos_k5_real": dict(dataset="stanford_cars", n=400, d=32, seed=50,
+                             argv=["--dataset", "stanford_cars", "--noise_type", "real", "--noise_level", "0", "--real_dataset",
+                                   "--knn_k", "5", "--data_seed", "1"]),
     # caption dataset (mostly unique text rows; DB = random subset smaller than train => mixed in_db)
     "coco_cos_k5_cat_subset": dict(dataset="mscoco", n=1000, d=32, seed=21,
                                    argv=["--dataset", "mscoco", "--noise_type", "cat", "--knn_k", "5",

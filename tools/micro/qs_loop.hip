@@ -194,5 +194,7 @@ int main(int argc, char **argv) {
     run<1 | 2 | 8>(g, out, cus, "tile through registers, all workgroups walk the same 300 tiles in step", 300, 1);
     run<1 | 2 | 8 | 16>(g, out, cus, "tile through registers, reads two ahead, all workgroups in step", 300, 1);
     run<1 | 2 | 4 | 16>(g, out, cus, "LDS-DMA, reads two ahead, all workgroups in step", 300, 1);
+    run<2 | 4>(g, out, cus, "no fragment reads: barrier + LDS-DMA, all workgroups in step", 300, 1);
+    run<2 | 4>(g, out, cus, "no fragment reads: barrier + LDS-DMA, every workgroup on the same 4 tiles", 4);
     return 0;
 }
