@@ -37,7 +37,7 @@ def pmc_traffic(kernel_substr):
     from inside the timed process, so this is NOT a measurement of the current run: the file it came from is
     reported next to it as `traffic_source`.  (None, None) when no summary is committed."""
     import csv
-    path = next((p for p in (os.path.join(ROOT, "profiles", r, "bench_default_pmc.csv") for r in ("r2", "r1"))
+    path = next((p for p in (os.path.join(ROOT, "profiles", r, "bench_default_pmc.csv") for r in ("r3", "r2", "r1"))
                  if os.path.exists(p)), None)
     if path is None:
         return None, None
@@ -56,8 +56,8 @@ def sustained_bf16_peak():
     (tools/micro/mfma_peak.hip; the board's power management lowers the shader clock), read from the COMMITTED output of
     that micro-benchmark -- context for the bf16 scan's `frac` of the data-sheet peak, not a measurement of this run."""
     import re
-    path = os.path.join(ROOT, "profiles", "r2", "micro_mfma_peak.txt")
-    if not os.path.exists(path):
+    path = next((p for p in (os.path.join(ROOT, "profiles", r, "micro_mfma_peak.txt") for r in ("r3", "r2")) if os.path.exists(p)), None)
+    if path is None:
         return None, None
     for ln in open(path):
         m = re.search(r"bf16 32x32x16 sustained, random\s+operands.*?([0-9.]+) TFLOP/s", ln)
@@ -92,7 +92,8 @@ def parse():
     ap.add_argument("--cpu_sample_queries", type=int, default=2048)
     ap.add_argument("--no_knn_1m", action="store_true",
                     help="skip the extra 1M x 768 self-join object (`knn_1m`) the N=1 headline line carries")
-    ap.add_argument("--knn_cpu_queries", type=int, default=4096, help="query slice of the kNN workload's CPU baseline")
+    ap.add_argument("--knn_cpu_queries", type=int, default=10000,
+                    help="query slice of the kNN workload's CPU baseline (BASELINE.md 3.5: 10 000 queries against the full DB)")
     return ap.parse_args()
 
 
@@ -111,9 +112,32 @@ def launch_ranks(args):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # rank 0's line is read by a thread (its pipe must be drained while we poll); every child is polled, and the first
+    # non-zero exit terminates the others -- a rank that dies at start-up must not leave the rest in the rendezvous
+    import threading
+    out = []
+    reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for i, pr in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = pr.poll()
+        if any(c not in (None, 0) for c in codes):
+            for i, pr in enumerate(procs):
+                if codes[i] is None:
+                    pr.terminate()
+            for i, pr in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = pr.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        codes[i] = pr.wait()
+            break
+        time.sleep(0.2)
+    reader.join(timeout=5)
+    sys.stdout.write(b"".join(out).decode())
     sys.stdout.flush()
     if any(codes):
         raise SystemExit(f"bench.py: rank exit codes {codes}")
@@ -195,7 +219,7 @@ def make_cifar_like(args, cfg, rank, dev):
 def bench_cifar(args, world, rank, dev):
     from lemon_amd import _lib
     from lemon_amd.clip import ClipConfig, LemonCLIP, encoder_flops
-    from lemon_amd.pipeline import Embedder, FIXED_HPARAMS, run_hot_path
+    from lemon_amd.pipeline import Embedder, FIXED_HPARAMS, GatherLog, run_hot_path
 
     cfg = ClipConfig.named(args.arch)
     model = LemonCLIP(cfg)                       # seeded random init (no checkpoints offline)
@@ -220,9 +244,12 @@ def bench_cifar(args, world, rank, dev):
         p = db.index_txt.profile_read()
         prof_txt["launches"] += p["launches"]; prof_txt["kernel_ms"] += p["kernel_ms"]
 
+    glog = GatherLog() if world > 1 else None   # HIP events around every all-gather of the timed region (read afterwards)
+
     def step(timers=None, events=False):
         return run_hot_path(emb, data, k=args.knn_k, dist_type=args.dist_type, hparams=FIXED_HPARAMS,
-                            world_size=world, rank=rank, algo=algo, timers=timers, profile_index=events)
+                            world_size=world, rank=rank, algo=algo, timers=timers, profile_index=events,
+                            gather_log=glog if events else None)
 
     for _ in range(args.warmup):
         step()
@@ -287,6 +314,8 @@ def bench_cifar(args, world, rank, dev):
             "hbm_scan_model": {"B": info["query_panel"], "achieved_GBs": prof["algo_bytes"] / sec / 1e9,
                                "peak_GBs": PEAK_HBM_GBS, "frac": prof["algo_bytes"] / sec / 1e9 / PEAK_HBM_GBS},
         }
+    if world > 1:
+        line["exchange"] = exchange_report(glog, world, info, db, args.steps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"], line["auroc_check"] = cpu_baseline_cifar(args, cfg, model, data, recs, db, n_scored)
     if world == 1 and not args.no_knn_1m:
@@ -299,6 +328,25 @@ def bench_cifar(args, world, rank, dev):
         line["knn_1m"] = {"workload": k1["config"]["workload"], "ms": k1["ms_per_step"], "scores_per_s": k1["value"],
                           "roofline": k1["roofline"], "cpu_baseline": k1.get("cpu_baseline")}
     return line
+
+
+def exchange_report(glog, world, info, db, steps):
+    """N > 1: what the DB all-gather cost on rank 0 (per step, per array: ms, algorithm and bus GB/s) and which scan every rank
+    ran against the gathered DB -- so that a scaling record explains itself."""
+    import torch.distributed as dist
+    from lemon_amd import _lib
+    names = {_lib.ALGO_F32_MFMA: "f32", _lib.ALGO_BF16_FILTER: "bf16"}
+    mine = {"img": names.get(info["algo"], str(info["algo"])),
+            "txt": names.get(db.index_txt.last_search_info()["algo"], "?"),
+            "txt_distinct_queries": int(db.index_txt.last_search_info()["nq_distinct"]), "db_rows": int(db.index_img.ntotal)}
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, mine)
+    rep = glog.summary() if glog is not None else {"allgather_ms": 0.0, "arrays": []}
+    rep["allgather_ms_per_step"] = rep["allgather_ms"] / max(steps, 1)
+    rep["backend"] = dist.get_backend()
+    rep["knn_algo_per_rank"] = per_rank
+    rep["note"] = "HIP events around all_gather_into_tensor on rank 0; busbw = algbw x (W-1)/W (nccl-tests convention)"
+    return rep
 
 
 def cpu_baseline_cifar(args, cfg, model, data, recs, db, n_scored):
@@ -351,6 +399,28 @@ def cpu_baseline_cifar(args, cfg, model, data, recs, db, n_scored):
     auroc = {"gpu": o.auroc(y, sgpu), "oracle": o.auroc(y, sref), "n": int(nqs),
              "max_abs_score_diff": float(np.abs(sgpu - sref).max()), "topk_sets_identical": same_sets,
              "per_sample_arrays_bit_exact": bool(arrays_equal)}
+    # The towers are random-init: image and text embeddings are not aligned, so d_1 is noise and the fixed-hparam score
+    # (d_1 + 5 d_n + 5 d_m) sits near chance.  What CAN carry signal is the neighbour structure (same-class images are
+    # planted near each other, the neighbours' prompts vote): the same parity check on score variants that weight it
+    # (SURVEY 8d metrics (i)-(iii)) -- GPU (lemon_score on the GPU records) against the oracle, each to 3 decimals.
+    from lemon_amd import ops
+    rec_gpu = {key: rv[key][:nqs] for key in ("d_1", "D_n", "dists_n", "dists_tr_n", "D_m", "dists_m", "dists_tr_m")}
+    zero_d1 = dict(rec_gpu, d_1=torch.zeros_like(rec_gpu["d_1"]))
+    ref_zero = dict(ref, d_1=np.zeros_like(ref["d_1"]))
+    variants = {
+        "d1_only (--ablation multimodal_baseline)": (dict(beta=0, gamma=0, tau_1_n=0, tau_2_n=0, tau_1_m=0, tau_2_m=0), rec_gpu, ref),
+        "beta=gamma=100": (dict(FIXED_HPARAMS, beta=100.0, gamma=100.0), rec_gpu, ref),
+        "neighbour terms only (--ablation d1, beta=gamma=1, tau=0)": (dict(beta=1, gamma=1, tau_1_n=0, tau_2_n=0, tau_1_m=0, tau_2_m=0), zero_d1, ref_zero),
+        "image-neighbour term only (d1 zeroed, beta=1)": (dict(beta=1, gamma=0, tau_1_n=0, tau_2_n=0, tau_1_m=0, tau_2_m=0), zero_d1, ref_zero),
+    }
+    auroc["variants"] = {}
+    for name, (hp, rg, rr) in variants.items():
+        sg = ops.lemon_score(rg, hp).cpu().numpy()
+        so = o.score(rr, hp)
+        ag, ao = o.auroc(y, sg), o.auroc(y, so)
+        auroc["variants"][name] = {"gpu": ag, "oracle": ao, "equal_to_3_decimals": bool(round(ag, 3) == round(ao, 3)),
+                                   "max_abs_score_diff": float(np.abs(sg - so).max())}
+    auroc["informative"] = bool(max(v["gpu"] for v in auroc["variants"].values()) > 0.6)
     base = {
         "value": 1.0 / per_sample, "unit": "scores/s", "cores": cores, "kind": "port",
         "sample": f"{ni} images through PIL generic_transform (time / {cores} cores) and {ni} image+prompt pairs through the same CLIP module on CPU fp32 (torch, {cores} threads) "
@@ -366,7 +436,7 @@ def bench_knn(args, world, rank, dev):
     Strong-scaled over ranks by query sharding (DB replicated after an all-gather of the shards)."""
     from lemon_amd import _lib, ops
     from lemon_amd.neighbors import LemonDB
-    from lemon_amd.pipeline import FIXED_HPARAMS, all_gather_rows, shard_bounds
+    from lemon_amd.pipeline import FIXED_HPARAMS, GatherLog, all_gather_rows, shard_bounds
     n, d, k = args.knn_n, args.knn_d, args.knn_k
     lo, hi = shard_bounds(n, world, rank)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
@@ -375,8 +445,12 @@ def bench_knn(args, world, rank, dev):
     algo = {"auto": None, "f32": _lib.ALGO_F32_MFMA, "bf16": _lib.ALGO_BF16_FILTER}[args.algo]
     prof = {"launches": 0, "kernel_ms": 0.0, "algo_flops": 0.0, "algo_bytes": 0.0}
 
+    glog = GatherLog() if world > 1 else None
+
     def step(events):
-        db = LemonDB(all_gather_rows(img, n), all_gather_rows(txt, n), args.dist_type, algo=algo)
+        lg = glog if events else None
+        db = LemonDB(all_gather_rows(img, n, log=lg, name="emb_img"), all_gather_rows(txt, n, log=lg, name="emb_txt"),
+                     args.dist_type, algo=algo)
         if events:
             db.index_img.set_profiling(True); db.index_txt.set_profiling(True)
         rec = db.neighbors(img, txt, k, drop_self=True, return_indices=False)
@@ -424,6 +498,8 @@ def bench_knn(args, world, rank, dev):
         if sus:
             line["roofline"]["peak_sustained_random_operands"] = {"value": sus, "unit": "TFLOP/s", "source": src,
                                                                   "frac": prof["algo_flops"] / sec / 1e12 / sus}
+    if world > 1:
+        line["exchange"] = exchange_report(glog, world, info, db, args.steps)
     if cpu is not None:
         line["cpu_baseline"] = cpu
     return line

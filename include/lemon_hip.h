@@ -179,7 +179,9 @@ const float *lemon_index_data(const lemon_index_t *idx);
 /* index.search(x, k): run_lemon.py:235-236; lib/baselines/discrepancy_baseline.py:166,209.
  * D_dev [nq,k] float32 and I_dev [nq,k] int64, best first (IP: descending inner product;
  * L2: ascending SQUARED distance max(0, |q|^2+|x|^2-2<q,x>)).  Slots beyond ntotal get
- * I=-1 and D=-FLT_MAX (IP) / +FLT_MAX (L2).  1 <= k <= LEMON_MAX_K.
+ * I=-1 and D=-FLT_MAX (IP) / +FLT_MAX (L2).  1 <= k <= LEMON_MAX_K_DEEP (2048; faiss itself has no limit): up to
+ * LEMON_MAX_K (64) one scan pass; deeper lists are produced LEMON_MAX_K at a time by key-bounded passes of the exact
+ * fp32 scan (each pass admits only rows ranked behind the previous pass's last result: same order, same tie rule).
  * Grows an internal workspace on first use of a larger (nq,k): that first call is not
  * graph-capturable; later calls with nq,k no larger only enqueue kernels.  With LEMON_ALGO_AUTO
  * (default) the first LARGE search (ntotal >= 65536, nq*ntotal >= 8e9, d <= 768) after an add()
@@ -191,8 +193,10 @@ int lemon_index_set_algo(lemon_index_t *idx, int algo);
  * q are grouped by content (64-bit hash + stable sort + full bitwise comparison) and, when at most half of them are
  * distinct, the search runs once per distinct row and its (D, I) lists are copied to every member -- exact, because a
  * query's result does not depend on the other queries.  Classification datasets make the text-side search of
- * run_lemon.py:236 a C-query problem this way.  Costs one stream synchronisation per search call (the group
- * count is read back). */
+ * run_lemon.py:236 a C-query problem this way.  Costs one stream synchronisation per search call of >= 1024
+ * queries (the group count is read back to size the reduced search) -- the one exception to "later calls only enqueue
+ * kernels" above; lemon_index_set_query_dedup(idx, 0) restores it.  lemon_neighbors applies de-duplication to its TEXT
+ * index only (image queries of the LEMoN loop are distinct), so its image-side search never synchronises. */
 int lemon_index_set_query_dedup(lemon_index_t *idx, int enabled);
 
 /* last search's dominant-kernel launch statistics (for bench/roofline bookkeeping) */
@@ -241,6 +245,10 @@ int lemon_debug_scan_plan(int panels, int n_tiles, int *grid, int *splits, int *
  * Outputs, caller-allocated: d1 [nq]; D_n, dists_n, dists_tr_n, D_m, dists_m, dists_tr_m [nq,k]
  * float32 with the sign convention of :269-270,285-286; I_n, I_m [nq,k] int64 (may be NULL).
  * Neighbours that do not exist (ntotal < k+drop_self) give I=-1 and NaN distances.
+ * Limit: k + drop_self <= LEMON_MAX_K (64), i.e. k <= 63 on the train split -- the faiss contract behind :235-236 has no
+ * such limit, but the loop's per-sample record is built from ONE scan pass here; the reference's own grids stop at
+ * k = 50 (+1) (experiments.py:86), and deeper lists are available from lemon_index_search (k <= 2048).  Larger k is
+ * refused with LEMON_E_INVALID, never truncated.  De-duplication of identical query rows is applied to idx_txt only.
  */
 int lemon_neighbors(lemon_index_t *idx_img, lemon_index_t *idx_txt, const float *dists_tr_dev,
                     const float *q_img_dev, const float *q_txt_dev, int64_t nq, int k,

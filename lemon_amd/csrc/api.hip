@@ -485,7 +485,14 @@ extern "C" int lemon_neighbors(lemon_index_t *idx_img, lemon_index_t *idx_txt, c
     }
     float *Dn = idx_img->ws_D, *Dm = idx_img->ws_D + nq * ks;
     int64_t *In = idx_img->ws_I, *Im = idx_img->ws_I + nq * ks;
+    // The image-side queries of the LEMoN loop are embeddings of distinct images: looking for duplicates among them costs a
+    // row hash, a radix sort and a host synchronisation per call for nothing, so de-duplication is applied to the TEXT side
+    // only (class datasets: C distinct prompts among nq queries).  A caller that does have duplicate image
+    // queries gets them folded by lemon_index_search on the handle itself.
+    const int img_dedup = idx_img->qdedup;
+    idx_img->qdedup = 0;
     int rc = lemon_search_internal(idx_img, q_img_dev, nq, ks, Dn, In, stream);   // run_lemon.py:235
+    idx_img->qdedup = img_dedup;
     if (rc) return rc;
     rc = lemon_search_internal(idx_txt, q_txt_dev, nq, ks, Dm, Im, stream);       // run_lemon.py:236
     if (rc) return rc;

@@ -115,16 +115,19 @@ int lemon_dedup_queries(lemon_index_t *idx, const float *q_dev, int64_t nq, hipS
     void *cub_tmp = p;
     const unsigned rows4 = (unsigned)((nq + 3) / 4);
     hipLaunchKernelGGL(k_row_hash, dim3(rows4), dim3(256), 0, stream, q_dev, nq, d, h, iota);
+    LEMON_HIP_CHECK(hipGetLastError());
     size_t tb = tmp;
     if (hipcub::DeviceRadixSort::SortPairs(cub_tmp, tb, h, hs, iota, order, (int)nq, 0, 64, stream) != hipSuccess) {
         lemon_set_error("hipcub radix sort failed"); return LEMON_E_HIP;
     }
     hipLaunchKernelGGL(k_group_heads, dim3(rows4), dim3(256), 0, stream, q_dev, d, nq, hs, order, head);
+    LEMON_HIP_CHECK(hipGetLastError());
     tb = tmp;
     if (hipcub::DeviceScan::InclusiveSum(cub_tmp, tb, head, scan, (int)nq, stream) != hipSuccess) {
         lemon_set_error("hipcub scan failed"); return LEMON_E_HIP;
     }
     hipLaunchKernelGGL(k_assign_groups, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, order, head, scan, nq, rep, group_of);
+    LEMON_HIP_CHECK(hipGetLastError());
     int U = 0;
     LEMON_HIP_CHECK(hipMemcpyAsync(&U, scan + (nq - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
     LEMON_HIP_CHECK(hipStreamSynchronize(stream));

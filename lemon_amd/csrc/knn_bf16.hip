@@ -460,8 +460,11 @@ __device__ __forceinline__ void qs_filter_tile(f32x16 a, float th, unsigned jb, 
             for (int i = 0; i < 4; ++i) {
                 if (be[i]) {                            // scalar branch
                     const int e = 4 * g + i;
-                    const unsigned j = jb + (e & 3) + 8 * (e >> 2);
                     if (a[e] > th) {                    // (rows >= n: masked to -inf by the caller, last tile only)
+                        // (the row number is made opaque here: otherwise hipcc strength-reduces the 64 `~j` key words of a
+                        // tile into registers it carries around the whole scan loop)
+                        unsigned j = jb + (e & 3) + 8 * (e >> 2);
+                        asm volatile("" : "+v"(j));
                         // approximate key: for L2 the clamped -D~ = min(0, proxy - |q|^2)
                         const float s = l2 ? fminf(0.0f, a[e] - qn) : a[e];
                         *reinterpret_cast<u64 *>(panel_bytes + (my_off + 8u * append_slot(ccnt))) = lemon_make_key(s, j);
@@ -590,7 +593,7 @@ __device__ __forceinline__ void qs_dma_stage(const float *__restrict__ src, int 
 // behind its MFMA.  "a" constraints pin both to AGPRs (64 acc + 192 query = all 256); the A
 // fragments, addresses and the epilogue live in VGPRs.  First step of a tile uses C = 0.
 __device__ __forceinline__ void mfma_qs_init(f32x16 &acc, bf16x8 a, const bf16x8 &bq) {
-    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "a"(bq));
+    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&a"(acc) : "v"(a), "a"(bq));
 }
 __device__ __forceinline__ void mfma_qs(f32x16 &acc, bf16x8 a, const bf16x8 &bq) {
     asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(bq));
@@ -843,6 +846,342 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
     }
 }
 
+
+// ======================================================================================
+// Q-stationary variant with TWO 32-query blocks per wave ("QS2").
+//
+// What bounded k_scan_bf16_qs's loop (tools/micro/qs_loop.hip, qs2_loop.hip; same box, random operands, all workgroups
+// walking one chunk in step): the delivery of the database tile.  The barrier + LDS-DMA skeleton WITHOUT any fragment
+// read or dependent MFMA wait already stops at 0.55 of the bf16 peak (full clock, zero or random data alike): a workgroup of
+// 128 queries needs a 16 KB slice per 16 MFMAs of a wave = 32 B/clk/CU at the MFMA peak, which the L2 -> LDS path does not
+// sustain, and every MFMA reads 1 KB of LDS on top.  Here a wave owns 64 queries: block 0 in the 192 AccVGPRs next to the
+// 64 accumulator registers (as before), block 1 in ARCHITECTURAL VGPRs -- the MFMA B operand may come from either half of
+// the unified file -- except its last PARK k-steps, which are parked in LDS (lane-linear, conflict-free ds_read_b128)
+// because 192 + ~90 working registers do not fit 256.  A database tile is 64 rows, every A-fragment read feeds two MFMAs,
+// a workgroup covers 256 queries: LDS bytes per MFMA and global -> LDS bytes per flop both halve at the same 32 MFMAs per
+// wave between barriers.  Loop replica: 1 269 -> 1 534 TFLOP/s (0.508 -> 0.614 of 2.5 PF; 0.635 -> 0.812 on all-zero data).
+// Candidate bookkeeping is the QS kernel's, per block: thresholds / counts in VGPRs, lane-private half-lists.
+// Tiles, splits and chunks are counted in 64-ROW units here (p.b.n_tiles, tiles_per_split, chunk_t0/t1).
+// ======================================================================================
+constexpr int RT2 = 64;        // database rows per tile
+constexpr int BQ2 = 256;       // queries per workgroup (64 per wave)
+
+// one MFMA with the accumulator tile in the AccVGPR (CV = false) or the architectural (CV = true) half of the register file
+// and the stationary B operand in AccVGPRs (BA) or VGPRs; INIT: C = 0
+template <bool CV, bool BA, bool INIT>
+__device__ __forceinline__ void mfma_x(f32x16 &acc, bf16x8 a, const bf16x8 &bq) {
+    if (INIT) {
+        // (early-clobber: a multi-pass MFMA may write its destination before it has read all of A / B, so the fresh tile
+        // must not share registers with the fragments -- hipcc would otherwise reuse a dying fragment's VGPRs for it)
+        if (CV) { if (BA) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(bq));
+                  else    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(bq)); }
+        else    { if (BA) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&a"(acc) : "v"(a), "a"(bq));
+                  else    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&a"(acc) : "v"(a), "v"(bq)); }
+    } else {
+        if (CV) { if (BA) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(bq));
+                  else    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(bq)); }
+        else    { if (BA) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(bq));
+                  else    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(bq)); }
+    }
+}
+
+// LDS-DMA of one 64-row x 128-B slice (8 KB): each wave moves 16 rows with two 1-KiB global_load_lds_dwordx4, issued by hand
+// as `SGPR base + 32-bit lane offset` (the builtin wants a 64-bit per-lane pointer: two VGPRs and a v_lshl_add_u64 per DMA;
+// the lane offsets below are constants of the kernel).  M0 = LDS destination of the wave's 1 KiB; nothing else in this
+// kernel uses M0 (no builtin DMA, no movrel), so it is not declared clobbered (hipcc warns that it is reserved).
+__device__ __forceinline__ void qs2_dma_slice(const float *__restrict__ src, unsigned lds_bytes, unsigned voff0, unsigned voff1) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff0), "s"(src), "s"(lds_bytes) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff1), "s"(src), "s"(lds_bytes + 1024u) : "memory");
+}
+
+// ACCV: the four accumulator tiles live in ARCHITECTURAL VGPRs (the epilogue then reads them with VALU instructions directly:
+// no 64 v_accvgpr_read per tile) and the first NA k-steps of query block 1 take the 64 AccVGPRs they leave free
+template <int KT, int PARK, bool l2, bool PROF, bool ACCV>
+__global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs2(ScanParamsH p) {
+    unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ts = 0;
+#define PH_STAMP(acc) do { if (PROF) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - ts; ts = now_; } } while (0)
+    constexpr int KS = 4 * KT;                 // 16-wide k steps
+    constexpr int NR = KS - PARK;              // block-1 fragments kept in registers
+    constexpr int NA = ACCV ? (NR < 16 ? NR : 16) : 0;   // ... of which in AccVGPRs
+    constexpr int SUB = 2, KT2 = KT / SUB, NB = 4, LA = NB - 1;
+    constexpr int STG = SUB * RT2 * BK;        // floats per stage (16 KB)
+    constexpr int PK = PARK ? PARK : 1;
+    static_assert(NT == BQ2 && NR > 0 && KT % SUB == 0, "one thread per query row in the prologue");
+    __shared__ __attribute__((aligned(16))) float smem[NB * STG + (NT / 64) * PK * 256 + 2 * BQ2 + (NT / 64) * (512 + 128)];
+    float *s_x = smem;                                   // [NB][SUB][64 * 32]
+    float *s_q = smem + NB * STG;                        // [4 waves][PARK][64 lanes x 16 B] parked block-1 fragments
+    float *s_qn = s_q + (NT / 64) * PK * 256;            // [256]
+    float *s_eps = s_qn + BQ2;                           // [256]
+    u64 *s_keys = reinterpret_cast<u64 *>(s_eps + BQ2);  // [4][256] rank-select scratch
+    u64 *s_best = s_keys + (NT / 64) * 256;              // [4][64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const int panel = blockIdx.x / p.b.splits;
+    const int split = blockIdx.x % p.b.splits;
+    const int64_t q0 = (int64_t)panel * BQ2;
+    int t_begin = split * p.b.tiles_per_split;
+    int t_end = t_begin + p.b.tiles_per_split;
+    if (t_end > p.b.n_tiles) t_end = p.b.n_tiles;
+    if (p.b.splits == 1) { t_begin = p.chunk_t0; t_end = p.chunk_t1; }
+    const int ntile = t_end - t_begin;
+    const bool final_pass = (p.b.splits > 1) || p.last_chunk;
+    const int dpad = p.dpad_h / 2;             // row pitch in 4-byte words
+
+    {
+        const float qn = p.b.qnorm[q0 + tid];
+        s_eps[tid] = band_eps(p, qn, p.qres2[q0 + tid], l2);
+        s_qn[tid] = qn;
+    }
+
+    // ---- lane-private candidate state, per query block b: query = 64*wave + 32*b + (lane&31), half-list h = lane>>5 ----
+    const int qrow0 = 64 * wave + l31, qrow1 = qrow0 + 32;
+    const bool qvalid0 = q0 + qrow0 < p.b.nq, qvalid1 = q0 + qrow1 < p.b.nq;
+    const float my_qn0 = p.b.qnorm[q0 + qrow0], my_qn1 = p.b.qnorm[q0 + qrow1];
+    u64 *cand_panel = p.b.cand + (int64_t)blockIdx.x * BQ2 * CAPH;
+    char *panel_bytes = reinterpret_cast<char *>(cand_panel);
+    const unsigned my_off0 = (unsigned)(qrow0 * CAPH + h * (CAPH / 2)) * 8u, my_off1 = (unsigned)(qrow1 * CAPH + h * (CAPH / 2)) * 8u;
+    int ccnt0 = 0, clast0 = 0, ccnt1 = 0, clast1 = 0;
+    float thkey0 = qvalid0 ? -INFINITY : INFINITY, thkey1 = qvalid1 ? -INFINITY : INFINITY;
+    if (p.b.splits == 1 && !p.first_chunk) {   // resume from the previous database chunk
+        const float *st = p.state + 8 * ((int64_t)blockIdx.x * NT + tid);
+        ccnt0 = __float_as_int(st[0]); clast0 = __float_as_int(st[1]); thkey0 = st[2];
+        ccnt1 = __float_as_int(st[4]); clast1 = __float_as_int(st[5]); thkey1 = st[6];
+    }
+    auto th_of = [&](float tk, float qn) -> float {      // what the epilogue compares against (L2: proxy carries +|q|^2)
+        if (!l2 || tk == -INFINITY || tk == INFINITY) return tk;
+        return (tk + qn) - (fabsf(tk) + qn) * 2.4e-7f - 1e-37f;
+    };
+    float th0 = th_of(thkey0, my_qn0), th1 = th_of(thkey1, my_qn1);
+
+    // ---- stationary operands: this lane's two query rows ----
+    bf16x8 qa[KS], qb[NR];
+    {
+        const __bf16 *src0 = p.qh + (q0 + qrow0) * (int64_t)p.dpad_h + 8 * h;
+        const __bf16 *src1 = p.qh + (q0 + qrow1) * (int64_t)p.dpad_h + 8 * h;
+        // (loads in groups of eight with a scheduling fence in between: left alone hipcc issues all 84 loads up front,
+        // needs 336 registers for them and spills the query rows through scratch on their way into the AccVGPRs)
+#pragma unroll
+        for (int s = NR; s < KS; ++s)          // (prologue: before any LDS-DMA is in flight)
+            *reinterpret_cast<bf16x8 *>(s_q + ((wave * PK + (s - NR)) * 64 + lane) * 4) = *reinterpret_cast<const bf16x8 *>(src1 + 16 * s);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qa[s] = *reinterpret_cast<const bf16x8 *>(src0 + 16 * s);
+            if ((s & 7) == 7) { asm volatile("" : "+a"(qa[s])); __builtin_amdgcn_sched_barrier(0); }
+        }
+#pragma unroll
+        for (int s = 0; s < NR; ++s) {
+            qb[s] = *reinterpret_cast<const bf16x8 *>(src1 + 16 * s);
+            if ((s & 7) == 7) { if (s < NA) asm volatile("" : "+a"(qb[s])); else asm volatile("" : "+v"(qb[s])); __builtin_amdgcn_sched_barrier(0); }
+        }
+    }
+
+    f32x16 acc00, acc01, acc10, acc11;         // acc<block><row half>
+    unsigned frag_addr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        frag_addr[u] = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float *)(s_x + swz(l31, 2 * u + h));
+    const unsigned vq = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float *)(s_q + (wave * PK * 64 + lane) * 4);
+
+    const float *xbase = reinterpret_cast<const float *>(p.xh + (int64_t)t_begin * RT2 * p.dpad_h);
+    const int total = ntile * KT2;
+    // a wave moves rows 16 wave + 8 i + lane/8 of a slice (i = 0, 1), 16-B chunk (lane&7) ^ swizzle(row) of each
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float *)s_x + (unsigned)wave * 2048u;
+    const unsigned voff0 = (unsigned)(((16 * wave + (lane >> 3)) * dpad + 4 * ((lane & 7) ^ ((lane >> 4) & 7))) * 4);
+    const unsigned voff1 = (unsigned)(((16 * wave + 8 + (lane >> 3)) * dpad + 4 * ((lane & 7) ^ ((4 + (lane >> 4)) & 7))) * 4);
+#define Q2_ISSUE_STAGE(tile_base, kt2_, slot_)                                                          \
+    do {                                                                                                \
+        _Pragma("unroll") for (int sb_ = 0; sb_ < SUB; ++sb_)                                           \
+            qs2_dma_slice((tile_base) + (SUB * (kt2_) + sb_) * BK, lds0 + (unsigned)(((slot_) * STG + sb_ * RT2 * BK) * 4), voff0, voff1); \
+    } while (0)
+#pragma unroll
+    for (int s0 = 0; s0 < LA; ++s0)
+        if (s0 < total) Q2_ISSUE_STAGE(xbase + (int64_t)(s0 / KT2) * RT2 * dpad, s0 % KT2, s0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (prologue only)
+    __syncthreads();
+
+    if (PROF) ts = __builtin_amdgcn_s_memtime();
+    for (int jl = 0; jl < ntile; ++jl) {
+        const float *xt = xbase + (int64_t)jl * RT2 * dpad;
+#pragma clang loop unroll(full)
+        for (int kt = 0; kt < KT2; ++kt) {
+            const int t = jl * KT2 + kt;
+            const bool more = t + LA < total;
+            if (more) {   // stage t+LA into the slot stage t-1 was read from (everyone passed the last barrier)
+                const int kn = kt + LA;
+                Q2_ISSUE_STAGE(xt + (int64_t)(kn / KT2) * RT2 * dpad, kn % KT2, (t + LA) & (NB - 1));
+            }
+            // ---- the stage's 8 k-steps: fragment reads one k-step ahead, two fragment sets, counted lgkmcnt ----
+            {
+                const unsigned sbase = (unsigned)((t & (NB - 1)) * STG * 4);
+                const int ks0 = 4 * SUB * kt;
+                bf16x8 fa0, fa1, fb0, fb1, pa, pb;      // p<set>: the parked block-1 fragment of the step, when it has one
+#define Q2_LOADS(S, KSV)                                                                                                 \
+                do {                                                                                                     \
+                    const unsigned va_ = frag_addr[(KSV) & 3] + sbase + (((KSV) & 4) ? (unsigned)(RT2 * 128) : 0u);      \
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096"                                \
+                                 : "=&v"(f##S##0), "=&v"(f##S##1) : "v"(va_) : "memory");                                \
+                    if (PARK && ks0 + (KSV) >= NR) {                                                                     \
+                        const unsigned vp_ = vq + (unsigned)((ks0 + (KSV) - NR) * 1024);                                 \
+                        asm volatile("ds_read_b128 %0, %1" : "=&v"(p##S) : "v"(vp_) : "memory");                         \
+                    }                                                                                                    \
+                } while (0)
+#define Q2_NRD(KSV) ((KSV) > 7 ? 0 : ((PARK && ks0 + (KSV) >= NR) ? 3 : 2))     /* reads the step's LOADS issues */
+#define Q2_WAIT(S, N)                                                                                                    \
+                do {                                                                                                     \
+                    if (PARK && (N) == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f##S##0), "+v"(f##S##1), "+v"(p##S)); \
+                    else if ((N) == 2)    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f##S##0), "+v"(f##S##1), "+v"(p##S)); \
+                    else                  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f##S##0), "+v"(f##S##1), "+v"(p##S)); \
+                } while (0)
+#define Q2_STEP(S, KSV)                                                                                                  \
+                do {                                                                                                     \
+                    const int ks_ = ks0 + (KSV);                     /* compile-time after unrolling */                  \
+                    if (ks_ == 0) {                                                                                      \
+                        mfma_x<ACCV, true, true>(acc00, f##S##0, qa[0]); mfma_x<ACCV, true, true>(acc01, f##S##1, qa[0]); \
+                        mfma_x<ACCV, (NA > 0), true>(acc10, f##S##0, qb[0]); mfma_x<ACCV, (NA > 0), true>(acc11, f##S##1, qb[0]); \
+                    } else {                                                                                             \
+                        mfma_x<ACCV, true, false>(acc00, f##S##0, qa[ks_]); mfma_x<ACCV, true, false>(acc01, f##S##1, qa[ks_]); \
+                        if (ks_ < NA)      { mfma_x<ACCV, true, false>(acc10, f##S##0, qb[ks_ < NR ? ks_ : 0]); mfma_x<ACCV, true, false>(acc11, f##S##1, qb[ks_ < NR ? ks_ : 0]); } \
+                        else if (ks_ < NR) { mfma_x<ACCV, false, false>(acc10, f##S##0, qb[ks_ < NR ? ks_ : 0]); mfma_x<ACCV, false, false>(acc11, f##S##1, qb[ks_ < NR ? ks_ : 0]); } \
+                        else               { mfma_x<ACCV, false, false>(acc10, f##S##0, p##S); mfma_x<ACCV, false, false>(acc11, f##S##1, p##S); } \
+                    }                                                                                                    \
+                } while (0)
+                pa = fa0 = fa1 = pb = fb0 = fb1 = bf16x8{};
+                Q2_LOADS(a, 0);
+                Q2_LOADS(b, 1); Q2_WAIT(a, Q2_NRD(1)); Q2_STEP(a, 0);
+                Q2_LOADS(a, 2); Q2_WAIT(b, Q2_NRD(2)); Q2_STEP(b, 1);
+                Q2_LOADS(b, 3); Q2_WAIT(a, Q2_NRD(3)); Q2_STEP(a, 2);
+                Q2_LOADS(a, 4); Q2_WAIT(b, Q2_NRD(4)); Q2_STEP(b, 3);
+                Q2_LOADS(b, 5); Q2_WAIT(a, Q2_NRD(5)); Q2_STEP(a, 4);
+                Q2_LOADS(a, 6); Q2_WAIT(b, Q2_NRD(6)); Q2_STEP(b, 5);
+                Q2_LOADS(b, 7); Q2_WAIT(a, Q2_NRD(7)); Q2_STEP(a, 6);
+                                Q2_WAIT(b, 0);         Q2_STEP(b, 7);
+#undef Q2_STEP
+#undef Q2_WAIT
+#undef Q2_NRD
+#undef Q2_LOADS
+            }
+            if (kt == KT2 - 1 && !(p.ablate & 1)) {
+                PH_STAMP(ph0);
+                if ((unsigned)(t_begin + jl + 1) * RT2 > (unsigned)p.b.n) {
+                    // last tile of the database (uniform): its padding rows must never pass.  One more MFMA per accumulator
+                    // tile does it: A' = -inf in k-slot 0 of the padding rows (0 elsewhere), B' = 1 in k-slot 0 (0
+                    // elsewhere), so every score of a padding row becomes -inf and a valid row's gets +0.  (Masking the 64
+                    // accumulator values with VALU code costs 64 live VGPRs + 32 compare masks that this kernel does not have.)
+                    const unsigned row = (unsigned)(t_begin + jl) * RT2 + (unsigned)l31;
+                    const unsigned short ninf = 0xff80u, one = 0x3f80u;       // bf16 -inf, 1.0
+                    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+                    u16x8 m0 = {}, m1 = {}, ones = {};
+                    m0[0] = (h == 0 && row >= (unsigned)p.b.n) ? ninf : (unsigned short)0;
+                    m1[0] = (h == 0 && row + 32 >= (unsigned)p.b.n) ? ninf : (unsigned short)0;
+                    ones[0] = h == 0 ? one : (unsigned short)0;
+                    const bf16x8 a0 = __builtin_bit_cast(bf16x8, m0), a1 = __builtin_bit_cast(bf16x8, m1), b1 = __builtin_bit_cast(bf16x8, ones);
+                    mfma_x<ACCV, false, false>(acc00, a0, b1); mfma_x<ACCV, false, false>(acc01, a1, b1);
+                    mfma_x<ACCV, false, false>(acc10, a0, b1); mfma_x<ACCV, false, false>(acc11, a1, b1);
+                }
+                if (ACCV) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc00), "+v"(acc01), "+v"(acc10), "+v"(acc11));
+                else      asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc00), "+a"(acc01), "+a"(acc10), "+a"(acc11));
+                // ---- epilogue: acc<b><i>[e] = s~(db row 32 i + (e&3) + 8(e>>2) + 4h of the tile, query block b's lane&31) ----
+                const unsigned jb = (unsigned)(t_begin + jl) * RT2 + 4 * h;
+                const float tf0 = (p.ablate & 4) ? INFINITY : th0, tf1 = (p.ablate & 4) ? INFINITY : th1;
+                // (L2: scheduling fences keep hipcc from hoisting all sixteen |x|^2 float4 loads of the four calls to the top)
+                qs_filter_tile<l2>(acc00, tf0, jb, my_qn0, p.b.xnorm, (unsigned)p.b.n, ccnt0, panel_bytes, my_off0);
+                if (l2) __builtin_amdgcn_sched_barrier(0);
+                qs_filter_tile<l2>(acc01, tf0, jb + 32, my_qn0, p.b.xnorm, (unsigned)p.b.n, ccnt0, panel_bytes, my_off0);
+                if (l2) __builtin_amdgcn_sched_barrier(0);
+                qs_filter_tile<l2>(acc10, tf1, jb, my_qn1, p.b.xnorm, (unsigned)p.b.n, ccnt1, panel_bytes, my_off1);
+                if (l2) __builtin_amdgcn_sched_barrier(0);
+                qs_filter_tile<l2>(acc11, tf1, jb + 32, my_qn1, p.b.xnorm, (unsigned)p.b.n, ccnt1, panel_bytes, my_off1);
+                PH_STAMP(ph1);
+
+                // ---- maintenance, per query block: which queries need a (light) compaction? ----
+                bool waited = false;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    int &ccnt = b ? ccnt1 : ccnt0, &clast = b ? clast1 : clast0;
+                    float &thkey = b ? thkey1 : thkey0, &th = b ? th1 : th0;
+                    const float my_qn = b ? my_qn1 : my_qn0;
+                    const bool qvalid = b ? qvalid1 : qvalid0;
+                    const int pair = ccnt + __shfl_xor(ccnt, 32);
+                    const bool warm = thkey == -INFINITY && pair >= p.b.kk;
+                    const bool stale = pair >= p.b.kk && pair - clast >= p.b.stale;
+                    const bool full = ccnt > CAPH / 2 - RT2 / 2;          // my half could overflow on the next tile (<= 32 appends)
+                    u64 todo = __ballot(qvalid && (warm || stale || full));
+                    todo = (todo | (todo >> 32)) & 0xffffffffull;          // one bit per query of this block
+                    if (!todo) continue;
+                    if (!waited) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); waited = true; }   // this tile's appends are visible
+                    do {
+                        const int r = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1;
+                        const int row = 64 * wave + 32 * b + r;
+                        u64 *list = cand_panel + (int64_t)row * CAPH;
+                        const int n0 = __builtin_amdgcn_readlane(ccnt, r), n1 = __builtin_amdgcn_readlane(ccnt, r + 32);
+                        float lo;
+                        int kept = qs_compact_light(list, n0, n1, p.b.kk, s_eps[row], lane, &lo);
+                        if (kept > CAPH / 2 - RT2 / 2) {    // the band itself does not fit: settle it exactly
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            const int k0 = kept < CAPH / 2 ? kept : CAPH / 2;
+                            u64 kth;
+                            kept = qs_compact_exact(p, list, k0, kept - k0, q0 + row, s_qn[row], lane,
+                                                    s_keys + wave * 256, s_best + wave * 64, &kth);
+                            if (kept == p.b.kk) lo = bound_from_tau(lemon_key_score(kth), s_eps[row]);
+                        }
+                        if (l31 == r) {                    // both lanes of the pair take the new state
+                            ccnt = h == 0 ? kept : 0;      // (kept <= CAPH/2 - 32 here: all in half-list 0)
+                            clast = kept;
+                            thkey = lo;
+                            th = th_of(lo, my_qn);
+                        }
+                    } while (todo);
+                }
+                if (waited) PH_STAMP(ph3);
+            }
+            // stage t+1 must have landed (all waves' parts) before anyone reads it: at most the LA-1 youngest stages
+            // (4 DMA instructions each; younger appends only make the wait longer, never shorter) may still be in flight
+            if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS reads retired
+            if (PROF && (p.ablate & 8) && kt == KT2 - 1) PH_STAMP(ph3);
+            __builtin_amdgcn_s_barrier();
+            if (kt == KT2 - 1) PH_STAMP(ph2);
+        }
+    }
+
+    if (PROF && tid == 0) {
+        atomicAdd(&p.phase_dbg[0], ph0); atomicAdd(&p.phase_dbg[1], ph1);
+        atomicAdd(&p.phase_dbg[2], ph2); atomicAdd(&p.phase_dbg[3], ph3);
+    }
+#undef PH_STAMP
+#undef Q2_ISSUE_STAGE
+    if (!final_pass) {      // park the lane-private state for the next database chunk
+        float *st = p.state + 8 * ((int64_t)blockIdx.x * NT + tid);
+        st[0] = __int_as_float(ccnt0); st[1] = __int_as_float(clast0); st[2] = thkey0;
+        st[4] = __int_as_float(ccnt1); st[5] = __int_as_float(clast1); st[6] = thkey1;
+        return;
+    }
+    // ---- final pass: exact re-scoring + exact top-k of every query, then the result rows ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int r = 0; r < 64; ++r) {
+        const int row = 64 * wave + r;
+        const int64_t q = q0 + row;
+        if (q >= p.b.nq) break;
+        u64 *list = cand_panel + (int64_t)row * CAPH;
+        const int src = r & 31;
+        const int n0 = r < 32 ? __builtin_amdgcn_readlane(ccnt0, src) : __builtin_amdgcn_readlane(ccnt1, src);
+        const int n1 = r < 32 ? __builtin_amdgcn_readlane(ccnt0, src + 32) : __builtin_amdgcn_readlane(ccnt1, src + 32);
+        u64 kth;
+        const int have = qs_compact_exact(p, list, n0, n1, q, s_qn[row], lane, s_keys + wave * 256,
+                                          s_best + wave * 64, &kth);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const u64 key = (lane < have && lane < p.b.kk) ? list[lane] : 0;
+        write_out_row(p.b, split, q, lane, key);
+    }
+}
+
 }  // namespace
 
 // column pitch of the bf16 copies: the Q-stationary kernel is instantiated for 256/512/768
@@ -896,6 +1235,28 @@ static int ensure_bf16_copy(lemon_index_t *idx, hipStream_t stream) {
 
 static const int64_t QCHUNK_H = 1 << 19;
 
+// QS2 (two query blocks per wave, 256 queries per workgroup, 64-row tiles) serves the register-resident pitches;
+// LEMON_QS2=0 selects the one-block kernel (A/B aid)
+static bool use_qs2() {
+    const char *e = getenv("LEMON_QS2");
+    return !(e && e[0] == '0');
+}
+
+template <bool l2, bool PROF>
+static void launch_qs2(int kt, unsigned grid, hipStream_t stream, const ScanParamsH &p) {
+    static const bool accv = [] { const char *e = getenv("LEMON_QS2_ACCV"); return !(e && e[0] == '0'); }();   // A/B aid
+    switch (kt) {
+        case 8:
+            if (accv) hipLaunchKernelGGL((k_scan_bf16_qs2<8, 0, l2, PROF, true>), dim3(grid), dim3(NT), 0, stream, p);
+            else      hipLaunchKernelGGL((k_scan_bf16_qs2<8, 0, l2, PROF, false>), dim3(grid), dim3(NT), 0, stream, p);
+            break;
+        default:    // (the L2 epilogue's |x|^2 loads need a few more registers: four more parked k-steps)
+            if (accv) hipLaunchKernelGGL((k_scan_bf16_qs2<12, l2 ? 20 : 16, l2, PROF, true>), dim3(grid), dim3(NT), 0, stream, p);
+            else      hipLaunchKernelGGL((k_scan_bf16_qs2<12, l2 ? 20 : 16, l2, PROF, false>), dim3(grid), dim3(NT), 0, stream, p);
+            break;
+    }
+}
+
 int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, float *D_dev,
                       int64_t *I_dev, hipStream_t stream) {
     const int d = idx->d;
@@ -903,14 +1264,27 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
     int rc = ensure_bf16_copy(idx, stream);
     if (rc) return rc;
     const int dpad_h = idx->dpad_h;
-    const int n_tiles = (int)((idx->n + BX - 1) / BX);
+    const bool qs = dpad_h <= 768;
+    // QS2 halves the panel count.  When 256-query panels alone do not fill the chip the database would be split between more
+    // workgroups, and every split pays its own cold start (k ln(n/k) appends per query): measured 13.0 -> 20.1 ms at
+    // 50 000 x 40 000 x 512 and 17.3 -> 21.8 ms at 131 072^2 x 256 (k = 11), against 1 648 -> 1 501 ms at 1 M x 768,
+    // 142.1 -> 129.9 ms at 262 144^2 x 768 and 103.9 -> 97.8 ms at 262 144^2 x 512.  So: from 768 panels of 256 queries on
+    // (the splits == 1 regime of lemon_plan_splits), pitches 512 and 768.
+    const char *qs2_env = getenv("LEMON_QS2_MIN_PANELS");      // (read per call: the tests force QS2 onto small shapes with 0)
+    const int qs2_min = qs2_env ? atoi(qs2_env) : 768;
+    const bool qs2 = qs && use_qs2() && dpad_h >= 512 && (nq < QCHUNK_H ? nq : QCHUNK_H) >= (int64_t)qs2_min * BQ2;
+    const int bqw = qs2 ? BQ2 : BQ;                     // queries per workgroup
+    const int rt = qs2 ? RT2 : BX;                      // database rows per tile
+    const int n_tiles128 = (int)((idx->n + BX - 1) / BX);
+    const int n_tiles = (int)((idx->n + rt - 1) / rt);
     for (int64_t c0 = 0; c0 < nq; c0 += QCHUNK_H) {
         const int64_t cn = (nq - c0) < QCHUNK_H ? (nq - c0) : QCHUNK_H;
-        const int64_t nq_pad = round_up(cn, BQ);
-        const int panels = (int)(nq_pad / BQ);
+        const int64_t nq_pad = round_up(cn, bqw);
+        const int panels = (int)(nq_pad / bqw);
         int splits, tiles_per_split;
-        lemon_plan_splits(panels, n_tiles, &splits, &tiles_per_split);
-        rc = lemon_ensure_search_ws(idx, nq_pad, splits, (int64_t)panels * splits, dpad_h * 2, CAPH, stream);
+        lemon_plan_splits(panels, n_tiles128, &splits, &tiles_per_split);
+        if (qs2) tiles_per_split *= BX / RT2;            // (the plan counts 128-row tiles)
+        rc = lemon_ensure_search_ws(idx, nq_pad, splits, (int64_t)panels * splits * (bqw / BQ), dpad_h * 2, CAPH, stream);
         if (rc) return rc;
         // bf16 query panel (pad rows zero), chain norms, measured rounding residuals
         __bf16 *qh = reinterpret_cast<__bf16 *>(idx->ws_qp);
@@ -936,42 +1310,44 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
         static const int refresh = [] { const char *e = getenv("LEMON_REFRESH"); return e && atoi(e) > 0 ? atoi(e) : REFRESH; }();
         p.b.stale = refresh;                  // new candidates per query that trigger a light compaction (tuning knob)
         const unsigned grid = (unsigned)(panels * splits);
-        const bool qs = dpad_h <= 768;
         // database chunks sized for the Infinity Cache (the chunk is re-read by every query panel)
         int chunk_tiles = n_tiles;
         if (qs && splits == 1) {
             const char *env = getenv("LEMON_CHUNK_MB");
             const double mb = env ? atof(env) : 64.0;
             if (mb > 0) {
-                chunk_tiles = (int)(mb * 1048576.0 / ((double)BX * dpad_h * 2));
+                chunk_tiles = (int)(mb * 1048576.0 / ((double)rt * dpad_h * 2));
                 if (chunk_tiles < 8) chunk_tiles = 8;
             }
             if (chunk_tiles > n_tiles) chunk_tiles = n_tiles;
-            if ((int64_t)grid * NT * 4 > idx->ws_state_elems) {
+            const int64_t state_elems = (int64_t)grid * NT * (qs2 ? 8 : 4);
+            if (state_elems > idx->ws_state_elems) {
                 LEMON_HIP_CHECK(hipStreamSynchronize(stream));
                 if (idx->ws_state) (void)hipFree(idx->ws_state);
                 idx->ws_state = nullptr; idx->ws_state_elems = 0;
-                if (hipMalloc(&idx->ws_state, (size_t)grid * NT * 4 * sizeof(float)) != hipSuccess) {
+                if (hipMalloc(&idx->ws_state, (size_t)state_elems * sizeof(float)) != hipSuccess) {
                     lemon_set_error("scan state allocation failed");
                     return LEMON_E_NOMEM;
                 }
-                idx->ws_state_elems = (int64_t)grid * NT * 4;
+                idx->ws_state_elems = state_elems;
             }
         }
         p.state = idx->ws_state;
+        const bool l2m = idx->metric == LEMON_METRIC_L2;
         for (int t0 = 0; t0 < n_tiles; t0 += chunk_tiles) {
             const int t1 = (t0 + chunk_tiles < n_tiles) ? t0 + chunk_tiles : n_tiles;
             p.chunk_t0 = t0; p.chunk_t1 = t1; p.first_chunk = (t0 == 0); p.last_chunk = (t1 == n_tiles);
-            const double rows = (double)(t1 - t0) * BX < (double)idx->n - (double)t0 * BX ? (double)(t1 - t0) * BX
-                                                                                            : (double)idx->n - (double)t0 * BX;
+            const double rows = (double)(t1 - t0) * rt < (double)idx->n - (double)t0 * rt ? (double)(t1 - t0) * rt
+                                                                                            : (double)idx->n - (double)t0 * rt;
             const double flops = 2.0 * (double)cn * rows * (double)d;
-            const double bytes = 2.0 * d * ((double)panels * rows) + (p.last_chunk ? 2.0 * d * cn + 12.0 * k * (double)cn : 0.0);
+            const double bytes = 2.0 * d * ((double)nq_pad / BQ * rows) + (p.last_chunk ? 2.0 * d * cn + 12.0 * k * (double)cn : 0.0);
             LemonProfScope prof(idx, stream, flops, bytes);
-            if (qs && dpad_h / BKH == 12 && idx->metric == LEMON_METRIC_IP && getenv("LEMON_PHASE_PROF")) {   // diagnostic build: phase cycle sums
+            if (qs && dpad_h / BKH == 12 && !l2m && getenv("LEMON_PHASE_PROF")) {   // diagnostic build: phase cycle sums
                 static unsigned long long *dbg = nullptr;
                 if (!dbg) { (void)hipMalloc(&dbg, 64); (void)hipMemset(dbg, 0, 64); }
                 p.phase_dbg = dbg;
-                hipLaunchKernelGGL((k_scan_bf16_qs<12, false, true>), dim3(grid), dim3(NT), 0, stream, p);
+                if (qs2) launch_qs2<false, true>(12, grid, stream, p);
+                else hipLaunchKernelGGL((k_scan_bf16_qs<12, false, true>), dim3(grid), dim3(NT), 0, stream, p);
                 (void)hipStreamSynchronize(stream);
                 unsigned long long h[8]; (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost);
 
@@ -981,7 +1357,11 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
                 (void)hipMemset(dbg, 0, 64);
                 continue;
             }
-            const bool l2m = idx->metric == LEMON_METRIC_L2;
+            if (qs2) {
+                if (l2m) launch_qs2<true, false>(dpad_h / BKH, grid, stream, p);
+                else     launch_qs2<false, false>(dpad_h / BKH, grid, stream, p);
+                continue;
+            }
             switch (qs ? dpad_h / BKH : 0) {
                 case 4:
                     if (l2m) hipLaunchKernelGGL((k_scan_bf16_qs<4, true, false>), dim3(grid), dim3(NT), 0, stream, p);
@@ -1005,7 +1385,7 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
         }
         idx->last.algo = LEMON_ALGO_BF16_FILTER;
         idx->last.grid = (int)grid; idx->last.block = NT;
-        idx->last.query_panel = BQ; idx->last.db_splits = splits;
+        idx->last.query_panel = bqw; idx->last.db_splits = splits;
     }
     idx->last.nq = nq; idx->last.n = idx->n; idx->last.d = d; idx->last.k = k;
     return LEMON_OK;

@@ -26,9 +26,45 @@ def shard_bounds(n, world_size, rank):
     return lo, min(n, lo + per)
 
 
-def all_gather_rows(t, n_total, group=None):
+class GatherLog:
+    """What the path's only exchange step cost ("log the achieved bus bandwidth"): one entry per
+    all-gathered array with HIP events recorded around the collective on the caller's stream (the collective's own stream
+    is joined by `wait()` before the second event).  `summary()` synchronises the events; call it after the timed region."""
+
+    def __init__(self):
+        self.entries = []
+
+    def add(self, name, rows, row_bytes, world, backend, start, end):
+        self.entries.append(dict(name=name, rows=int(rows), row_bytes=int(row_bytes), world=int(world), backend=backend,
+                                 start=start, end=end))
+
+    def summary(self):
+        """{"allgather_ms": total, "arrays": [{name, bytes_gathered, ms, algbw_GBs, busbw_GBs}]}: algbw = gathered bytes /
+        time; busbw = algbw x (W-1)/W, the per-rank receive rate a ring or a direct exchange must sustain (nccl-tests
+        convention) -- to be read against 7 xGMI links x ~153 GB/s per GPU."""
+        out, total = {}, 0.0
+        for e in self.entries:
+            e["end"].synchronize()
+            ms = e["start"].elapsed_time(e["end"])
+            a = out.setdefault(e["name"], dict(name=e["name"], calls=0, ms=0.0, bytes_gathered=0, backend=e["backend"]))
+            a["calls"] += 1; a["ms"] += ms; a["bytes_gathered"] += e["rows"] * e["row_bytes"]
+            total += ms
+            W = e["world"]
+            a["_w"] = W
+        arrays = []
+        for a in out.values():
+            W = a.pop("_w")
+            sec = max(a["ms"], 1e-9) / 1e3
+            a["algbw_GBs"] = a["bytes_gathered"] / sec / 1e9
+            a["busbw_GBs"] = a["algbw_GBs"] * (W - 1) / W
+            arrays.append(a)
+        return {"allgather_ms": total, "arrays": arrays}
+
+
+def all_gather_rows(t, n_total, group=None, log=None, name="rows"):
     """All-gather row shards (possibly ragged: last shard short/empty) into global row order.
-    One RCCL all_gather per array; shards are padded to ceil(n/W) rows."""
+    One RCCL all_gather per array; shards are padded to ceil(n/W) rows.  `log`: a GatherLog that
+    receives the collective's HIP-event bracket."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return t
@@ -36,15 +72,26 @@ def all_gather_rows(t, n_total, group=None):
     per = (n_total + W - 1) // W
     pad = torch.zeros((per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[: t.shape[0]] = t
-    if t.is_cuda and dist.get_backend(group) == "gloo":
+    backend = dist.get_backend(group)
+    ev = None
+    if log is not None and t.is_cuda:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    if t.is_cuda and backend == "gloo":
         # rehearsal mode only (several ranks on ONE card, LEMON_DIST_BACKEND=gloo: RCCL needs distinct devices):
         # gloo gathers host buffers, so the shard is staged through the host; the product path is the RCCL branch below
         host = torch.empty((W * per,) + tuple(t.shape[1:]), dtype=t.dtype)
         dist.all_gather_into_tensor(host, pad.cpu(), group=group)
-        return host[:n_total].to(t.device)
-    out = torch.empty((W * per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
-    return out[:n_total]
+        out = host[:n_total].to(t.device)
+    else:
+        out = torch.empty((W * per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, pad, group=group)
+        out = out[:n_total]
+    if ev is not None:
+        ev[1].record()
+        log.add(name, W * per, t[0].numel() * t.element_size() if t.shape[0] else pad[0].numel() * pad.element_size(), W,
+                backend, ev[0], ev[1])
+    return out
 
 
 class Embedder:
@@ -149,7 +196,7 @@ def score_splits(db, splits, k, hparams=None, discrete=False):
 
 
 def run_hot_path(embedder, data, k=5, dist_type="cosine", hparams=FIXED_HPARAMS, discrete=False,
-                 world_size=1, rank=0, algo=None, timers=None, profile_index=False):
+                 world_size=1, rank=0, algo=None, timers=None, profile_index=False, gather_log=None):
     """One pass of the hot path over `data` = {split: {"pixels": float [n,3,S,S] or raw uint8 [n,H,W,3], "ids": [n,L], "label_id": [n]}}
     for split in train/val/test, this rank's shard of each.  DB = all ranks' train shards in global
     order.  The train split is embedded ONCE and reused as DB and as queries (the reference embeds it
@@ -164,10 +211,10 @@ def run_hot_path(embedder, data, k=5, dist_type="cosine", hparams=FIXED_HPARAMS,
         timers["embed_s"] = time.perf_counter() - t0
         t0 = time.perf_counter()
     n_train_total = data["train"].get("n_total", emb["train"][0].shape[0])
-    img_tr = all_gather_rows(emb["train"][0], n_train_total)
-    txt_tr = all_gather_rows(emb["train"][1], n_train_total)
+    img_tr = all_gather_rows(emb["train"][0], n_train_total, log=gather_log, name="emb_img_tr")
+    txt_tr = all_gather_rows(emb["train"][1], n_train_total, log=gather_log, name="emb_txt_tr")
     lab = data["train"].get("label_id")
-    lab_tr = all_gather_rows(lab.to(dev), n_train_total) if (discrete and lab is not None) else None
+    lab_tr = all_gather_rows(lab.to(dev), n_train_total, log=gather_log, name="label_id_tr") if (discrete and lab is not None) else None
     db = LemonDB(img_tr, txt_tr, dist_type, tr_label_id=lab_tr, algo=algo)
     if profile_index:
         db.index_img.set_profiling(True)

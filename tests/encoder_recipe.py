@@ -12,6 +12,11 @@ CONFIGS = {
     "scratch_b16_77": dict(embed_dim=768, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=16,
                            context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8,
                            transformer_layers=12),
+    # load_clip(None) with its DEFAULT context_length = 256 (:458): the mimic_clip_from_scratch_* / chexzero branches
+    # (lib/models/utils.py:79-95): 256-token causal text tower
+    "scratch_b16_256": dict(embed_dim=768, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=16,
+                            context_length=256, vocab_size=49408, transformer_width=512, transformer_heads=8,
+                            transformer_layers=12),
 }
 
 

@@ -29,3 +29,13 @@ def planted(seed, n_tr, n_q, d, C, noise=0.4, sigma=0.5):
                 clean.astype(np.int32), noisy.astype(np.int32))
 
     return {"proto": proto, "train": make(n_tr), "query": make(n_q)}
+
+
+def second_opinion_inputs():
+    """Inputs of tests/golden/knn_second_opinion.npz (tools/make_golden_knn.py): 2 048 x 64 features for the reference's
+    cosDistance + topk, and an un-normalised 2 048 x 64 database with 64 queries for its sklearn euclidean metric."""
+    rs = np.random.RandomState(31)
+    feat = rs.randn(2048, 64).astype(np.float32)
+    X = (rs.randn(2048, 64) * rs.uniform(0.5, 2.0, (2048, 1))).astype(np.float32)
+    Q = (rs.randn(64, 64) * rs.uniform(0.5, 2.0, (64, 1))).astype(np.float32)
+    return feat, X, Q

@@ -81,7 +81,7 @@ def test_flop_model_matches_survey():
 
 
 # ------------------------------------------------------------------ in-tree CLIP (A3'): reference-generated goldens
-@pytest.mark.parametrize("name", ["small_hd64", "scratch_b16_77"])
+@pytest.mark.parametrize("name", ["small_hd64", "scratch_b16_77", "scratch_b16_256"])
 def test_openai_format_loader_matches_reference_clip(name):
     """LemonCLIP loaded from an OpenAI-format state dict vs the outputs of the reference's own CLIP module
     (lib/models/chexzero_clip.py:263-392; `scratch_b16_77` is built by its load_clip(None, 77), :458-479) on the same

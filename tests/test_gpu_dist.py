@@ -33,10 +33,17 @@ def _launch(case, out_dir, data_dir, world):
         if world == 1:
             for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
                 env.pop(k_)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), case, out_dir, data_dir],
-                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
-    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+        # every rank writes to its own FILE: with pipes read one after the other a chatty rank could fill its pipe while the
+        # rank being waited on sits in a collective with it
+        os.makedirs(out_dir, exist_ok=True)
+        log = open(os.path.join(out_dir, f"rank{r}.log"), "wb")
+        procs.append((subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), case, out_dir, data_dir],
+                                       env=env, stdout=log, stderr=subprocess.STDOUT), log))
+    for pr, log in procs:
+        pr.wait(timeout=600)
+        log.close()
+    outs = [open(os.path.join(out_dir, f"rank{r}.log")).read() for r in range(world)]
+    assert all(pr.returncode == 0 for pr, _ in procs), "\n".join(outs)[-3000:]
     return pickle.load(open(os.path.join(out_dir, "res.pkl"), "rb"))["df"]
 
 
@@ -74,6 +81,11 @@ def test_bench_self_launches_its_ranks(hip):
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert "knn_1m" not in line and "cpu_baseline" not in line          # N = 1 extras only
     assert line["config"]["parallelism"] == "dp2+allgather"
+    # N > 1: the line explains its exchange step: time and bus bandwidth per gathered array, scan per rank
+    ex = line["exchange"]
+    assert {a["name"] for a in ex["arrays"]} == {"emb_img_tr", "emb_txt_tr"} and ex["allgather_ms"] > 0
+    assert all(a["bytes_gathered"] == 2 * 1500 * 32 * 4 and a["busbw_GBs"] > 0 for a in ex["arrays"])
+    assert len(ex["knn_algo_per_rank"]) == 2 and all(r["db_rows"] == 3000 for r in ex["knn_algo_per_rank"])
     # WORLD_SIZE that contradicts --gpus is an error, not a silent single-GPU run
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"],
                          env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())),

@@ -91,7 +91,7 @@ def test_fused_gpu_encoder_vs_hf_clip_at_full_size(hip, arch):
     assert float((nn_ - torch.nn.functional.normalize(ref_txt, dim=1)).abs().max()) <= 5e-6
 
 
-@pytest.mark.parametrize("name", ["small_hd64", "scratch_b16_77"])
+@pytest.mark.parametrize("name", ["small_hd64", "scratch_b16_77", "scratch_b16_256"])
 def test_fused_gpu_encoder_vs_reference_in_tree_clip(hip, name):
     from tests.encoder_recipe import CONFIGS, inputs, lemon_clip_from_recipe
     fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "encoder_chexzero.npz"))

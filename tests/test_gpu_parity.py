@@ -237,6 +237,24 @@ def test_bf16_filter_bit_exact(hip, oracle, metric, nq, n, d, k):
 
 
 @pytest.mark.parametrize("metric", ["ip", "l2"])
+@pytest.mark.parametrize("nq,n,d,k", [(300, 2049, 768, 5), (64, 5000, 512, 50), (513, 1300, 300, 51), (1000, 9000, 700, 64),
+                                       (257, 63, 768, 10), (130, 129, 400, 64)])
+def test_bf16_two_block_kernel_forced_on_small_shapes(hip, oracle, monkeypatch, metric, nq, n, d, k):
+    # k_scan_bf16_qs2 normally serves >= 196 608 queries; LEMON_QS2_MIN_PANELS=0 puts the oracle-sized cases through it:
+    # ragged last panel (nq % 256), database tails (n % 64, n < 64), database splits with merge, pitches 512 and 768
+    monkeypatch.setenv("LEMON_QS2_MIN_PANELS", "0")
+    rng = np.random.default_rng(nq * 7 + n * 3 + d + k)
+    X, Q = unit_rows(rng, n, d), unit_rows(rng, nq, d)
+    if metric == "l2":
+        X *= rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32)
+        Q *= rng.uniform(0.5, 2.0, (nq, 1)).astype(np.float32)
+    D, I, idx = _search(hip, metric, X, Q, k, algo=BF16)
+    info = idx.last_search_info()
+    assert info["algo"] == BF16 and info["query_panel"] == 256
+    _assert_knn_equal((D, I), oracle.knn(metric, X, Q, k))
+
+
+@pytest.mark.parametrize("metric", ["ip", "l2"])
 def test_bf16_filter_ties_and_clusters(hip, oracle, metric):
     # prototypes (exact duplicates) + tight clusters whose spread is far below the bf16 band:
     # the filter cannot separate them, only the exact re-rank can
@@ -251,6 +269,27 @@ def test_bf16_filter_ties_and_clusters(hip, oracle, metric):
     Q = Q.astype(np.float32)
     D, I, _ = _search(hip, metric, X, Q, k, algo=BF16)
     _assert_knn_equal((D, I), oracle.knn(metric, X, Q, k))
+
+
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+def test_bf16_two_block_kernel_ties_and_clusters(hip, oracle, monkeypatch, metric):
+    # the band-overflow path (exact compaction on the spot) and the all-ties path of k_scan_bf16_qs2: duplicates + clusters
+    # far tighter than the bf16 band at pitch 512, every row of the ascending-score worst case admitted at pitch 768
+    monkeypatch.setenv("LEMON_QS2_MIN_PANELS", "0")
+    rng = np.random.default_rng(19)
+    C, n, d, k = 12, 6000, 400, 51
+    proto = unit_rows(rng, C, d)
+    X = proto[rng.integers(0, C, n)].copy()
+    X[n // 2:] += rng.standard_normal((n - n // 2, d)).astype(np.float32) * 1e-4
+    Q = (proto[rng.integers(0, C, 300)] + rng.standard_normal((300, d)).astype(np.float32) * 1e-3).astype(np.float32)
+    D, I, idx = _search(hip, metric, X, Q, k, algo=BF16)
+    assert idx.last_search_info()["query_panel"] == 256
+    _assert_knn_equal((D, I), oracle.knn(metric, X, Q, k))
+    base = unit_rows(rng, 1, 768)[0]
+    X = (base[None, :] * np.linspace(0.2, 1.0, 64 * 50, dtype=np.float32)[:, None]).astype(np.float32)
+    Q = (base[None, :] * np.linspace(0.5, 1.5, 300, dtype=np.float32)[:, None]).astype(np.float32)
+    D, I, _ = _search(hip, "ip", X, Q, k, algo=BF16)
+    _assert_knn_equal((D, I), oracle.knn("ip", X, Q, k))
 
 
 def test_bf16_filter_unnormalised_and_wide_dynamic_range(hip, oracle):
@@ -367,16 +406,19 @@ def test_neighbors_record_bf16_algo(hip, oracle):
         assert np.array_equal(got[key].cpu().numpy(), ref[key]), key
 
 
-def test_bf16_filter_chunked_database_state_carry(hip, oracle, monkeypatch):
+@pytest.mark.parametrize("d,nq", [(64, 131072 + 77), (300, 196608 + 77), (768, 196608 + 300)])
+def test_bf16_filter_chunked_database_state_carry(hip, oracle, monkeypatch, d, nq):
     # >= 1024 query panels -> one launch per Infinity-Cache-sized database chunk with the per-query
-    # state carried between launches; force tiny chunks (8 tiles) so several launches happen
+    # state carried between launches; force tiny chunks (8 tiles) so several launches happen.
+    # d = 64: one query block per wave (k_scan_bf16_qs); d = 300 / 768 from 768 panels of 256 queries on: two blocks per
+    # wave (k_scan_bf16_qs2, 64-row tiles, two states per lane; at 768 part of block 1 is parked in LDS)
     monkeypatch.setenv("LEMON_CHUNK_MB", "0.01")
     g = torch.Generator(device="cuda").manual_seed(9)
-    X = hip.normalize_vectors(torch.randn(5000, 64, generator=g, device="cuda"))
-    Q = hip.normalize_vectors(torch.randn(131072 + 77, 64, generator=g, device="cuda"))
+    X = hip.normalize_vectors(torch.randn(5000, d, generator=g, device="cuda"))
+    Q = hip.normalize_vectors(torch.randn(nq, d, generator=g, device="cuda"))
     out = []
     for algo in (1, BF16):
-        idx = hip.IndexFlatIP(64)
+        idx = hip.IndexFlatIP(d)
         idx.set_algo(algo)
         idx.add(X)
         out.append(idx.search(Q, 51))
@@ -597,6 +639,18 @@ def test_cos_distance_topk_matches_reference_golden(hip):
     assert np.abs(vals.cpu().numpy() - g["vals"]).max() < 5e-7
     prob = count_knn_distribution(4, 0.0, cu(g["feat"]), np.arange(64) % 4, 6)
     assert prob.shape == (64, 4) and torch.allclose(prob.norm(dim=1), torch.ones(64, device="cuda"), atol=1e-5)
+
+
+@pytest.mark.parametrize("algo", [1, BF16])
+def test_flat_search_against_reference_second_opinion_n2048_k51(hip, algo):
+    """lib/metrics/utils.py:198-214 (cosDistance + topk) and lib/metrics/distance_metrics.py:48-73 (sklearn euclidean)
+    executed by tools/make_golden_knn.py: both scan kernels against the reference's own brute-force arithmetic."""
+    from tests.test_oracle_golden import check_second_opinion
+
+    def knn(metric, X, Q, k):
+        D, I, _ = _search(hip, metric, X, Q, k, algo=algo)
+        return D, I
+    check_second_opinion(knn, lambda x: hip.normalize_vectors(cu(x)).cpu().numpy())
 
 
 @pytest.mark.gpu

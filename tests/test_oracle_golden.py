@@ -92,6 +92,29 @@ def test_knn_against_reference_cosdistance_topk(oracle):
     assert np.abs((1.0 - D) - g["vals"]).max() < 5e-7
 
 
+def check_second_opinion(knn, normalize):
+    """knn(metric, X, Q, k) -> (D, I) against tests/golden/knn_second_opinion.npz (tools/make_golden_knn.py): the
+    reference's cosDistance + topk (IP) and its sklearn euclidean metric + argsort (L2) at N = 2 048, d = 64, k = 51.
+    Values must agree everywhere; index rows must agree wherever the reference's own consecutive values are further
+    apart than float32 noise (two float32 implementations may order a 1-ulp near-tie differently)."""
+    from tests.synth import second_opinion_inputs
+    g = load("knn_second_opinion.npz")
+    feat, X, Q = second_opinion_inputs()
+    f = normalize(feat)
+    D, I = knn("ip", f, np.ascontiguousarray(f[::4]), 51)
+    assert np.abs((1.0 - D) - g["ip_vals"]).max() < 1e-6             # (sgemm vs fma chain over d = 64; north_star: 1e-4)
+    clear = np.diff(g["ip_vals"], axis=1).min(1) > 1e-6
+    assert clear.mean() > 0.9 and np.array_equal(I[clear], g["ip_idx"][clear].astype(np.int64))
+    assert (I != g["ip_idx"]).sum() <= 2 * (~clear).sum()           # a near-tie swaps two neighbouring entries
+    D, I = knn("l2", X, Q, 51)
+    assert np.array_equal(I, g["l2_idx"].astype(np.int64))           # smallest gap 1.5e-5: no near-ties
+    assert np.abs(np.sqrt(D) - g["l2_dist"]).max() < 2e-5 * g["l2_dist"].max()
+
+
+def test_knn_against_reference_second_opinion_n2048_k51(oracle):
+    check_second_opinion(oracle.knn, oracle.normalize_rows)
+
+
 def test_knn_against_torch_mm_topk(oracle):
     rng = np.random.default_rng(1)
     X = oracle.normalize_rows(rng.standard_normal((3000, 96)).astype(np.float32))

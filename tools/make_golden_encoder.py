@@ -27,6 +27,9 @@ for name, cfg in CONFIGS.items():
     if name == "scratch_b16_77":
         model = cz.load_clip(None, context_length=77)           # the reference's own constructor path (:458-479)
         assert model.context_length == 77 and model.visual.conv1.weight.shape == (768, 3, 16, 16)
+    elif name == "scratch_b16_256":
+        model = cz.load_clip(None)                              # default context_length (256): the MIMIC configuration
+        assert model.context_length == 256 and model.positional_embedding.shape == (256, 512)
     else:
         model = cz.CLIP(**cfg)
     sd = openai_state_dict(cfg)
