@@ -544,7 +544,7 @@ CASES = {
     # LEMON_GOLDEN_ABL_SEED overrides the seed while searching for one)
     **{f"c10_cos_k5_abl_{a}": dict(dataset="cifar10", n=500, d=32, seed=int(os.environ.get("LEMON_GOLDEN_ABL_SEED", sd)),
                                    argv=["--dataset", "cifar10", "--noise_type", "asymmetric", "--knn_k", "5", "--ablation", a])
-       for a, sd in (("d1", 40), ("tau_1_2", 41), ("beta", 42), ("tau_1", 43), ("tau_2", 44), ("gamma", 45))},
+       for a, sd in (("d1", 61), ("tau_1_2", 41), ("beta", 70), ("tau_1", 43), ("tau_2", 93), ("gamma", 83))},
     # 'real noise' CSV dataset through the real get_large_scale_dataset / LargeScaleDataset + image files on disk
     "cars_cos_k5_real": dict(dataset="stanford_cars", n=400, d=32, seed=50,
                              argv=["--dataset", "stanford_cars", "--noise_type", "real", "--noise_level", "0", "--real_dataset",
