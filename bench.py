@@ -223,7 +223,15 @@ def bench_cifar(args, world, rank, dev):
 
     cfg = ClipConfig.named(args.arch)
     model = LemonCLIP(cfg)                       # seeded random init (no checkpoints offline)
-    emb = Embedder(model, dev, batch_size=args.encoder_batch, text_dedup=args.text_dedup)
+    # text micro-batch = a common divisor of the split sizes (5 000 at the headline shape): every micro-batch then has the
+    # same row count, so the same prompt gets the same GEMM shape -> the same bits wherever it is embedded (a short tail
+    # batch meets another hipBLASLt solution and differs in the last bit: 200 "distinct" prompt embeddings for 100 classes)
+    import math
+    tb = math.gcd(math.gcd(args.n_train, args.n_val), args.n_test)
+    while tb > 8 * args.encoder_batch and tb % 2 == 0:
+        tb //= 2
+    text_batch = tb if 2 * args.encoder_batch <= tb <= 8 * args.encoder_batch else None
+    emb = Embedder(model, dev, batch_size=args.encoder_batch, text_dedup=args.text_dedup, text_batch_size=text_batch)
     data = make_cifar_like(args, cfg, rank, dev)
     data["train"]["n_total"] = args.n_train * world
     algo = {"auto": None, "f32": _lib.ALGO_F32_MFMA, "bf16": _lib.ALGO_BF16_FILTER}[args.algo]
@@ -288,7 +296,7 @@ def bench_cifar(args, world, rank, dev):
                         f"{args.dist_type} brute-force kNN k={args.knn_k} over the all-gathered {args.n_train * world}-row DB, "
                         "multimodal-neighbour scores (beta=gamma=5,tau1=0.1,tau2=5)",
             "noise": "pair-flip 0.4 (reference's 'asymmetric'; 'cat' is not defined for CIFAR upstream)",
-            "encoder_batch": args.encoder_batch, "text_dedup": bool(args.text_dedup),
+            "encoder_batch": args.encoder_batch, "text_batch": emb.text_batch_size, "text_dedup": bool(args.text_dedup),
             "train_embedded_once": True, "parallelism": f"dp{world}+allgather",
             "gemm": "lemon_linear_f32 (hipBLASLt, recorded solution per shape, SiLU/residual epilogues)",
         },

@@ -88,6 +88,7 @@ struct ScanParamsH {
     // for every query panel, so that the chunk is re-read from the 256 MiB Infinity Cache instead of
     // HBM; per-query state (list length, admission bound) lives in `state` between launches
     int chunk_t0, chunk_t1, first_chunk, last_chunk;
+    int *cnt;                  // [grid * queries per workgroup][2]: half-list counts at the end of the scan, for k_bf16_final
     float *state;              // [grid*256 lanes][4]: {half-list count, last compacted length, thr_key, -}
     int ablate;                // diagnostics only (LEMON_ABLATE): 1 = skip the filter epilogue AND maintenance (nothing is
                                // appended), 4 = nothing passes the filter, 8 (phase-stamped build) = the tile-end wait for
@@ -829,23 +830,10 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
         st[0] = __int_as_float(ccnt); st[1] = __int_as_float(clast); st[2] = thkey;
         return;
     }
-    // ---- final pass: exact re-scoring + exact top-k of every query, then the result rows ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int r = 0; r < 32; ++r) {
-        const int row = 32 * wave + r;
-        const int64_t q = q0 + row;
-        if (q >= p.b.nq) break;
-        u64 *list = cand_panel + (int64_t)row * CAPH;
-        const int n0 = __builtin_amdgcn_readlane(ccnt, r), n1 = __builtin_amdgcn_readlane(ccnt, r + 32);
-        u64 kth;
-        const int have = qs_compact_exact(p, list, n0, n1, q, s_qn[row], lane, s_keys + wave * 256,
-                                          s_best + wave * 64, &kth);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const u64 key = (lane < have && lane < p.b.kk) ? list[lane] : 0;
-        write_out_row(p.b, split, q, lane, key);
-    }
+    // ---- end of the scan: the exact re-scoring + exact top-k of every query runs in its own kernel (k_bf16_final: one
+    // wave per query, many waves per CU); here only the half-list counts are handed over ----
+    p.cnt[2 * ((int64_t)blockIdx.x * BQ + qrow_l) + h] = ccnt;
 }
-
 
 // ======================================================================================
 // Q-stationary variant with TWO 32-query blocks per wave ("QS2").
@@ -1163,23 +1151,133 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs2(ScanParamsH p) {
         st[4] = __int_as_float(ccnt1); st[5] = __int_as_float(clast1); st[6] = thkey1;
         return;
     }
-    // ---- final pass: exact re-scoring + exact top-k of every query, then the result rows ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int r = 0; r < 64; ++r) {
-        const int row = 64 * wave + r;
-        const int64_t q = q0 + row;
-        if (q >= p.b.nq) break;
-        u64 *list = cand_panel + (int64_t)row * CAPH;
-        const int src = r & 31;
-        const int n0 = r < 32 ? __builtin_amdgcn_readlane(ccnt0, src) : __builtin_amdgcn_readlane(ccnt1, src);
-        const int n1 = r < 32 ? __builtin_amdgcn_readlane(ccnt0, src + 32) : __builtin_amdgcn_readlane(ccnt1, src + 32);
-        u64 kth;
-        const int have = qs_compact_exact(p, list, n0, n1, q, s_qn[row], lane, s_keys + wave * 256,
-                                          s_best + wave * 64, &kth);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const u64 key = (lane < have && lane < p.b.kk) ? list[lane] : 0;
-        write_out_row(p.b, split, q, lane, key);
+    // ---- end of the scan: counts for k_bf16_final (exact re-scoring + exact top-k, one wave per query) ----
+    p.cnt[2 * ((int64_t)blockIdx.x * BQ2 + qrow0) + h] = ccnt0;
+    p.cnt[2 * ((int64_t)blockIdx.x * BQ2 + qrow1) + h] = ccnt1;
+}
+
+// ======================================================================================
+// Final pass of the Q-stationary scans: exact fp32-chain re-scoring of every surviving candidate + exact top-k.
+//
+// Inside the scan kernel this ran with ONE wave per SIMD, one lane per candidate row, every lane walking its own 3 KB row
+// 16 B at a time: 64 cache lines per load instruction, four waves of loads in flight per CU.  Measured at 1 M x 768 (kernel
+// trace, 23 chunk launches per 524 288 queries): steady-state launch 28 ms, the LAST launch 87-93 ms -- the final pass was
+// 8.6 % of the whole scan.  Here one wave owns one query, many waves share a CU, candidate rows are fetched a full 128-B line
+// per 8 lanes and transposed through LDS (the K4 gather's scheme), the query row sits in LDS once and is read by broadcast.
+// Same fmaf chain in ascending k as exact_score(): bit-identical keys.
+// ======================================================================================
+constexpr int FIN_PITCH = 36;      // floats per transposed row (conflict-free 128-bit reads)
+
+struct FinalParams {
+    ScanParams b;              // D / I / part / nq / kk / metric / splits / nq_pad / xnorm / qnorm / cand
+    const float *q, *x;        // originals, row-major [nq, d], [n, d]
+    const int *cnt;            // [lists][2]
+    int d, rows_per_wg;        // queries per scan workgroup (128 / 256)
+    int64_t n_lists;
+};
+
+// dot(q, x_row) by the chain contract for 64 rows at once: lane l owns x_row (its candidate); rows are fetched one 128-B line
+// at a time -- lane (r8, c) fetches chunk c of rows r8, r8 + 8, ... -- transposed through `lx` [64][FIN_PITCH], and the next
+// line is in flight while the current one is consumed against q_lds (broadcast reads).  d % 4 == 0, 16-byte aligned rows.
+__device__ __forceinline__ float chain_dot_wave_q(const float *__restrict__ q_lds, const float *x_row, int d,
+                                                  float *__restrict__ lx, int lane) {
+    const int r8 = lane >> 3, c = lane & 7;
+#define FIN_PTR(i) const float *px##i = reinterpret_cast<const float *>(__shfl((unsigned long long)(uintptr_t)x_row, r8 + 8 * i)) + 4 * c;
+    FIN_PTR(0) FIN_PTR(1) FIN_PTR(2) FIN_PTR(3) FIN_PTR(4) FIN_PTR(5) FIN_PTR(6) FIN_PTR(7)
+#undef FIN_PTR
+    float4 v0, v1, v2, v3, v4, v5, v6, v7;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#define FIN_FETCH(koff)                                                                             \
+    do {                                                                                            \
+        if ((koff) + 4 * c < d) {                                                                   \
+            v0 = *reinterpret_cast<const float4 *>(px0 + (koff)); v1 = *reinterpret_cast<const float4 *>(px1 + (koff)); \
+            v2 = *reinterpret_cast<const float4 *>(px2 + (koff)); v3 = *reinterpret_cast<const float4 *>(px3 + (koff)); \
+            v4 = *reinterpret_cast<const float4 *>(px4 + (koff)); v5 = *reinterpret_cast<const float4 *>(px5 + (koff)); \
+            v6 = *reinterpret_cast<const float4 *>(px6 + (koff)); v7 = *reinterpret_cast<const float4 *>(px7 + (koff)); \
+        } else { v0 = v1 = v2 = v3 = v4 = v5 = v6 = v7 = zero; }                                    \
+    } while (0)
+#define FIN_STORE(i, v) *reinterpret_cast<float4 *>(&lx[(r8 + 8 * i) * FIN_PITCH + 4 * c]) = v;
+    FIN_FETCH(0);
+    float acc = 0.0f;
+    for (int k0 = 0; k0 < d; k0 += 32) {
+        FIN_STORE(0, v0) FIN_STORE(1, v1) FIN_STORE(2, v2) FIN_STORE(3, v3) FIN_STORE(4, v4) FIN_STORE(5, v5) FIN_STORE(6, v6) FIN_STORE(7, v7)
+        const int kn = k0 + 32;
+        if (kn < d) FIN_FETCH(kn);                       // wave-uniform: next 128 B of every row
+        __builtin_amdgcn_wave_barrier();
+        const int lim = d - k0 < 32 ? d - k0 : 32;       // wave-uniform; multiple of 4
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (4 * u < lim) {
+                const float4 xv = *reinterpret_cast<const float4 *>(&lx[lane * FIN_PITCH + 4 * u]);
+                const float4 qv = *reinterpret_cast<const float4 *>(&q_lds[k0 + 4 * u]);
+                acc = __builtin_fmaf(qv.x, xv.x, acc);
+                acc = __builtin_fmaf(qv.y, xv.y, acc);
+                acc = __builtin_fmaf(qv.z, xv.z, acc);
+                acc = __builtin_fmaf(qv.w, xv.w, acc);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
+#undef FIN_STORE
+#undef FIN_FETCH
+    return acc;
+}
+
+// one wave per candidate list (= per query, or per (query, database split)); STAGED needs d % 4 == 0
+template <bool l2, bool STAGED>
+__global__ __launch_bounds__(256) void k_bf16_final(FinalParams p) {
+    constexpr int DQ = 1024;                              // query row capacity in LDS (register-resident pitches: d <= 768)
+    __shared__ __attribute__((aligned(16))) float s_q[4][STAGED ? DQ : 4];
+    __shared__ __attribute__((aligned(16))) float s_x[4][STAGED ? 64 * FIN_PITCH : 4];
+    __shared__ __attribute__((aligned(16))) u64 s_keys[4][256];
+    __shared__ __attribute__((aligned(16))) u64 s_best[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t L = (int64_t)blockIdx.x * 4 + wave;     // list = (scan workgroup, row inside it)
+    if (L >= p.n_lists) return;
+    const int64_t wg = L / p.rows_per_wg;
+    const int row = (int)(L - wg * p.rows_per_wg);
+    const int64_t panel = wg / p.b.splits;
+    const int split = (int)(wg - panel * p.b.splits);
+    const int64_t q = panel * p.rows_per_wg + row;
+    if (q >= p.b.nq) return;
+    const u64 *list = p.b.cand + L * CAPH;
+    const int n0 = p.cnt[2 * L], n1 = p.cnt[2 * L + 1];
+    const int kk = p.b.kk, d = p.d;
+    const float *qrow = p.q + q * (int64_t)d;
+    const float qn = l2 ? p.b.qnorm[q] : 0.0f;
+    if (STAGED) {
+        for (int c4 = lane; c4 < d / 4; c4 += 64)
+            *reinterpret_cast<float4 *>(&s_q[wave][4 * c4]) = *reinterpret_cast<const float4 *>(qrow + 4 * c4);
+        __builtin_amdgcn_wave_barrier();
+    }
+    u64 best = 0;                                         // lane i: i-th best exact key so far
+    const int c = n0 + n1;
+#pragma unroll 1
+    for (int base = 0; base < c; base += 64) {
+        const int e = base + lane;
+        const bool valid = e < c;
+        const u64 old = valid ? list[e < n0 ? e : CAPH / 2 + (e - n0)] : 0;
+        const u32 j = valid ? lemon_key_index(old) : 0u;   // idle lanes shadow row 0 (always allocated)
+        const float *xrow = p.x + (int64_t)j * d;
+        float dot;
+        if (STAGED) dot = chain_dot_wave_q(s_q[wave], xrow, d, s_x[wave], lane);
+        else { dot = 0.0f; for (int t = 0; t < d; ++t) dot = __builtin_fmaf(qrow[t], xrow[t], dot); }
+        float sc = dot;
+        if (l2) {
+            const float dd = __builtin_fmaf(-2.0f, dot, qn + p.b.xnorm[j]);
+            sc = -(dd > 0.0f ? dd : 0.0f);
+        }
+        const u64 key = (valid && old && sc == sc) ? lemon_make_key(sc, j) : 0;   // NaN is never selected
+        const Ranked r = wave_rank_keys(best, key, 0, 0, 128, s_keys[wave], lane);
+        s_best[wave][lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (best && r.r0 < kk) s_best[wave][r.r0] = best;
+        if (key && r.r1 < kk) s_best[wave][r.r1] = key;
+        __builtin_amdgcn_wave_barrier();
+        best = s_best[wave][lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+    write_out_row(p.b, split, q, lane, lane < kk ? best : 0);
 }
 
 }  // namespace
@@ -1320,19 +1418,33 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
                 if (chunk_tiles < 8) chunk_tiles = 8;
             }
             if (chunk_tiles > n_tiles) chunk_tiles = n_tiles;
-            const int64_t state_elems = (int64_t)grid * NT * (qs2 ? 8 : 4);
-            if (state_elems > idx->ws_state_elems) {
-                LEMON_HIP_CHECK(hipStreamSynchronize(stream));
-                if (idx->ws_state) (void)hipFree(idx->ws_state);
-                idx->ws_state = nullptr; idx->ws_state_elems = 0;
-                if (hipMalloc(&idx->ws_state, (size_t)state_elems * sizeof(float)) != hipSuccess) {
-                    lemon_set_error("scan state allocation failed");
-                    return LEMON_E_NOMEM;
-                }
-                idx->ws_state_elems = state_elems;
+        }
+        // per-lane state carried between chunk launches (splits == 1) + the half-list counts handed to k_bf16_final
+        const int64_t state_elems = (qs && splits == 1) ? (int64_t)grid * NT * (qs2 ? 8 : 4) : 0;
+        const int64_t cnt_elems = qs ? (int64_t)grid * bqw * 2 : 0;
+        if (state_elems + cnt_elems > idx->ws_state_elems) {
+            LEMON_HIP_CHECK(hipStreamSynchronize(stream));
+            if (idx->ws_state) (void)hipFree(idx->ws_state);
+            idx->ws_state = nullptr; idx->ws_state_elems = 0;
+            if (hipMalloc(&idx->ws_state, (size_t)(state_elems + cnt_elems) * sizeof(float)) != hipSuccess) {
+                lemon_set_error("scan state allocation failed");
+                return LEMON_E_NOMEM;
             }
+            idx->ws_state_elems = state_elems + cnt_elems;
         }
         p.state = idx->ws_state;
+        p.cnt = reinterpret_cast<int *>(idx->ws_state + state_elems);
+        const bool l2m_ = idx->metric == LEMON_METRIC_L2;
+        FinalParams fp;
+        fp.b = p.b; fp.q = p.q; fp.x = p.x; fp.cnt = p.cnt; fp.d = d; fp.rows_per_wg = bqw; fp.n_lists = (int64_t)grid * bqw;
+        auto launch_final = [&]() {     // exact re-scoring + exact top-k of every (query, split) list, one wave each
+            const unsigned fg = (unsigned)((fp.n_lists + 3) / 4);
+            const bool staged = (d % 4) == 0 && d <= 1024;
+            if (l2m_) { if (staged) hipLaunchKernelGGL((k_bf16_final<true, true>), dim3(fg), dim3(256), 0, stream, fp);
+                        else        hipLaunchKernelGGL((k_bf16_final<true, false>), dim3(fg), dim3(256), 0, stream, fp); }
+            else      { if (staged) hipLaunchKernelGGL((k_bf16_final<false, true>), dim3(fg), dim3(256), 0, stream, fp);
+                        else        hipLaunchKernelGGL((k_bf16_final<false, false>), dim3(fg), dim3(256), 0, stream, fp); }
+        };
         const bool l2m = idx->metric == LEMON_METRIC_L2;
         for (int t0 = 0; t0 < n_tiles; t0 += chunk_tiles) {
             const int t1 = (t0 + chunk_tiles < n_tiles) ? t0 + chunk_tiles : n_tiles;
@@ -1355,11 +1467,13 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
                 fprintf(stderr, "[phase] grid=%u loop=%.1f%% epilogue=%.1f%% sync=%.1f%% maintain=%.1f%% total=%.3g cyc/WG=%.3g\n",
                         grid, 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, tot, tot / grid);
                 (void)hipMemset(dbg, 0, 64);
+                if (p.last_chunk) launch_final();
                 continue;
             }
             if (qs2) {
                 if (l2m) launch_qs2<true, false>(dpad_h / BKH, grid, stream, p);
                 else     launch_qs2<false, false>(dpad_h / BKH, grid, stream, p);
+                if (p.last_chunk) launch_final();
                 continue;
             }
             switch (qs ? dpad_h / BKH : 0) {
@@ -1377,6 +1491,7 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
                     break;
                 default: hipLaunchKernelGGL(k_scan_bf16, dim3(grid), dim3(NT), 0, stream, p); break;
             }
+            if (qs && p.last_chunk) launch_final();
         }
         LEMON_HIP_CHECK(hipGetLastError());
         if (splits > 1) {

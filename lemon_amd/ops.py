@@ -104,21 +104,24 @@ def grid_f1(rec, y, hparams, xtol=1e-8, maxfun=500, return_scores=False):
 ATTENTION_MAX_SEQ = 288
 ACT_NONE, ACT_SILU = 0, 1
 QUICK_GELU_SCALE = 1.702
-_linear_tuned_loaded = False
+_linear_tuned_loaded = set()      # device indices whose per-device hipBLASLt state has the recorded choices
 
 
-def _ensure_linear_tuned(lib):
-    """Hand the recorded hipBLASLt solution choices (lemon_amd/data/linear_gfx950.csv, or
-    $LEMON_LINEAR_TUNED) to the library once per process; keys not in the file are tuned on first use."""
-    global _linear_tuned_loaded
-    if _linear_tuned_loaded:
+def _ensure_linear_tuned(lib, device):
+    """Hand the recorded hipBLASLt solution choices (lemon_amd/data/linear_gfx950.csv, or $LEMON_LINEAR_TUNED) to the
+    library once per DEVICE: the library keeps one state per device (selected by hipGetDevice), so the file is loaded with
+    `device` current -- a rank on cuda:3 gets the same solutions (same embedding bits, same speed) as rank 0.  A key that is
+    not in the file uses the library's first-ranked solution (no timing; lemon_linear_set_tuning(1) turns timing on)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx in _linear_tuned_loaded:
         return
-    _linear_tuned_loaded = True
+    _linear_tuned_loaded.add(idx)
     import os
     path = os.environ.get("LEMON_LINEAR_TUNED",
                           os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "linear_gfx950.csv"))
     if path and os.path.exists(path):
-        lib.lemon_linear_load_tuned(path.encode())
+        with torch.cuda.device(device):
+            lib.lemon_linear_load_tuned(path.encode())
 
 
 def linear(x, weight, bias=None, residual=None, act=None, alpha=1.0):
@@ -138,7 +141,7 @@ def linear(x, weight, bias=None, residual=None, act=None, alpha=1.0):
     if bias is not None:
         bias = bias.contiguous()
     lib = _lib.load()
-    _ensure_linear_tuned(lib)
+    _ensure_linear_tuned(lib, x.device)
     code = {None: ACT_NONE, "silu": ACT_SILU}[act]
     with torch.cuda.device(x.device):
         _lib.check(lib.lemon_linear_f32(ptr(x), ptr(weight), ptr(bias) if bias is not None else None,

@@ -1,7 +1,7 @@
 """Copy the judged summaries of a tools/gpu_profile.sh run from gpurun_out/ into profiles/<tag>/.
 python tools/collect_profiles.py [tag]"""
 import csv, glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles", tag)
 os.makedirs(P, exist_ok=True)
@@ -51,3 +51,4 @@ for d, dst in ((f"prof_bench_{tag}", "bench_default_kernel_stats.csv"), (f"prof_
         shutil.copyfile(f, os.path.join(P, dst)); print(dst)
 write_pmc("bench_default_pmc.csv", [f"pmc_bench_fetch_{tag}", f"pmc_bench_write_{tag}", f"pmc_bench_mfma_{tag}"])
 write_pmc("knn_1000000x768_pmc.csv", [f"pmc_fetch_{tag}", f"pmc_write_{tag}", f"pmc_mfma_{tag}"])
+write_pmc("encoder_mfma_pmc.csv", [f"pmc_encoder_mfma_{tag}"])

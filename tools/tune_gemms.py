@@ -1,7 +1,8 @@
 """Regenerate lemon_amd/data/linear_gfx950.csv on an MI355X: one pass of the encoder workload with
 lemon_linear_f32 in tuning mode (benchmarking every GEMM key it meets), then dump the winners with the
 hipBLASLt-version / arch stamp the loader checks.
-Run via gpurun: python tools/tune_gemms.py [arch[:batch] ...] -> gpurun_out/linear_gfx950.csv"""
+Run via gpurun: python tools/tune_gemms.py [arch[:batch[:text_batch]] ...] -> gpurun_out/linear_gfx950.csv
+(text_batch defaults to 4 x batch, pipeline.Embedder's default; bench.py uses gcd(split sizes) = 5000 at the headline shape)"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("LEMON_LINEAR_TUNE_MS", "6000")
@@ -13,13 +14,14 @@ from lemon_amd.ops import linear_dump_tuned
 
 dev = torch.device("cuda:0")
 for spec in (sys.argv[1:] or ["vit-b-32:1000"]):
-    arch, _, bs = spec.partition(":")
+    arch, _, rest = spec.partition(":")
+    bs, _, tbs = rest.partition(":")
     cfg = ClipConfig.named(arch)
     bs = int(bs or 256)
+    tbs = int(tbs or 4 * bs)
     model = LemonCLIP(cfg).eval().to(dev)
     tok = SyntheticTokenizer(cfg.vocab_size, cfg.context_length, cfg.eos_token_id)
-    prompts = (["A photo of a " + l for l in ds.cifar100_labels] * (bs // 100 + 1))[:bs]
-    prompts = prompts * 4                                   # text micro-batch = 4 x image micro-batch (pipeline.Embedder)
+    prompts = (["A photo of a " + l for l in ds.cifar100_labels] * (tbs // 100 + 1))[:tbs]     # one text micro-batch
     ids = torch.tensor(tok(prompts, padding="max_length", truncation=True)["input_ids"]).to(dev)
     from lemon_amd.data import gpu_transform_batch
     u8 = torch.randint(0, 256, (bs, 32, 32, 3), dtype=torch.uint8, device=dev)
