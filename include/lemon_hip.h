@@ -150,6 +150,23 @@ int lemon_text_tokens(const int64_t *ids_dev, int64_t ids_pitch, const float *to
 #define LEMON_ACT_SILU 1
 int lemon_linear_f32(const float *x_dev, const float *w_dev, const float *bias_dev, const float *residual_dev,
                      int64_t m, int n, int k, float alpha, int act, float *y_dev, void *stream);
+
+/* The same nn.Linear (same reference call sites, same epilogues, same fp32 result type) with the products on the bf16
+ * matrix cores at fp32-equivalent accuracy: every fp32 operand value v is split EXACTLY into three bf16 parts
+ * (hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid): 24 significant bits) and the six cross products of order
+ * <= 2 are summed by ONE bf16 GEMM with fp32 accumulation over a 6k-long k axis:
+ *     x6_dev [m, 6k] rows = [hi | hi | mid | hi | mid | lo]   (lemon_layernorm_split3, or lemon_split3_f32 with weight = 0)
+ *     w6_dev [n, 6k] rows = [hi | mid | hi | lo | mid | hi]   (lemon_split3_f32 with weight = 1; once per weight)
+ * k6 = 6k.  The dropped products are O(2^-24) of the result; against float64 the max relative error at the ViT-B/32 tower
+ * shapes is 6e-9 (fp32 GEMM: 3e-7) -- tools/split_gemm_probe.py.  y_dev / bias_dev / residual_dev are float32. */
+int lemon_linear_bf16x6(const uint16_t *x6_dev, const uint16_t *w6_dev, const float *bias_dev, const float *residual_dev,
+                        int64_t m, int n, int k6, float alpha, int act, float *y_dev, void *stream);
+/* 3-way bf16 split of a row-major float32 matrix [rows, k] (k a multiple of 4) into lemon_linear_bf16x6's operand rows
+ * y6_dev [rows, 6k] bf16; weight = 0: activation layout, 1: weight layout. */
+int lemon_split3_f32(const float *x_dev, int64_t rows, int k, int weight, uint16_t *y6_dev, void *stream);
+/* lemon_layernorm_f32 whose result is written as the split activation operand y6_dev [rows, 6 width] bf16 (one pass). */
+int lemon_layernorm_split3(const float *x_dev, const float *weight_dev, const float *bias_dev, float eps, int64_t rows,
+                           int width, uint16_t *y6_dev, void *stream);
 /* Recorded solution choices: a "# lemon_linear hipblaslt=<version> arch=<gfx name>" stamp line followed by
  * "m,n,k,epilogue,residual,index,usec" lines.  load returns the number of keys taken -- 0 when the stamp
  * does not match this process's hipBLASLt version / device arch (the file is then ignored) -- and dump the

@@ -124,6 +124,8 @@ class Block(nn.Module):
             # inference on the GPU: every GEMM of the block goes through lemon_linear_f32 (bias, QuickGELU
             # and the residual adds ride in the hipBLASLt epilogue), attention through lemon_attention_f32
             from . import ops
+            if W % 4 == 0 and W <= 1024 and ops.gemm_mode() == "split":
+                return self._forward_split(x, causal, rows, ops)
             ln = lambda m, t: ops.layer_norm(t, m.weight, m.bias, m.eps) if t.shape[-1] % 4 == 0 else m(t)
             qkv = ops.linear(ln(self.ln1, x), self.qkv.weight, self.qkv.bias)
             if W == 64 * self.heads and L <= ops.ATTENTION_MAX_SEQ:
@@ -144,6 +146,36 @@ class Block(nn.Module):
         h = self.fc1(self.ln2(x))
         h = h * torch.sigmoid(1.702 * h)          # QuickGELU
         return x + self.fc2(h)
+
+    def _w6(self, name, ops):
+        """The layer's weight as the split bf16 operand [n, 6k], made once per weight version (inference: once)."""
+        w = getattr(self, name).weight
+        cache = self.__dict__.setdefault("_split_cache", {})
+        hit = cache.get(name)
+        if hit is None or hit[0] != (w.data_ptr(), w._version):
+            hit = ((w.data_ptr(), w._version), ops.split3(w.detach(), weight=True))
+            cache[name] = hit
+        return hit[1]
+
+    def _forward_split(self, x, causal, rows, ops):
+        """The fused inference path with the three k = width GEMMs of the block (QKV, output projection, fc1) on the bf16
+        matrix cores at fp32-equivalent accuracy (ops.linear_split3: exact 3-way bf16 splits of both operands, six cross
+        products, fp32 accumulate); LayerNorm writes the split operand directly.  fc2 (k = 4 width) stays an fp32 GEMM: its
+        activation operand would need a split pass over the [m, 4 width] MLP activations that costs what the faster GEMM
+        saves (tools/split_gemm_probe.py)."""
+        B, L, W = x.shape
+        qkv = ops.linear_split3(ops.layer_norm_split3(x, self.ln1.weight, self.ln1.bias, self.ln1.eps), self._w6("qkv", ops), self.qkv.bias)
+        if W == 64 * self.heads and L <= ops.ATTENTION_MAX_SEQ:
+            a = ops.attention(qkv, self.heads, causal)
+        else:
+            a = self._sdpa(qkv, B, L, W, causal)
+        if rows is not None:
+            a, x = a[rows].contiguous(), x[rows].contiguous()
+        x = ops.linear_split3(ops.split3(a), self._w6("out", ops), self.out.bias, residual=x)
+        s = ops.QUICK_GELU_SCALE
+        h = ops.linear_split3(ops.layer_norm_split3(x, self.ln2.weight, self.ln2.bias, self.ln2.eps), self._w6("fc1", ops),
+                              self.fc1.bias * s, act="silu", alpha=s)
+        return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=x, alpha=1.0 / s)
 
     def _sdpa(self, qkv, B, L, W, causal):
         q, k, v = qkv.view(B, L, 3, self.heads, W // self.heads).permute(2, 0, 3, 1, 4)

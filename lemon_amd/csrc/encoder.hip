@@ -11,7 +11,44 @@
 
 namespace {
 
-template <int CH>   // float4 chunks per lane: width <= 256*CH
+// ---- 3-way bf16 split of fp32 values (lemon_linear_bf16x6) ---------------------------------------------------------
+// v = hi + mid + lo with hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid): both differences are exact in fp32, so
+// the three parts carry 24 significant bits of v (|v - hi - mid - lo| <= 2^-25 |v|).  A row of the ACTIVATION operand is
+// stored as six k-long bf16 segments [hi | hi | mid | hi | mid | lo], a row of the WEIGHT operand as
+// [hi | mid | hi | lo | mid | hi]: the dot product of the two rows is the sum of the six cross products of order <= 2.
+typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+__device__ __forceinline__ float bf16_val(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ void split3(float v, unsigned short &hi, unsigned short &mid, unsigned short &lo) {
+    hi = bf16_bits(v);
+    const float r1 = v - bf16_val(hi);
+    mid = bf16_bits(r1);
+    lo = bf16_bits(r1 - bf16_val(mid));
+}
+// four consecutive k of one row -> the six segments (row6 = start of the row's 6k bf16, c = float4 chunk index)
+template <bool WEIGHT>
+__device__ __forceinline__ void store_split4(unsigned short *__restrict__ row6, int k, int c, float4 v) {
+    unsigned short h_[4], m_[4], l_[4];
+    split3(v.x, h_[0], m_[0], l_[0]); split3(v.y, h_[1], m_[1], l_[1]);
+    split3(v.z, h_[2], m_[2], l_[2]); split3(v.w, h_[3], m_[3], l_[3]);
+    const us4 hi = {h_[0], h_[1], h_[2], h_[3]}, mid = {m_[0], m_[1], m_[2], m_[3]}, lo = {l_[0], l_[1], l_[2], l_[3]};
+    us4 *o = reinterpret_cast<us4 *>(row6) + c;
+    const int seg = k >> 2;                               // us4 chunks per segment
+    if (WEIGHT) { o[0] = hi; o[seg] = mid; o[2 * seg] = hi; o[3 * seg] = lo; o[4 * seg] = mid; o[5 * seg] = hi; }
+    else        { o[0] = hi; o[seg] = hi; o[2 * seg] = mid; o[3 * seg] = hi; o[4 * seg] = mid; o[5 * seg] = lo; }
+}
+
+template <bool WEIGHT>
+__global__ __launch_bounds__(256) void k_split3_rows(const float *__restrict__ x, int64_t rows, int k, unsigned short *__restrict__ y6) {
+    const int nch = k >> 2;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * nch) return;
+    const int64_t r = t / nch;
+    const int c = (int)(t - r * nch);
+    store_split4<WEIGHT>(y6 + r * 6 * (int64_t)k, k, c, reinterpret_cast<const float4 *>(x + r * (int64_t)k)[c]);
+}
+
+template <int CH, bool SPLIT = false>   // float4 chunks per lane: width <= 256*CH; SPLIT: y is the [rows, 6 width] bf16 activation operand
 __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ w,
                                                    const float *__restrict__ b, float eps, int64_t rows, int width,
                                                    float *__restrict__ y) {
@@ -55,7 +92,8 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
             o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
             o.z = (v[i].z - mean) * rstd * ww.z + bb.z;
             o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
-            yr[c] = o;
+            if (SPLIT) store_split4<false>(reinterpret_cast<unsigned short *>(y) + row * 6 * (int64_t)width, width, c, o);
+            else yr[c] = o;
         }
     }
 }
@@ -179,6 +217,39 @@ extern "C" int lemon_layernorm_f32(const float *x_dev, const float *weight_dev, 
     if (width <= 512) hipLaunchKernelGGL(k_layernorm<2>, grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
     else if (width <= 1024) hipLaunchKernelGGL(k_layernorm<4>, grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
     else hipLaunchKernelGGL(k_layernorm<8>, grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}
+
+// LayerNorm whose output is the 3-way bf16 split activation operand of lemon_linear_bf16x6 ([rows, 6 width] bf16): the same
+// arithmetic as lemon_layernorm_f32 (the fp32 result is split, not recomputed), one pass.
+extern "C" int lemon_layernorm_split3(const float *x_dev, const float *weight_dev, const float *bias_dev, float eps,
+                                      int64_t rows, int width, uint16_t *y6_dev, void *stream_) {
+    LEMON_REQUIRE(rows >= 0 && width > 0 && (width & 3) == 0 && width <= 2048, "rows >= 0, width a multiple of 4, <= 2048");
+    if (rows == 0) return LEMON_OK;
+    LEMON_REQUIRE(x_dev && weight_dev && bias_dev && y6_dev, "null pointer");
+    LEMON_REQUIRE(((((uintptr_t)x_dev) | ((uintptr_t)weight_dev) | ((uintptr_t)bias_dev)) & 15) == 0 && (((uintptr_t)y6_dev) & 7) == 0,
+                  "aligned pointers");
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    float *y = reinterpret_cast<float *>(y6_dev);
+    if (width <= 512) hipLaunchKernelGGL((k_layernorm<2, true>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
+    else if (width <= 1024) hipLaunchKernelGGL((k_layernorm<4, true>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
+    else hipLaunchKernelGGL((k_layernorm<8, true>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}
+
+// 3-way bf16 split of a row-major fp32 matrix [rows, k] into the 6k-long operand rows of lemon_linear_bf16x6:
+// weight = 0: activation layout [hi | hi | mid | hi | mid | lo]; weight = 1: weight layout [hi | mid | hi | lo | mid | hi].
+extern "C" int lemon_split3_f32(const float *x_dev, int64_t rows, int k, int weight, uint16_t *y6_dev, void *stream_) {
+    LEMON_REQUIRE(rows >= 0 && k > 0 && (k & 3) == 0, "rows >= 0, k a multiple of 4");
+    if (rows == 0) return LEMON_OK;
+    LEMON_REQUIRE(x_dev && y6_dev && (((uintptr_t)x_dev) & 15) == 0 && (((uintptr_t)y6_dev) & 7) == 0, "aligned pointers");
+    const int64_t threads = rows * (k >> 2);
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    if (weight) hipLaunchKernelGGL(k_split3_rows<true>, grid, block, 0, (hipStream_t)stream_, x_dev, rows, k, y6_dev);
+    else hipLaunchKernelGGL(k_split3_rows<false>, grid, block, 0, (hipStream_t)stream_, x_dev, rows, k, y6_dev);
     LEMON_HIP_CHECK(hipGetLastError());
     return LEMON_OK;
 }

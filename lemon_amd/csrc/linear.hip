@@ -53,7 +53,7 @@ namespace {
         }                                                                                           \
     } while (0)
 
-typedef std::tuple<int64_t, int, int, int, int> LinKey;   // m, n, k, epilogue, has_residual
+typedef std::tuple<int64_t, int, int, int, int, int> LinKey;   // m, n, k, epilogue, has_residual, operand type (0 f32, 1 bf16)
 
 struct LinState {
     hipblasLtHandle_t handle = nullptr;
@@ -105,16 +105,23 @@ struct Problem {
 
 // Row-major y[m,n] = x[m,k] W[n,k]^T is, in hipBLASLt's column-major terms, D[n,m] = op_T(A[k,n]) B[k,m]
 // with A = W (ld k), B = x (ld k), C/D = residual/y (ld n); the bias runs along D's rows (n).
-int make_problem(Problem &p, int64_t m, int n, int k, int epilogue, const float *bias) {
+// dt = 1: A (weights) and B (activations) are bf16 -- the 6k-long concatenated split operands of lemon_linear_bf16x6 --
+// C / D / bias / scale type stay fp32, the products accumulate in fp32
+int make_problem(Problem &p, int64_t m, int n, int k, int epilogue, const float *bias, int dt = 0) {
     LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+    if (dt) {
+        const hipDataType bt = HIP_R_32F;
+        LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt)));
+    }
     const hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
     LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)));
     LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb)));
     const hipblasLtEpilogue_t epi = (hipblasLtEpilogue_t)epilogue;
     LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)));
     if (bias) LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
-    LT_CHECK(hipblasLtMatrixLayoutCreate(&p.la, HIP_R_32F, (uint64_t)k, (uint64_t)n, k));
-    LT_CHECK(hipblasLtMatrixLayoutCreate(&p.lb, HIP_R_32F, (uint64_t)k, (uint64_t)m, k));
+    const hipDataType ot = dt ? HIP_R_16BF : HIP_R_32F;
+    LT_CHECK(hipblasLtMatrixLayoutCreate(&p.la, ot, (uint64_t)k, (uint64_t)n, k));
+    LT_CHECK(hipblasLtMatrixLayoutCreate(&p.lb, ot, (uint64_t)k, (uint64_t)m, k));
     LT_CHECK(hipblasLtMatrixLayoutCreate(&p.lc, HIP_R_32F, (uint64_t)n, (uint64_t)m, n));
     return LEMON_OK;
 }
@@ -148,7 +155,7 @@ int ensure_state(hipStream_t stream) {
 }
 
 // time one candidate on the caller's stream (D = scratch so that an in-place residual is not accumulated)
-float time_algo(Problem &p, const hipblasLtMatmulAlgo_t &algo, const float *x, const float *w, const float *c,
+float time_algo(Problem &p, const hipblasLtMatmulAlgo_t &algo, const void *x, const void *w, const float *c,
                 float beta, float *d, int reps, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
     const float alpha = 1.0f;                            // timing only: the scale does not change the kernel
     if (hipblasLtMatmul(g_lin.handle, p.desc, &alpha, w, p.la, x, p.lb, &beta, c, p.lc, d, p.lc, &algo, g_lin.ws,
@@ -175,8 +182,9 @@ bool supported(Problem &p, hipblasLtMatmulAlgo_t &algo, float beta) {
 }
 
 // benchmark the solutions that support this problem; returns the winner (synchronises the stream)
-int tune(const LinKey &key, Problem &p, const float *x, const float *w, const float *residual, int64_t m, int n,
+int tune(const LinKey &key, Problem &p, const void *x, const void *w, const float *residual, int64_t m, int n,
          hipStream_t stream, hipblasLtMatmulAlgo_t *best_out) {
+    const hipDataType ot = std::get<5>(key) ? HIP_R_16BF : HIP_R_32F;
     const float beta = residual ? 1.0f : 0.0f;
     float *scratch = nullptr;
     LEMON_HIP_CHECK(hipMalloc((void **)&scratch, (size_t)m * n * sizeof(float)));
@@ -203,7 +211,7 @@ int tune(const LinKey &key, Problem &p, const float *x, const float *w, const fl
     {
         std::vector<hipblasLtMatmulHeuristicResult_t> all;
         if (hipblaslt_ext::getAllAlgos(g_lin.handle, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, HIPBLAS_OP_T, HIPBLAS_OP_N,
-                                       HIP_R_32F, HIP_R_32F, HIP_R_32F, HIP_R_32F, HIPBLAS_COMPUTE_32F,
+                                       ot, ot, HIP_R_32F, HIP_R_32F, HIPBLAS_COMPUTE_32F,
                                        all) == HIPBLAS_STATUS_SUCCESS)
             cand.insert(cand.end(), all.begin(), all.end());
     }
@@ -300,8 +308,8 @@ int first_ranked(Problem &p, float beta, hipblasLtMatmulAlgo_t *out) {
 
 // one-time check of a recorded solution index on the caller's operands: its output must agree with the first-ranked
 // solution's (synchronises the stream; runs once per key and process).  Returns 1 = agrees, 0 = rejected, <0 error.
-int recorded_agrees(Problem &p, const hipblasLtMatmulAlgo_t &rec, const hipblasLtMatmulAlgo_t &first, const float *x,
-                    const float *w, const float *residual, float alpha, int64_t m, int n, hipStream_t stream) {
+int recorded_agrees(Problem &p, const hipblasLtMatmulAlgo_t &rec, const hipblasLtMatmulAlgo_t &first, const void *x,
+                    const void *w, const float *residual, float alpha, int64_t m, int n, hipStream_t stream) {
     const float beta = residual ? 1.0f : 0.0f;
     const int64_t cnt = (int64_t)m * n;
     float *buf = nullptr;
@@ -343,8 +351,8 @@ extern "C" int lemon_linear_set_tuning(int enabled) {
     return LEMON_OK;
 }
 
-extern "C" int lemon_linear_f32(const float *x_dev, const float *w_dev, const float *bias_dev, const float *residual_dev,
-                                int64_t m, int n, int k, float alpha, int act, float *y_dev, void *stream_) {
+static int linear_impl(int dt, const void *x_dev, const void *w_dev, const float *bias_dev, const float *residual_dev,
+                       int64_t m, int n, int k, float alpha, int act, float *y_dev, void *stream_) {
     LEMON_REQUIRE(m >= 0 && n > 0 && k > 0, "m >= 0, n > 0, k > 0");
     LEMON_REQUIRE(act == LEMON_ACT_NONE || act == LEMON_ACT_SILU, "act must be LEMON_ACT_NONE or LEMON_ACT_SILU");
     LEMON_REQUIRE(!(act != LEMON_ACT_NONE && residual_dev), "activation and residual cannot be combined");
@@ -357,10 +365,10 @@ extern "C" int lemon_linear_f32(const float *x_dev, const float *w_dev, const fl
     int epilogue = HIPBLASLT_EPILOGUE_DEFAULT;
     if (act == LEMON_ACT_SILU) epilogue = bias_dev ? HIPBLASLT_EPILOGUE_SWISH_BIAS_EXT : HIPBLASLT_EPILOGUE_SWISH_EXT;
     else if (bias_dev) epilogue = HIPBLASLT_EPILOGUE_BIAS;
-    const LinKey key(m, n, k, epilogue, residual_dev ? 1 : 0);
+    const LinKey key(m, n, k, epilogue, residual_dev ? 1 : 0, dt);
     const float beta = residual_dev ? 1.0f : 0.0f;
     Problem p;
-    rc = make_problem(p, m, n, k, epilogue, bias_dev);
+    rc = make_problem(p, m, n, k, epilogue, bias_dev, dt);
     if (rc) return rc;
 
     hipblasLtMatmulAlgo_t algo;
@@ -406,6 +414,24 @@ extern "C" int lemon_linear_f32(const float *x_dev, const float *w_dev, const fl
     return LEMON_OK;
 }
 
+extern "C" int lemon_linear_f32(const float *x_dev, const float *w_dev, const float *bias_dev, const float *residual_dev,
+                                int64_t m, int n, int k, float alpha, int act, float *y_dev, void *stream_) {
+    return linear_impl(0, x_dev, w_dev, bias_dev, residual_dev, m, n, k, alpha, act, y_dev, stream_);
+}
+
+// fp32-equivalent linear layer on the bf16 matrix cores: x6 [m, 6k] and w6 [n, 6k] are the 3-way bf16 splits of the fp32
+// operands (x = hi + mid + lo, each part bf16; lemon_split3_f32 / lemon_layernorm_split3) laid out so that ONE bf16 GEMM over
+// the 6k-long k axis sums the six cross products of order <= 2 (hi.hi, hi.mid, mid.hi, hi.lo, mid.mid, lo.hi) in fp32:
+//     x6 row = [hi | hi | mid | hi | mid | lo],   w6 row = [hi | mid | hi | lo | mid | hi].
+// The dropped products are O(2^-24) of the result: measured against float64 the emulation is MORE accurate than the fp32
+// GEMM (6e-9 vs 3e-7 max relative error at the tower shapes, tools/split_gemm_probe.py) and 1.7-2.0x faster.
+// k6 = 6 k.  Same epilogues, same solution policy (keys carry the operand type) as lemon_linear_f32.
+extern "C" int lemon_linear_bf16x6(const uint16_t *x6_dev, const uint16_t *w6_dev, const float *bias_dev, const float *residual_dev,
+                                   int64_t m, int n, int k6, float alpha, int act, float *y_dev, void *stream_) {
+    LEMON_REQUIRE(k6 % 6 == 0, "k6 must be 6 * k");
+    return linear_impl(1, x6_dev, w6_dev, bias_dev, residual_dev, m, n, k6, alpha, act, y_dev, stream_);
+}
+
 // Results file: first line "# lemon_linear hipblaslt=<int> arch=<name>", then m,n,k,epilogue,residual,index,usec rows.
 // Returns the number of keys taken (0 when the stamp does not match this process's library / device), <0 on error.
 extern "C" int lemon_linear_load_tuned(const char *path) {
@@ -430,9 +456,9 @@ extern "C" int lemon_linear_load_tuned(const char *path) {
             }
             continue;
         }
-        long long m; int n, k, epi, res, index; float us;
-        if (stamped && sscanf(line, "%lld,%d,%d,%d,%d,%d,%f", &m, &n, &k, &epi, &res, &index, &us) == 7) {
-            const LinKey key((int64_t)m, n, k, epi, res);
+        long long m; int n, k, epi, res, index, dt = 0; float us;
+        if (stamped && sscanf(line, "%lld,%d,%d,%d,%d,%d,%f,%d", &m, &n, &k, &epi, &res, &index, &us, &dt) >= 7) {
+            const LinKey key((int64_t)m, n, k, epi, res, dt);
             if (!g_lin.algo.count(key)) { g_lin.index[key] = index; g_lin.usec[key] = us; g_lin.from_file[key] = true; ++loaded; }
         }
     }
@@ -448,12 +474,14 @@ extern "C" int lemon_linear_dump_tuned(const char *path) {
     FILE *f = fopen(path, "w");
     if (!f) { lemon_set_error("cannot write %s", path); return LEMON_E_INVALID; }
     fprintf(f, "# lemon_linear hipblaslt=%d arch=%s\n", g_lin.version, g_lin.arch);
-    fprintf(f, "# m,n,k,epilogue,residual,hipblaslt_solution_index,usec   (fp32, y = act(x W^T + b) [+ residual])\n");
+    fprintf(f, "# m,n,k,epilogue,residual,hipblaslt_solution_index,usec[,operand type: 1 = bf16 split operands, k = 6 x the layer's k]   (y = act(x W^T + b) [+ residual])\n");
     int rows = 0;
     for (const auto &kv : g_lin.index) {
         const LinKey &key = kv.first;
-        fprintf(f, "%lld,%d,%d,%d,%d,%d,%.2f\n", (long long)std::get<0>(key), std::get<1>(key), std::get<2>(key),
+        fprintf(f, "%lld,%d,%d,%d,%d,%d,%.2f", (long long)std::get<0>(key), std::get<1>(key), std::get<2>(key),
                 std::get<3>(key), std::get<4>(key), kv.second, g_lin.usec.count(key) ? g_lin.usec[key] : 0.0f);
+        if (std::get<5>(key)) fprintf(f, ",%d", std::get<5>(key));
+        fprintf(f, "\n");
         ++rows;
     }
     fclose(f);

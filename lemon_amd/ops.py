@@ -150,6 +150,61 @@ def linear(x, weight, bias=None, residual=None, act=None, alpha=1.0):
     return y
 
 
+# ---- fp32-equivalent GEMMs on the bf16 matrix cores (3-way split operands, lemon_linear_bf16x6) -------------------------
+def gemm_mode():
+    """'split' (default): the tower GEMMs with k <= 1024 run as 3-way bf16 split GEMMs (fp32-equivalent accuracy, 1.7-2x the
+    fp32 MFMA rate); 'f32': every GEMM on the fp32 matrix cores (LEMON_GEMM=f32)."""
+    import os
+    return "f32" if os.environ.get("LEMON_GEMM", "split").lower() in ("f32", "fp32", "0") else "split"
+
+
+def split3(x, weight=False):
+    """float32 [..., k] -> bf16 [..., 6k] split operand rows (activation layout, or the weight layout)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0
+    x = x.contiguous()
+    k = x.shape[-1]
+    y = torch.empty(x.shape[:-1] + (6 * k,), dtype=torch.bfloat16, device=x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.lemon_split3_f32(ptr(x), x.numel() // k, k, int(bool(weight)), ptr(y), stream_ptr(x.device)), "lemon_split3_f32")
+    return y
+
+
+def layer_norm_split3(x, weight, bias, eps=1e-5):
+    """LayerNorm whose output is the split activation operand [..., 6 width] bf16 (one pass: lemon_layernorm_split3)."""
+    assert x.is_cuda and x.dtype == torch.float32
+    x = x.contiguous()
+    width = x.shape[-1]
+    y = torch.empty(x.shape[:-1] + (6 * width,), dtype=torch.bfloat16, device=x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.lemon_layernorm_split3(ptr(x), ptr(weight.contiguous()), ptr(bias.contiguous()), float(eps),
+                                              x.numel() // width, width, ptr(y), stream_ptr(x.device)), "lemon_layernorm_split3")
+    return y
+
+
+def linear_split3(x6, w6, bias=None, residual=None, act=None, alpha=1.0):
+    """y = act(alpha * x @ W.T + bias) (+ residual), float32, from the split operands x6 [..., 6k], w6 [n, 6k] (bf16)."""
+    assert x6.is_cuda and x6.dtype == torch.bfloat16 and w6.dtype == torch.bfloat16 and x6.shape[-1] == w6.shape[1]
+    x6, w6 = x6.contiguous(), w6.contiguous()
+    k6, n = x6.shape[-1], w6.shape[0]
+    m = x6.numel() // k6
+    y = torch.empty(x6.shape[:-1] + (n,), dtype=torch.float32, device=x6.device)
+    if residual is not None:
+        assert residual.shape == y.shape and residual.dtype == torch.float32
+        residual = residual.contiguous()
+    if bias is not None:
+        bias = bias.contiguous()
+    lib = _lib.load()
+    _ensure_linear_tuned(lib, x6.device)
+    code = {None: ACT_NONE, "silu": ACT_SILU}[act]
+    with torch.cuda.device(x6.device):
+        _lib.check(lib.lemon_linear_bf16x6(ptr(x6), ptr(w6), ptr(bias) if bias is not None else None,
+                                           ptr(residual) if residual is not None else None, m, n, k6, float(alpha), code, ptr(y),
+                                           stream_ptr(x6.device)), "lemon_linear_bf16x6")
+    return y
+
+
 def layer_norm(x, weight, bias, eps=1e-5):
     """nn.LayerNorm over the last dimension of a float32 CUDA tensor in one HIP pass (lemon_layernorm_f32)."""
     assert x.is_cuda and x.dtype == torch.float32

@@ -523,6 +523,55 @@ def test_fused_attention_matches_float64_reference(hip, B, L, H, causal):
     assert (got - ref).abs().max() < 2e-5, (got - ref).abs().max()
 
 
+def test_split3_parts_are_exact_and_layernorm_split_equals_layernorm_then_split(hip):
+    # lemon_split3_f32: v = hi + mid + lo in bf16 with exact differences (24 significant bits); both operand layouts;
+    # lemon_layernorm_split3 == lemon_layernorm_f32 followed by the split, bit for bit
+    from lemon_amd.ops import layer_norm, layer_norm_split3, split3
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(37, 96, generator=g) * torch.exp(torch.randn(37, 1, generator=g) * 3)).cuda()
+    x[3, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1e-38, 65504.0])
+    for weight, order in ((False, (0, 0, 1, 0, 1, 2)), (True, (0, 1, 0, 2, 1, 0))):
+        y = split3(x, weight=weight).view(37, 6, 96).float().double().cpu()
+        parts = [y[:, order.index(i)] for i in range(3)]                      # hi, mid, lo
+        for seg, which in enumerate(order):
+            assert torch.equal(y[:, seg], parts[which])
+        err = (parts[0] + parts[1] + parts[2] - x.double().cpu()).abs()
+        assert bool((err <= x.double().cpu().abs() * 2.0 ** -24 + 1e-45).all()), err.max()
+        assert torch.equal(parts[0].float(), x.cpu().to(torch.bfloat16).float())                       # hi = RNE bf16(x)
+    w, b = torch.randn(96, generator=g).cuda(), torch.randn(96, generator=g).cuda()
+    assert torch.equal(layer_norm_split3(x, w, b), split3(layer_norm(x, w, b)))
+
+
+@pytest.mark.parametrize("m,n,k", [(100, 64, 48), (7, 512, 512), (3000, 2304, 768), (2500, 768, 3072), (5000, 1536, 512), (1, 32, 40)])
+@pytest.mark.parametrize("mode", ["plain", "bias", "bias_gelu", "bias_residual"])
+def test_split_bf16x3_linear_is_at_least_as_accurate_as_the_fp32_gemm(hip, m, n, k, mode):
+    # lemon_linear_bf16x6 against float64: the six-product emulation must meet the bar of the fp32 GEMM test below AND be no
+    # worse than the fp32 GEMM itself on the same operands (measured: ~50x better)
+    from lemon_amd.ops import linear, linear_split3, split3
+    g = torch.Generator().manual_seed(m * 7 + n * 3 + k)
+    x, w = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g) if "bias" in mode else None
+    r = torch.randn(m, n, generator=g) if "residual" in mode else None
+    ref = x.double() @ w.double().T
+    if b is not None:
+        ref = ref + b.double()
+    if "gelu" in mode:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    if r is not None:
+        ref = ref + r.double()
+    x6, w6 = split3(x.cuda()), split3(w.cuda(), weight=True)
+    bc, rc = (None if b is None else b.cuda()), (None if r is None else r.cuda())
+    if "gelu" in mode:
+        got = linear_split3(x6, w6, 1.702 * bc, None, "silu", alpha=1.702).cpu().double() / 1.702
+        f32 = linear(x.cuda(), w.cuda(), 1.702 * bc, None, "silu", alpha=1.702).cpu().double() / 1.702
+    else:
+        got = linear_split3(x6, w6, bc, rc).cpu().double()
+        f32 = linear(x.cuda(), w.cuda(), bc, rc).cpu().double()
+    e_split, e_f32 = float((got - ref).abs().max()), float((f32 - ref).abs().max())
+    assert e_split < 2e-5 * max(1.0, k ** 0.5 / 8), e_split
+    assert e_split <= 1.5 * e_f32 + 1e-6, (e_split, e_f32)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("m,n,k", [(100, 64, 48), (7, 512, 512), (3000, 2304, 768), (2500, 768, 3072), (1, 32, 40)])
 @pytest.mark.parametrize("mode", ["plain", "bias", "bias_gelu", "gelu", "bias_residual", "residual"])

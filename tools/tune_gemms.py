@@ -27,9 +27,11 @@ for spec in (sys.argv[1:] or ["vit-b-32:1000"]):
     u8 = torch.randint(0, 256, (bs, 32, 32, 3), dtype=torch.uint8, device=dev)
     px = gpu_transform_batch(u8, cfg.image_size, patch=cfg.patch_size)      # patch-major: the patch embedding is a GEMM
     t0 = time.perf_counter()
-    with torch.no_grad():
-        model.encode_image(px); model.encode_text(ids); model.encode_text(ids[:bs])
-    torch.cuda.synchronize()
+    for mode in ("split", "f32"):          # both GEMM modes of lemon_amd/clip.py meet their keys (bf16 split operands / fp32)
+        os.environ["LEMON_GEMM"] = mode
+        with torch.no_grad():
+            model.encode_image(px); model.encode_text(ids); model.encode_text(ids[:bs])
+        torch.cuda.synchronize()
     print(spec, "tuned in", round(time.perf_counter() - t0, 1), "s", flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
 print(linear_dump_tuned("gpurun_out/linear_gfx950.csv"), "keys written")
