@@ -88,6 +88,7 @@ def parse():
                     help="u8: raw 32x32 uint8 images resident in HBM, preprocessing (bicubic resize to 224, normalise) "
                          "inside the timed step; f32: already preprocessed pixel tensors")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_f32_gemm_check", action="store_true", help="skip the extra untimed step with every GEMM in fp32")
     ap.add_argument("--cpu_sample_images", type=int, default=96)
     ap.add_argument("--cpu_sample_queries", type=int, default=2048)
     ap.add_argument("--no_knn_1m", action="store_true",
@@ -285,6 +286,13 @@ def bench_cifar(args, world, rank, dev):
     f_img, f_txt = encoder_flops(cfg, n_tokens_text=model.text.seq_len_for(int(data["train"]["ids"].argmax(-1).max().item())))
 
     value = n_scored * world * args.steps / elapsed
+    from lemon_amd.ops import gemm_mode as _gm
+    gemm_mode = _gm()
+    gemm_note = ("tower GEMMs with k = width (QKV, output projection, fc1): lemon_linear_bf16x6 -- both fp32 operands split EXACTLY into "
+                 "three bf16 parts, the six cross products of order <= 2 summed by one hipBLASLt bf16 GEMM with fp32 accumulation "
+                 "(max relative error vs float64 6e-9, fp32 GEMM 3e-7; LEMON_GEMM=f32 switches it off); fc2 / patch embedding / "
+                 "projections: lemon_linear_f32; recorded solution per shape, bias / SiLU / residual epilogues"
+                 if gemm_mode == "split" else "lemon_linear_f32 (hipBLASLt fp32, recorded solution per shape, SiLU/residual epilogues)")
     line = {
         "metric": "label-error scores/sec (embed+kNN), CIFAR-100 noise=0.4",
         "value": value, "unit": "scores/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -298,14 +306,27 @@ def bench_cifar(args, world, rank, dev):
             "noise": "pair-flip 0.4 (reference's 'asymmetric'; 'cat' is not defined for CIFAR upstream)",
             "encoder_batch": args.encoder_batch, "text_batch": emb.text_batch_size, "text_dedup": bool(args.text_dedup),
             "train_embedded_once": True, "parallelism": f"dp{world}+allgather",
-            "gemm": "lemon_linear_f32 (hipBLASLt, recorded solution per shape, SiLU/residual epilogues)",
+            "gemm": gemm_note,
         },
         "stages_s": {k_: v for k_, v in stage.items()},
-        "encoder": {"bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_MFMA_TFLOPS,
+        "encoder": {"bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_MFMA_TFLOPS, "gemm_mode": gemm_mode,
                     "achieved": (f_img + f_txt) * n_scored / max(stage["embed_s"], 1e-9) / 1e12,
-                    "note": "algorithmic forward FLOPs (img+txt) / embed stage wall time; fp32 hipBLASLt GEMMs via lemon_linear_f32 "
-                            "(bias/SiLU/residual epilogues) + lemon_attention_f32"},
+                    "note": "algorithmic forward FLOPs (img+txt) of the fp32 model / embed stage wall time, against the fp32 MFMA peak; "
+                            "in gemm_mode 'split' the QKV / output-projection / fc1 GEMMs run as 3-way bf16 split GEMMs (fp32-equivalent "
+                            "results, bf16 MFMA peak / 6 = 416.7 TFLOP/s-equivalent), fc2 and the patch embedding stay fp32 GEMMs"},
     }
+    if gemm_mode == "split" and world == 1 and not args.no_f32_gemm_check:
+        # the same step once more, untimed region of its own, with every GEMM on the fp32 matrix cores (LEMON_GEMM=f32): what
+        # the split GEMMs buy, and the score difference between the two modes on the val split
+        os.environ["LEMON_GEMM"] = "f32"
+        t32 = {}
+        recs32, _ = step(timers=t32)
+        os.environ["LEMON_GEMM"] = "split"
+        ds_ = (recs32["val"]["score"] - recs["val"]["score"]).abs().max().item()
+        line["encoder_f32_gemm_mode"] = {"embed_s": t32["embed_s"], "achieved": (f_img + f_txt) * n_scored / max(t32["embed_s"], 1e-9) / 1e12,
+                                         "unit": "TFLOP/s", "max_abs_val_score_diff_vs_split": ds_,
+                                         "max_abs_val_embedding_diff_vs_split": float((recs32["val"]["emb_img"] - recs["val"]["emb_img"]).abs().max().item())}
+        del recs32
     if prof["launches"]:
         sec = prof["kernel_ms"] / 1e3
         tf = prof["algo_flops"] / sec / 1e12

@@ -110,6 +110,10 @@ int lemon_preprocess_u8(const uint8_t *img_dev, int64_t batch, int in_h, int in_
  * concatenated, ready for the output projection.  head_dim must be 64, seq_len <= 288. */
 int lemon_attention_f32(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
                         int causal, float *out_dev, void *stream);
+/* The same attention with the result written as the 3-way bf16 split activation operand of lemon_linear_bf16x6 (below):
+ * out6_dev [batch*seq_len, 6*heads*64] bf16, 16-byte aligned.  The fp32 result is split at the store, not recomputed. */
+int lemon_attention_split3(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
+                           int causal, uint16_t *out6_dev, void *stream);
 
 /* LayerNorm over the last dimension, float32: y = (x - mean) / sqrt(var + eps) * weight + bias (biased variance, like
  * torch.nn.LayerNorm) -- layer_norm1/2, pre_layrnorm, post_layernorm, final_layer_norm of the towers behind

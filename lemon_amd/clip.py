@@ -165,13 +165,15 @@ class Block(nn.Module):
         saves (tools/split_gemm_probe.py)."""
         B, L, W = x.shape
         qkv = ops.linear_split3(ops.layer_norm_split3(x, self.ln1.weight, self.ln1.bias, self.ln1.eps), self._w6("qkv", ops), self.qkv.bias)
-        if W == 64 * self.heads and L <= ops.ATTENTION_MAX_SEQ:
-            a = ops.attention(qkv, self.heads, causal)
+        hip_attn = W == 64 * self.heads and L <= ops.ATTENTION_MAX_SEQ
+        if hip_attn and rows is None:
+            a6 = ops.attention_split3(qkv, self.heads, causal)      # the attention kernel stores the split operand itself
         else:
-            a = self._sdpa(qkv, B, L, W, causal)
-        if rows is not None:
-            a, x = a[rows].contiguous(), x[rows].contiguous()
-        x = ops.linear_split3(ops.split3(a), self._w6("out", ops), self.out.bias, residual=x)
+            a = ops.attention(qkv, self.heads, causal) if hip_attn else self._sdpa(qkv, B, L, W, causal)
+            if rows is not None:
+                a, x = a[rows].contiguous(), x[rows].contiguous()
+            a6 = ops.split3(a)
+        x = ops.linear_split3(a6, self._w6("out", ops), self.out.bias, residual=x)
         s = ops.QUICK_GELU_SCALE
         h = ops.linear_split3(ops.layer_norm_split3(x, self.ln2.weight, self.ln2.bias, self.ln2.eps), self._w6("fc1", ops),
                               self.fc1.bias * s, act="silu", alpha=s)

@@ -265,6 +265,20 @@ def attention(qkv, heads, causal=False):
     return out
 
 
+def attention_split3(qkv, heads, causal=False):
+    """attention() whose output is the split activation operand [B, L, 6*W] bf16 (lemon_attention_split3)."""
+    assert qkv.is_cuda and qkv.dtype == torch.float32 and qkv.is_contiguous() and qkv.dim() == 3
+    B, L, W3 = qkv.shape
+    W = W3 // 3
+    assert W3 == 3 * W and W == heads * 64 and L <= ATTENTION_MAX_SEQ
+    out = torch.empty((B, L, 6 * W), dtype=torch.bfloat16, device=qkv.device)
+    lib = _lib.load()
+    with torch.cuda.device(qkv.device):
+        _lib.check(lib.lemon_attention_split3(ptr(qkv), B, L, heads, 64, int(bool(causal)), ptr(out),
+                                              stream_ptr(qkv.device)), "lemon_attention_split3")
+    return out
+
+
 def paired_distance(metric, a, b):
     a, b = dev_f32(a, "a"), dev_f32(b, "b")
     assert a.shape == b.shape and a.dim() == 2

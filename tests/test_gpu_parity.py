@@ -523,6 +523,15 @@ def test_fused_attention_matches_float64_reference(hip, B, L, H, causal):
     assert (got - ref).abs().max() < 2e-5, (got - ref).abs().max()
 
 
+@pytest.mark.parametrize("B,L,H,causal", [(3, 50, 12, False), (5, 8, 8, True), (2, 77, 8, True), (2, 197, 12, False)])
+def test_attention_split_output_equals_split_of_attention(hip, B, L, H, causal):
+    # lemon_attention_split3 stores the 3-way split of exactly the values lemon_attention_f32 stores (all three kernels)
+    from lemon_amd.ops import attention, attention_split3, split3
+    g = torch.Generator().manual_seed(B * 100 + L)
+    qkv = torch.randn(B, L, 3 * H * 64, generator=g).cuda()
+    assert torch.equal(attention_split3(qkv, H, causal), split3(attention(qkv, H, causal)))
+
+
 def test_split3_parts_are_exact_and_layernorm_split_equals_layernorm_then_split(hip):
     # lemon_split3_f32: v = hi + mid + lo in bf16 with exact differences (24 significant bits); both operand layouts;
     # lemon_layernorm_split3 == lemon_layernorm_f32 followed by the split, bit for bit
