@@ -545,7 +545,7 @@ def test_split3_parts_are_exact_and_layernorm_split_equals_layernorm_then_split(
         for seg, which in enumerate(order):
             assert torch.equal(y[:, seg], parts[which])
         err = (parts[0] + parts[1] + parts[2] - x.double().cpu()).abs()
-        assert bool((err <= x.double().cpu().abs() * 2.0 ** -24 + 1e-45).all()), err.max()
+        assert bool((err <= x.double().cpu().abs() * 2.0 ** -24 + 1e-40).all()), err.max()      # (+ one bf16 subnormal step)
         assert torch.equal(parts[0].float(), x.cpu().to(torch.bfloat16).float())                       # hi = RNE bf16(x)
     w, b = torch.randn(96, generator=g).cuda(), torch.randn(96, generator=g).cuda()
     assert torch.equal(layer_norm_split3(x, w, b), split3(layer_norm(x, w, b)))
