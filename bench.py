@@ -41,14 +41,15 @@ def pmc_traffic(kernel_substr):
                  if os.path.exists(p)), None)
     if path is None:
         return None, None
-    acc = {"FETCH_SIZE": [], "WRITE_SIZE": []}
+    # the dominant launch = the longest-running group of this kernel (the summary keeps launches of different problems apart)
+    best = {}
     for r in csv.DictReader(open(path)):
-        if kernel_substr in r["kernel"] and r["counter"] in acc and int(r["grid"]) >= 256 * 256:
-            acc[r["counter"]].append(float(r["value_KB"]))
-    if not acc["FETCH_SIZE"] or not acc["WRITE_SIZE"]:
+        if kernel_substr in r["kernel"] and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE") and int(r["grid"]) >= 256 * 256:
+            if r["counter"] not in best or float(r["dur_ms"]) > float(best[r["counter"]]["dur_ms"]):
+                best[r["counter"]] = r
+    if len(best) < 2:
         return None, None
-    mean = lambda v: sum(v) / len(v)
-    return (2.0 * mean(acc["FETCH_SIZE"]) + mean(acc["WRITE_SIZE"])) * 1024.0, os.path.relpath(path, ROOT)
+    return (2.0 * float(best["FETCH_SIZE"]["value_KB"]) + float(best["WRITE_SIZE"]["value_KB"])) * 1024.0, os.path.relpath(path, ROOT)
 
 
 def sustained_bf16_peak():

@@ -185,22 +185,40 @@ __global__ __launch_bounds__(64 * TJ) void k_attention_hd64_short(const float *_
         if (r < L) kreg[i] = *reinterpret_cast<const float4 *>(base + (int64_t)r * tok_stride + 4 * c + H * HD);
     }
     const int qi = 32 * wave + l31;
-    const int qrow = qi < L ? qi : L - 1;
+    // Q like K and V: 16 lanes fetch one token's 256 B (a lane walking its OWN row 16 B at a time touches 64 different
+    // lines per load instruction), then the tile goes through the LDS buffer once so that every lane can pick up its
+    // query's half row.  Rows >= L are zero (their queries are never stored).
+    {
+        float4 qreg[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int id = tid + i * 64 * TJ, r = id >> 4, c = id & 15;
+            qreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < L) qreg[i] = *reinterpret_cast<const float4 *>(base + (int64_t)r * tok_stride + 4 * c);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int id = tid + i * 64 * TJ, r = id >> 4, c = id & 15;
+            vreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < L) vreg[i] = *reinterpret_cast<const float4 *>(base + (int64_t)r * tok_stride + 4 * c + 2 * H * HD);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int id = tid + i * 64 * TJ, r = id >> 4, c = id & 15;
+            *reinterpret_cast<float4 *>(&sKV[r * PITCH + 4 * c]) = qreg[i];
+        }
+    }
+    __syncthreads();
     float q[32];
     {
-        const float *src = base + (int64_t)qrow * tok_stride + 32 * h;
+        const float *src = &sKV[qi * PITCH + 32 * h];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const float4 t = *reinterpret_cast<const float4 *>(src + 4 * u);
             q[4 * u] = t.x; q[4 * u + 1] = t.y; q[4 * u + 2] = t.z; q[4 * u + 3] = t.w;
         }
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int id = tid + i * 64 * TJ, r = id >> 4, c = id & 15;
-        vreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < L) vreg[i] = *reinterpret_cast<const float4 *>(base + (int64_t)r * tok_stride + 4 * c + 2 * H * HD);
-    }
+    __syncthreads();                                // every lane has its query row: the buffer now takes K
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int id = tid + i * 64 * TJ, r = id >> 4, c = id & 15;
@@ -270,22 +288,30 @@ __global__ __launch_bounds__(64 * TJ) void k_attention_hd64_short(const float *_
             o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], s[tj][m], o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], s[tj][m], o1, 0, 0, 0);
         }
-    if (qi < L) {
+    // the output tile goes back through the LDS buffer (V is dead): 16 lanes then store one token's 256 B (or, SPLIT, the
+    // six 128-B bf16 segments of it) instead of 32-B pieces of 32 different rows per store instruction
+    __syncthreads();
+    {
         const float inv = 1.0f / lsum;
-        float *dst = out + ((b * L + qi) * H + head) * HD;
-        unsigned short *row6 = reinterpret_cast<unsigned short *>(out) + (b * L + qi) * 6 * (int64_t)(H * HD);
+        float *dst = &sKV[qi * PITCH];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int c0 = 8 * g + 4 * h;
-            const float4 v0 = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-            const float4 v1 = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
-            if (SPLIT) {
-                lemon_split::store_split4<false>(row6, H * HD, (head * HD + c0) >> 2, v0);
-                lemon_split::store_split4<false>(row6, H * HD, (head * HD + 32 + c0) >> 2, v1);
-            } else {
-                *reinterpret_cast<float4 *>(dst + c0) = v0;
-                *reinterpret_cast<float4 *>(dst + 32 + c0) = v1;
-            }
+            *reinterpret_cast<float4 *>(dst + c0) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            *reinterpret_cast<float4 *>(dst + 32 + c0) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int id = tid + i * 64 * TJ, r = id >> 4, c = id & 15;
+        if (r < L) {
+            const float4 v = *reinterpret_cast<const float4 *>(&sKV[r * PITCH + 4 * c]);
+            if (SPLIT)
+                lemon_split::store_split4<false>(reinterpret_cast<unsigned short *>(out) + (b * L + r) * 6 * (int64_t)(H * HD), H * HD,
+                                                 head * (HD / 4) + c, v);
+            else
+                *reinterpret_cast<float4 *>(out + ((b * L + r) * H + head) * HD + 4 * c) = v;
         }
     }
 }

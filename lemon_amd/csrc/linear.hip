@@ -92,6 +92,23 @@ __global__ void k_count_off(const float *__restrict__ a, const float *__restrict
     if (bad) atomicAdd(out, bad);
 }
 
+// position independence of a candidate: with every row of x identical, every row of y must come out bit-identical.
+// Stream-K style solutions cut the k loop differently from tile to tile, so the same prompt embedded at two positions of a
+// micro-batch would differ in the last bit (bench.py: thousands of "distinct" embeddings for 100 class prompts); the tuner
+// only records solutions that pass (LEMON_LINEAR_ALLOW_POSITION_DEPENDENT=1 lifts the requirement).
+__global__ void k_replicate_row(const char *__restrict__ row0, int64_t rows, int64_t row_bytes, char *__restrict__ dst) {
+    const int64_t total = rows * (row_bytes / 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        reinterpret_cast<unsigned *>(dst)[i] = reinterpret_cast<const unsigned *>(row0)[i % (row_bytes / 4)];
+}
+__global__ void k_rows_differ(const float *__restrict__ y, int64_t m, int n, unsigned *__restrict__ out) {
+    unsigned bad = 0;
+    const int64_t total = m * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        bad += __float_as_uint(y[i]) != __float_as_uint(y[i % n]);
+    if (bad) atomicAdd(out, bad);
+}
+
 struct Problem {
     hipblasLtMatmulDesc_t desc = nullptr;
     hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr;
@@ -229,7 +246,8 @@ int tune(const LinKey &key, Problem &p, const void *x, const void *w, const floa
     int rc = LEMON_OK;
     float *ref = nullptr;
     unsigned *flag = nullptr;
-    size_t best = 0; float best_us = 1e30f; bool found = false; int rejected = 0;
+    char *xrep = nullptr;
+    size_t best = 0; float best_us = 1e30f; bool found = false; int rejected = 0, pos_dep = 0;
     if (!timed.empty() && (hipMalloc((void **)&ref, (size_t)m * n * sizeof(float)) != hipSuccess ||
                            hipMalloc((void **)&flag, 2 * sizeof(unsigned)) != hipSuccess)) {
         lemon_set_error("lemon_linear_f32: validation buffers (%lld x %d floats)", (long long)m, n);
@@ -253,8 +271,23 @@ int tune(const LinKey &key, Problem &p, const void *x, const void *w, const floa
         const float tol = 1e-3f * ref_max + 1e-6f;
         std::sort(timed.begin(), timed.end());
         int finals = 0;
+        const bool need_pos_indep = !(getenv("LEMON_LINEAR_ALLOW_POSITION_DEPENDENT") && atoi(getenv("LEMON_LINEAR_ALLOW_POSITION_DEPENDENT")));
+        const int64_t row_bytes = (int64_t)std::get<2>(key) * (std::get<5>(key) ? 2 : 4);
+        if (need_pos_indep && m > 1 && (row_bytes & 3) == 0 && hipMalloc((void **)&xrep, (size_t)m * row_bytes) == hipSuccess)
+            hipLaunchKernelGGL(k_replicate_row, dim3(2048), dim3(256), 0, stream, reinterpret_cast<const char *>(x), m, row_bytes, xrep);
         for (size_t j = 0; j < timed.size() && finals < 6; ++j) {   // front runners: validate, then re-time properly
             const size_t ci = timed[j].second;
+            if (xrep) {      // identical rows in, identical rows out (no residual: C = D = scratch, beta as the problem has it is irrelevant here)
+                const float zero = 0.0f, one = 1.0f;
+                (void)hipMemsetAsync(scratch, 0, (size_t)m * n * sizeof(float), stream);
+                if (hipblasLtMatmul(g_lin.handle, p.desc, &one, w, p.la, xrep, p.lb, &zero, scratch, p.lc, scratch, p.lc, &cand[ci].algo,
+                                    g_lin.ws, g_lin.ws_bytes, stream) != HIPBLAS_STATUS_SUCCESS) { ++rejected; continue; }
+                (void)hipMemsetAsync(flag + 1, 0, sizeof(unsigned), stream);
+                hipLaunchKernelGGL(k_rows_differ, dim3(blocks), dim3(256), 0, stream, scratch, m, n, flag + 1);
+                (void)hipMemcpyAsync(&hflag[1], flag + 1, sizeof(unsigned), hipMemcpyDeviceToHost, stream);
+                (void)hipStreamSynchronize(stream);
+                if (hflag[1] != 0) { ++rejected; ++pos_dep; continue; }
+            }
             {
                 if (!residual) (void)hipMemsetAsync(scratch, 0xFF, (size_t)m * n * sizeof(float), stream);   // NaN
                 (void)time_algo(p, cand[ci].algo, x, w, c, beta, scratch, 0, stream, e0, e1);
@@ -269,6 +302,7 @@ int tune(const LinKey &key, Problem &p, const void *x, const void *w, const floa
             if (us > 0.f && us < best_us) { best_us = us; best = ci; found = true; }
         }
     }
+    if (xrep) (void)hipFree(xrep);
     if (rc == LEMON_OK && !found) {
         lemon_set_error("lemon_linear_f32: no hipBLASLt solution supports m=%lld n=%d k=%d epilogue=%d", (long long)m, n,
                         std::get<2>(key), std::get<3>(key));
@@ -278,9 +312,9 @@ int tune(const LinKey &key, Problem &p, const void *x, const void *w, const floa
         g_lin.index[key] = hipblaslt_ext::getIndexFromAlgo(cand[best].algo);
         g_lin.usec[key] = best_us;
         if (getenv("LEMON_LINEAR_VERBOSE"))
-            fprintf(stderr, "[lemon_linear] m=%lld n=%d k=%d epi=%d res=%d: %zu of %zu solutions timed, %d rejected by validation, best index %d %.1f us\n",
-                    (long long)m, n, std::get<2>(key), std::get<3>(key), std::get<4>(key), timed.size(), cand.size(), rejected,
-                    g_lin.index[key], best_us);
+            fprintf(stderr, "[lemon_linear] m=%lld n=%d k=%d epi=%d res=%d dt=%d: %zu of %zu solutions timed, %d rejected by validation (%d position-dependent), best index %d %.1f us\n",
+                    (long long)m, n, std::get<2>(key), std::get<3>(key), std::get<4>(key), std::get<5>(key), timed.size(), cand.size(), rejected,
+                    pos_dep, g_lin.index[key], best_us);
     }
     if (ref) (void)hipFree(ref);
     if (flag) (void)hipFree(flag);

@@ -28,9 +28,13 @@ def write_pmc(name, dirs):
     rows = pmc_rows(dirs)
     if not rows:
         return
+    import math
     groups = {}
     for r in rows:
-        key = (r["kernel"], r["counter"], r["grid"], r["wg"], r["vgpr"], r["agpr"], r["lds"])
+        # (launches of one kernel and grid can still be different problems -- the planned fp32 scan uses 512 workgroups for the
+        # 50 000-query image-side search AND for a 7 000-query text-side one: a factor-of-two duration bucket keeps them apart)
+        bucket = int(math.floor(math.log2(max(r["dur_ms"], 1e-6))))
+        key = (r["kernel"], r["counter"], r["grid"], r["wg"], r["vgpr"], r["agpr"], r["lds"], bucket)
         groups.setdefault(key, []).append(r)
     out = []
     for key, rs in groups.items():
