@@ -142,10 +142,11 @@ def test_linear_results_file_is_stamped_and_well_formed():
     lines = [l.strip() for l in open(path) if l.strip()]
     assert re.fullmatch(r"# lemon_linear hipblaslt=\d+ arch=gfx950", lines[0]), lines[0]
     rows = [l.split(",") for l in lines if not l.startswith("#")]
-    assert rows and all(len(r) == 7 for r in rows)
-    keys = {tuple(int(v) for v in r[:5]) for r in rows}
-    assert len(keys) == len(rows)                                   # one solution per (m,n,k,epilogue,residual)
-    assert any(k[1:3] == (2304, 768) for k in keys)                 # ViT-B/32 QKV projection
+    assert rows and all(len(r) in (7, 8) for r in rows)            # 8th column: operand type (1 = bf16 split operands, k = 6 x width)
+    keys = {tuple(int(v) for v in r[:5]) + (int(r[7]) if len(r) == 8 else 0,) for r in rows}
+    assert len(keys) == len(rows)                                   # one solution per (m,n,k,epilogue,residual,operand type)
+    assert any(k[1:3] == (2304, 768) and k[5] == 0 for k in keys)   # ViT-B/32 QKV projection, fp32 GEMM
+    assert any(k[1:3] == (2304, 6 * 768) and k[5] == 1 for k in keys)   # ... and as the 3-way bf16 split GEMM
 
 
 def test_maximize_metric_survives_a_diverging_lbfgs_candidate():
