@@ -1021,9 +1021,9 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs2(ScanParamsH p) {
 #define Q2_NRD(KSV) ((KSV) > 7 ? 0 : ((PARK && ks0 + (KSV) >= NR) ? 3 : 2))     /* reads the step's LOADS issues */
 #define Q2_WAIT(S, N)                                                                                                    \
                 do {                                                                                                     \
-                    if (PARK && (N) == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f##S##0), "+v"(f##S##1), "+v"(p##S)); \
-                    else if ((N) == 2)    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f##S##0), "+v"(f##S##1), "+v"(p##S)); \
-                    else                  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f##S##0), "+v"(f##S##1), "+v"(p##S)); \
+                    if ((N) == 3)      asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(f##S##0), "+v"(f##S##1), "+v"(p##S)); \
+                    else if ((N) == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f##S##0), "+v"(f##S##1), "+v"(p##S)); \
+                    else               asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f##S##0), "+v"(f##S##1), "+v"(p##S)); \
                 } while (0)
 #define Q2_STEP(S, KSV)                                                                                                  \
                 do {                                                                                                     \
@@ -1038,6 +1038,7 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs2(ScanParamsH p) {
                         else               { mfma_x<ACCV, false, false>(acc10, f##S##0, p##S); mfma_x<ACCV, false, false>(acc11, f##S##1, p##S); } \
                     }                                                                                                    \
                 } while (0)
+                // (fragment reads TWO k-steps ahead over three sets were measured too: 1 404.5 vs 1 400.6 ms at 1 M x 768 -- nothing)
                 pa = fa0 = fa1 = pb = fb0 = fb1 = bf16x8{};
                 Q2_LOADS(a, 0);
                 Q2_LOADS(b, 1); Q2_WAIT(a, Q2_NRD(1)); Q2_STEP(a, 0);
@@ -1180,45 +1181,63 @@ struct FinalParams {
 // at a time -- lane (r8, c) fetches chunk c of rows r8, r8 + 8, ... -- transposed through `lx` [64][FIN_PITCH], and the next
 // line is in flight while the current one is consumed against q_lds (broadcast reads).  d % 4 == 0, 16-byte aligned rows.
 __device__ __forceinline__ float chain_dot_wave_q(const float *__restrict__ q_lds, const float *x_row, int d,
-                                                  float *__restrict__ lx, int lane) {
-    const int r8 = lane >> 3, c = lane & 7;
+                                                  float *__restrict__ lx, int lane, int nvalid) {
+    const int r8 = lane >> 3, c = lane & 7;       // (nvalid: lanes >= nvalid own no candidate -- their rows are not fetched)
 #define FIN_PTR(i) const float *px##i = reinterpret_cast<const float *>(__shfl((unsigned long long)(uintptr_t)x_row, r8 + 8 * i)) + 4 * c;
     FIN_PTR(0) FIN_PTR(1) FIN_PTR(2) FIN_PTR(3) FIN_PTR(4) FIN_PTR(5) FIN_PTR(6) FIN_PTR(7)
 #undef FIN_PTR
-    float4 v0, v1, v2, v3, v4, v5, v6, v7;
+    // two register sets: the rows' next TWO 128-B lines are in flight while the current one is consumed (with one set the
+    // gather ran at 3.5 TB/s: 8 KB in flight per wave)
+    float4 a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-#define FIN_FETCH(koff)                                                                             \
+#define FIN_FETCH(S, koff)                                                                          \
     do {                                                                                            \
+        S##0 = S##1 = S##2 = S##3 = S##4 = S##5 = S##6 = S##7 = zero;                               \
         if ((koff) + 4 * c < d) {                                                                   \
-            v0 = *reinterpret_cast<const float4 *>(px0 + (koff)); v1 = *reinterpret_cast<const float4 *>(px1 + (koff)); \
-            v2 = *reinterpret_cast<const float4 *>(px2 + (koff)); v3 = *reinterpret_cast<const float4 *>(px3 + (koff)); \
-            v4 = *reinterpret_cast<const float4 *>(px4 + (koff)); v5 = *reinterpret_cast<const float4 *>(px5 + (koff)); \
-            v6 = *reinterpret_cast<const float4 *>(px6 + (koff)); v7 = *reinterpret_cast<const float4 *>(px7 + (koff)); \
-        } else { v0 = v1 = v2 = v3 = v4 = v5 = v6 = v7 = zero; }                                    \
+            if (r8 < nvalid)      S##0 = *reinterpret_cast<const float4 *>(px0 + (koff));          \
+            if (r8 + 8 < nvalid)  S##1 = *reinterpret_cast<const float4 *>(px1 + (koff));          \
+            if (r8 + 16 < nvalid) S##2 = *reinterpret_cast<const float4 *>(px2 + (koff));          \
+            if (r8 + 24 < nvalid) S##3 = *reinterpret_cast<const float4 *>(px3 + (koff));          \
+            if (r8 + 32 < nvalid) S##4 = *reinterpret_cast<const float4 *>(px4 + (koff));          \
+            if (r8 + 40 < nvalid) S##5 = *reinterpret_cast<const float4 *>(px5 + (koff));          \
+            if (r8 + 48 < nvalid) S##6 = *reinterpret_cast<const float4 *>(px6 + (koff));          \
+            if (r8 + 56 < nvalid) S##7 = *reinterpret_cast<const float4 *>(px7 + (koff));          \
+        }                                                                                           \
     } while (0)
-#define FIN_STORE(i, v) *reinterpret_cast<float4 *>(&lx[(r8 + 8 * i) * FIN_PITCH + 4 * c]) = v;
-    FIN_FETCH(0);
+#define FIN_ST1(i, v) *reinterpret_cast<float4 *>(&lx[(r8 + 8 * i) * FIN_PITCH + 4 * c]) = v;
+#define FIN_STORE(S) FIN_ST1(0, S##0) FIN_ST1(1, S##1) FIN_ST1(2, S##2) FIN_ST1(3, S##3) FIN_ST1(4, S##4) FIN_ST1(5, S##5) FIN_ST1(6, S##6) FIN_ST1(7, S##7)
+#define FIN_CONSUME(k0_)                                                                            \
+    do {                                                                                            \
+        __builtin_amdgcn_wave_barrier();                                                            \
+        const int lim = d - (k0_) < 32 ? d - (k0_) : 32;       /* wave-uniform; multiple of 4 */     \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                             \
+            if (4 * u < lim) {                                                                      \
+                const float4 xv = *reinterpret_cast<const float4 *>(&lx[lane * FIN_PITCH + 4 * u]); \
+                const float4 qv = *reinterpret_cast<const float4 *>(&q_lds[(k0_) + 4 * u]);         \
+                acc = __builtin_fmaf(qv.x, xv.x, acc);                                              \
+                acc = __builtin_fmaf(qv.y, xv.y, acc);                                              \
+                acc = __builtin_fmaf(qv.z, xv.z, acc);                                              \
+                acc = __builtin_fmaf(qv.w, xv.w, acc);                                              \
+            }                                                                                       \
+        }                                                                                           \
+        __builtin_amdgcn_wave_barrier();                                                            \
+    } while (0)
+    FIN_FETCH(a, 0);
+    FIN_FETCH(b, 32);
     float acc = 0.0f;
-    for (int k0 = 0; k0 < d; k0 += 32) {
-        FIN_STORE(0, v0) FIN_STORE(1, v1) FIN_STORE(2, v2) FIN_STORE(3, v3) FIN_STORE(4, v4) FIN_STORE(5, v5) FIN_STORE(6, v6) FIN_STORE(7, v7)
-        const int kn = k0 + 32;
-        if (kn < d) FIN_FETCH(kn);                       // wave-uniform: next 128 B of every row
-        __builtin_amdgcn_wave_barrier();
-        const int lim = d - k0 < 32 ? d - k0 : 32;       // wave-uniform; multiple of 4
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (4 * u < lim) {
-                const float4 xv = *reinterpret_cast<const float4 *>(&lx[lane * FIN_PITCH + 4 * u]);
-                const float4 qv = *reinterpret_cast<const float4 *>(&q_lds[k0 + 4 * u]);
-                acc = __builtin_fmaf(qv.x, xv.x, acc);
-                acc = __builtin_fmaf(qv.y, xv.y, acc);
-                acc = __builtin_fmaf(qv.z, xv.z, acc);
-                acc = __builtin_fmaf(qv.w, xv.w, acc);
-            }
+    for (int k0 = 0; k0 < d; k0 += 64) {
+        FIN_STORE(a)
+        FIN_FETCH(a, k0 + 64);                           // (past the end: zeros, no loads)
+        FIN_CONSUME(k0);
+        if (k0 + 32 < d) {                               // wave-uniform
+            FIN_STORE(b)
+            FIN_FETCH(b, k0 + 96);
+            FIN_CONSUME(k0 + 32);
         }
-        __builtin_amdgcn_wave_barrier();
     }
+#undef FIN_CONSUME
 #undef FIN_STORE
+#undef FIN_ST1
 #undef FIN_FETCH
     return acc;
 }
@@ -1260,7 +1279,7 @@ __global__ __launch_bounds__(256) void k_bf16_final(FinalParams p) {
         const u32 j = valid ? lemon_key_index(old) : 0u;   // idle lanes shadow row 0 (always allocated)
         const float *xrow = p.x + (int64_t)j * d;
         float dot;
-        if (STAGED) dot = chain_dot_wave_q(s_q[wave], xrow, d, s_x[wave], lane);
+        if (STAGED) dot = chain_dot_wave_q(s_q[wave], xrow, d, s_x[wave], lane, c - base < 64 ? c - base : 64);
         else { dot = 0.0f; for (int t = 0; t < d; ++t) dot = __builtin_fmaf(qrow[t], xrow[t], dot); }
         float sc = dot;
         if (l2) {
@@ -1370,13 +1389,28 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
     // (the splits == 1 regime of lemon_plan_splits), pitches 512 and 768.
     const char *qs2_env = getenv("LEMON_QS2_MIN_PANELS");      // (read per call: the tests force QS2 onto small shapes with 0)
     const int qs2_min = qs2_env ? atoi(qs2_env) : 768;
-    const bool qs2 = qs && use_qs2() && dpad_h >= 512 && (nq < QCHUNK_H ? nq : QCHUNK_H) >= (int64_t)qs2_min * BQ2;
-    const int bqw = qs2 ? BQ2 : BQ;                     // queries per workgroup
-    const int rt = qs2 ? RT2 : BX;                      // database rows per tile
+    static const int cus = [] {
+        int dev = 0, c = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+        return c > 0 ? c : 256;
+    }();
     const int n_tiles128 = (int)((idx->n + BX - 1) / BX);
-    const int n_tiles = (int)((idx->n + rt - 1) / rt);
-    for (int64_t c0 = 0; c0 < nq; c0 += QCHUNK_H) {
-        const int64_t cn = (nq - c0) < QCHUNK_H ? (nq - c0) : QCHUNK_H;
+    int64_t cn = 0;
+    for (int64_t c0 = 0; c0 < nq; c0 += cn) {
+        cn = (nq - c0) < QCHUNK_H ? (nq - c0) : QCHUNK_H;
+        const bool qs2 = qs && use_qs2() && dpad_h >= 512 && cn >= (int64_t)qs2_min * BQ2;
+        if (qs2 && cn < QCHUNK_H) {
+            // Whole rounds first.  The chunked scan runs ONE workgroup per CU, all of equal length: 1 859 workgroups take
+            // eight rounds of 256 like 2 048 do (1 M queries = 2 048 + 1 859 panels: 4.6 % of the scan spent in a quarter-full
+            // last round).  So a final stretch that does not fill its last round to 80 % is cut at the last whole round; the
+            // ragged rest (< 205 panels) comes back through this loop, is too small for QS2 and goes through the one-block
+            // kernel with the database split between workgroups -- a few rounds of 1/splits of the scan each.
+            const int64_t panels_c = (cn + BQ2 - 1) / BQ2, full = panels_c / cus * cus;
+            if (full > 0 && panels_c != full && (panels_c - full) * 5 < (int64_t)cus * 4) cn = full * BQ2;
+        }
+        const int bqw = qs2 ? BQ2 : BQ;                     // queries per workgroup
+        const int rt = qs2 ? RT2 : BX;                      // database rows per tile
+        const int n_tiles = (int)((idx->n + rt - 1) / rt);
         const int64_t nq_pad = round_up(cn, bqw);
         const int panels = (int)(nq_pad / bqw);
         int splits, tiles_per_split;
@@ -1499,8 +1533,10 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
             if (rc) return rc;
         }
         idx->last.algo = LEMON_ALGO_BF16_FILTER;
-        idx->last.grid = (int)grid; idx->last.block = NT;
-        idx->last.query_panel = bqw; idx->last.db_splits = splits;
+        if (c0 == 0) {                                  // (the first chunk is the largest: its geometry is what gets reported)
+            idx->last.grid = (int)grid; idx->last.block = NT;
+            idx->last.query_panel = bqw; idx->last.db_splits = splits;
+        }
     }
     idx->last.nq = nq; idx->last.n = idx->n; idx->last.d = d; idx->last.k = k;
     return LEMON_OK;
