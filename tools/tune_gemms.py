@@ -30,7 +30,13 @@ for spec in (sys.argv[1:] or ["vit-b-32:1000"]):
     for mode in ("split", "f32"):          # both GEMM modes of lemon_amd/clip.py meet their keys (bf16 split operands / fp32)
         os.environ["LEMON_GEMM"] = mode
         with torch.no_grad():
-            model.encode_image(px); model.encode_text(ids); model.encode_text(ids[:bs])
+            # text tower: only position-independent solutions (identical prompts must get identical embeddings wherever they
+            # sit in a micro-batch: the text-side search folds them); image tower: rows are distinct images, the fastest
+            # validated solution is taken
+            os.environ["LEMON_LINEAR_ALLOW_POSITION_DEPENDENT"] = "1"
+            model.encode_image(px)
+            os.environ["LEMON_LINEAR_ALLOW_POSITION_DEPENDENT"] = "0"
+            model.encode_text(ids); model.encode_text(ids[:bs])
         torch.cuda.synchronize()
     print(spec, "tuned in", round(time.perf_counter() - t0, 1), "s", flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
