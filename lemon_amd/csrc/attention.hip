@@ -303,15 +303,19 @@ __global__ __launch_bounds__(64 * TJ) void k_attention_hd64_short(const float *_
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int id = tid + i * 64 * TJ, r = id >> 4, c = id & 15;
+    for (int i = 0; i < 4; ++i) {                   // 8 lanes per token row, 8 values each: 16-byte stores in both forms
+        const int id = tid + i * 64 * TJ, r = id >> 3, c8 = id & 7;
         if (r < L) {
-            const float4 v = *reinterpret_cast<const float4 *>(&sKV[r * PITCH + 4 * c]);
+            const float4 v0 = *reinterpret_cast<const float4 *>(&sKV[r * PITCH + 8 * c8]);
+            const float4 v1 = *reinterpret_cast<const float4 *>(&sKV[r * PITCH + 8 * c8 + 4]);
             if (SPLIT)
-                lemon_split::store_split4<false>(reinterpret_cast<unsigned short *>(out) + (b * L + r) * 6 * (int64_t)(H * HD), H * HD,
-                                                 head * (HD / 4) + c, v);
-            else
-                *reinterpret_cast<float4 *>(out + ((b * L + r) * H + head) * HD + 4 * c) = v;
+                lemon_split::store_split8<false>(reinterpret_cast<unsigned short *>(out) + (b * L + r) * 6 * (int64_t)(H * HD), H * HD,
+                                                 head * (HD / 8) + c8, v0, v1);
+            else {
+                float *dst = out + ((b * L + r) * H + head) * HD + 8 * c8;
+                *reinterpret_cast<float4 *>(dst) = v0;
+                *reinterpret_cast<float4 *>(dst + 4) = v1;
+            }
         }
     }
 }

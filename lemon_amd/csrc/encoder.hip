@@ -74,6 +74,66 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
     }
 }
 
+// LayerNorm for widths that are multiples of 8: every lane owns EIGHT consecutive elements per chunk (two float4), so the
+// split variant stores 16 bytes per segment instead of 8 (94 -> see DESIGN us per 50 000 x 768 rows); the fp32 variant uses
+// the same element-to-lane mapping, so lemon_layernorm_split3 == lemon_split3_f32(lemon_layernorm_f32) bit for bit.
+template <int CH8, bool SPLIT>   // 8-element chunks per lane: width <= 512*CH8
+__global__ __launch_bounds__(256) void k_layernorm8(const float *__restrict__ x, const float *__restrict__ w,
+                                                    const float *__restrict__ b, float eps, int64_t rows, int width,
+                                                    float *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = width >> 3;
+    const float4 *xr = reinterpret_cast<const float4 *>(x + row * (int64_t)width);
+    float4 v[CH8][2];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < CH8; ++i) {
+        const int c = lane + 64 * i;
+        v[i][0] = v[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < nch) { v[i][0] = xr[2 * c]; v[i][1] = xr[2 * c + 1]; }
+        s += ((v[i][0].x + v[i][0].y) + (v[i][0].z + v[i][0].w)) + ((v[i][1].x + v[i][1].y) + (v[i][1].z + v[i][1].w));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)width;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < CH8; ++i) {
+        if (lane + 64 * i < nch) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const float dx = v[i][hf].x - mean, dy = v[i][hf].y - mean, dz = v[i][hf].z - mean, dw = v[i][hf].w - mean;
+                q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = rsqrtf(q / (float)width + eps);
+    const float4 *w4 = reinterpret_cast<const float4 *>(w);
+    const float4 *b4 = reinterpret_cast<const float4 *>(b);
+    float4 *yr = reinterpret_cast<float4 *>(y + row * (int64_t)width);
+#pragma unroll
+    for (int i = 0; i < CH8; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            float4 o[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const float4 ww = w4[2 * c + hf], bb = b4[2 * c + hf];
+                o[hf].x = (v[i][hf].x - mean) * rstd * ww.x + bb.x;
+                o[hf].y = (v[i][hf].y - mean) * rstd * ww.y + bb.y;
+                o[hf].z = (v[i][hf].z - mean) * rstd * ww.z + bb.z;
+                o[hf].w = (v[i][hf].w - mean) * rstd * ww.w + bb.w;
+            }
+            if (SPLIT) store_split8<false>(reinterpret_cast<unsigned short *>(y) + row * 6 * (int64_t)width, width, c, o[0], o[1]);
+            else { yr[2 * c] = o[0]; yr[2 * c + 1] = o[1]; }
+        }
+    }
+}
+
 // Token assembly of the vision tower (HF CLIPVisionEmbeddings + pre_layrnorm; chexzero_clip.py:243-249): row 0 of every image
 // is the class embedding, rows 1.. are the patch-embedding GEMM's output; add the position embedding and apply the
 // pre-LayerNorm -- torch runs this as cat + add + layer_norm (three read+write passes); here it is one.
@@ -190,7 +250,12 @@ extern "C" int lemon_layernorm_f32(const float *x_dev, const float *weight_dev, 
                   "16-byte aligned pointers");
     hipStream_t stream = (hipStream_t)stream_;
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-    if (width <= 512) hipLaunchKernelGGL(k_layernorm<2>, grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
+    if ((width & 7) == 0) {
+        if (width <= 512) hipLaunchKernelGGL((k_layernorm8<1, false>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
+        else if (width <= 1024) hipLaunchKernelGGL((k_layernorm8<2, false>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
+        else hipLaunchKernelGGL((k_layernorm8<4, false>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
+    }
+    else if (width <= 512) hipLaunchKernelGGL(k_layernorm<2>, grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
     else if (width <= 1024) hipLaunchKernelGGL(k_layernorm<4>, grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
     else hipLaunchKernelGGL(k_layernorm<8>, grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
     LEMON_HIP_CHECK(hipGetLastError());
@@ -209,7 +274,12 @@ extern "C" int lemon_layernorm_split3(const float *x_dev, const float *weight_de
     hipStream_t stream = (hipStream_t)stream_;
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     float *y = reinterpret_cast<float *>(y6_dev);
-    if (width <= 512) hipLaunchKernelGGL((k_layernorm<2, true>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
+    if ((width & 7) == 0 && (((uintptr_t)y6_dev) & 15) == 0) {
+        if (width <= 512) hipLaunchKernelGGL((k_layernorm8<1, true>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
+        else if (width <= 1024) hipLaunchKernelGGL((k_layernorm8<2, true>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
+        else hipLaunchKernelGGL((k_layernorm8<4, true>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
+    }
+    else if (width <= 512) hipLaunchKernelGGL((k_layernorm<2, true>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
     else if (width <= 1024) hipLaunchKernelGGL((k_layernorm<4, true>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
     else hipLaunchKernelGGL((k_layernorm<8, true>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
     LEMON_HIP_CHECK(hipGetLastError());

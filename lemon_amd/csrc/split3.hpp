@@ -37,4 +37,22 @@ __device__ __forceinline__ void store_split4(unsigned short *__restrict__ row6, 
 }
 
 
+// eight consecutive k of one row -> the six segments, 16-byte stores (c8 = 8-element chunk index)
+typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+template <bool WEIGHT>
+__device__ __forceinline__ void store_split8(unsigned short *__restrict__ row6, int k, int c8, float4 v0, float4 v1) {
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    us8 hi, mid, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        unsigned short h_, m_, l_;
+        split3(v[e], h_, m_, l_);
+        hi[e] = h_; mid[e] = m_; lo[e] = l_;
+    }
+    us8 *o = reinterpret_cast<us8 *>(row6) + c8;
+    const int seg = k >> 3;                               // us8 chunks per segment
+    if (WEIGHT) { o[0] = hi; o[seg] = mid; o[2 * seg] = hi; o[3 * seg] = lo; o[4 * seg] = mid; o[5 * seg] = hi; }
+    else        { o[0] = hi; o[seg] = hi; o[2 * seg] = mid; o[3 * seg] = hi; o[4 * seg] = mid; o[5 * seg] = lo; }
+}
+
 }  // namespace lemon_split
