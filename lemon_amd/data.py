@@ -224,15 +224,17 @@ def synthetic_caption_frame(n, seed, n_cat=80, image_hw=32):
     return df, px
 
 
-def _read_cifar(root, name):
+def _read_cifar(root, name, train=True):
+    """The CIFAR python pickles torchvision's CIFAR10 / CIFAR100(train=...) classes unpickle (lib/datasets/utils.py:356-386):
+    uint8 [N, 32, 32, 3] images and the (fine) labels."""
     if name.startswith("cifar100"):
-        with open(os.path.join(root, "cifar-100-python", "train"), "rb") as f:
+        with open(os.path.join(root, "cifar-100-python", "train" if train else "test"), "rb") as f:
             d = pickle.load(f, encoding="bytes")
         x, y = d[b"data"], np.array(d[b"fine_labels"])
     else:
         xs, ys = [], []
-        for i in range(1, 6):
-            with open(os.path.join(root, "cifar-10-batches-py", f"data_batch_{i}"), "rb") as f:
+        for fn in ([f"data_batch_{i}" for i in range(1, 6)] if train else ["test_batch"]):
+            with open(os.path.join(root, "cifar-10-batches-py", fn), "rb") as f:
                 d = pickle.load(f, encoding="bytes")
             xs.append(d[b"data"]); ys += list(d[b"labels"])
         x, y = np.concatenate(xs), np.array(ys)
@@ -257,6 +259,24 @@ def get_dataset(name, data_seed, percent_flips=0.40, flip_type="real", data_root
         tr, va, te = ds.split_80_10_10(n, data_seed)
         full = ImageLabelSet(images, y, noisy, image_size)
         return full.subset(tr), full.subset(va), full.subset(te)
+    if name in ("cifar10_full", "cifar100_full"):
+        # lib/datasets/utils.py:374-391: train / val = an 80 / 20 split of the training set, test = the dataset's own test
+        # split, each with its own noise vector drawn with the same seed
+        C = ds.class_num_dict[name]
+        if str(data_root).startswith("synthetic"):
+            n = int(str(data_root).split(":")[1]) if ":" in str(data_root) else 5000
+            rs = np.random.RandomState(data_seed)
+            y, y_te = rs.randint(0, C, n), rs.randint(0, C, max(n // 5, 1))
+            images = rs.randint(0, 256, (n, 32, 32, 3), dtype=np.uint8)
+            images_te = rs.randint(0, 256, (len(y_te), 32, 32, 3), dtype=np.uint8)
+        else:
+            images, y = _read_cifar(data_root, name, True)
+            images_te, y_te = _read_cifar(data_root, name, False)
+        noisy = np.asarray(ds.add_noisy_labels(name, flip_type, percent_flips, data_seed, list(y), data_root))
+        noisy_te = np.asarray(ds.add_noisy_labels(name, flip_type, percent_flips, data_seed, list(y_te), data_root))
+        tr, va = ds.split_80_20(len(y), data_seed)
+        full = ImageLabelSet(images, y, noisy, image_size)
+        return full.subset(tr), full.subset(va), ImageLabelSet(images_te, y_te, noisy_te, image_size)
     if name in ("mscoco", "flickr30k", "mimiccxr_caption", "mmimdb", "cc3m"):
         import pandas as pd
         pixels = None

@@ -111,6 +111,13 @@ def split_80_10_10(n, data_seed):
     return tr, va, te
 
 
+def split_80_20(n, data_seed):
+    """train/val index arrays of the *_full datasets, lib/datasets/utils.py:389 (one sklearn shuffle; the test set is the
+    dataset's own test split)."""
+    from sklearn.model_selection import train_test_split
+    return train_test_split(np.arange(n), test_size=0.2, random_state=data_seed)
+
+
 # ---------------------------------------------------------------------------- caption noise
 def random_noise_dict(num_items, frac_noise=0.3, seed=42):
     """{row -> row whose caption it receives}; lib/datasets/noise_captioning.py:35-42."""

@@ -45,7 +45,7 @@ def install(case, monkeypatch, tmp_path):
     if case.is_caption:
         prompt_ids = {str(c): i for i, c in enumerate(fx["captions"])}
     else:
-        labels = ds.LABEL_SETS[case.dataset]
+        labels = ds.LABEL_SETS[case.dataset]          # (cifar10_full shares cifar10's label set)
         prompt_ids = {str(fx["prefix"]) + l: i for i, l in enumerate(labels)}
 
     def factory(name, text_base_name=None, img_base=None, return_tokenizer=False, arch=None, bpe_path=None):
@@ -88,5 +88,5 @@ def install(case, monkeypatch, tmp_path):
         monkeypatch.setattr(data, "generic_transform", lambda img, size=224: torch.from_numpy(
             np.frombuffer(np.asarray(img, np.uint8).tobytes()[:4 * d], np.float32).copy()))
     else:
-        monkeypatch.setattr(data, "_read_cifar", lambda r, n: (fx["img_all"], fx["y_all"]))
+        monkeypatch.setattr(data, "_read_cifar", lambda r, n, train=True: (fx["img_all"], fx["y_all"]) if train else (fx["img_test"], fx["y_test"]))
     return ["--data_root", root, "--clip_path", "planted"]

@@ -42,6 +42,23 @@ def test_large_scale_csv_reader_matches_reference_run(monkeypatch, tmp_path):
     assert len(raw) == sum(len(s) for s in sets)
 
 
+def test_cifar_full_split_matches_reference_run(monkeypatch, tmp_path):
+    """cifar10_full (lib/datasets/utils.py:374-391): train / val = 80 / 20 of the training set, test = the dataset's own test
+    split with its own noise vector -- labels and membership against the reference's own run (loop_c10full_cos_k5.npz)."""
+    from lemon_amd import data
+    from tests import planted
+    c = LoopCase("c10full_cos_k5")
+    extra = planted.install(c, monkeypatch, tmp_path)
+    a = c.argv
+    seed = int(a[a.index("--data_seed") + 1])
+    sets = data.get_dataset("cifar10_full", seed, percent_flips=0.4, flip_type="symmetric", data_root=extra[1])
+    assert [len(s) for s in sets] == [len(c.fx[f"{s}_d_1"]) for s in ("train", "val", "test")] == [640, 160, 150]
+    for part, s in zip(sets, ("train", "val", "test")):
+        assert np.array_equal(np.asarray(part.noisy, np.int64), c.fx[f"{s}_noisy"]), s
+        assert np.array_equal(np.asarray(part.clean, np.int64), c.fx[f"{s}_clean"]), s
+    assert np.array_equal(sets[2].images, c.fx["img_test"])           # the test split is the test set, in file order
+
+
 def _write_cifar(root, name, x, y):
     if name == "cifar100":
         os.makedirs(os.path.join(root, "cifar-100-python"))
@@ -78,6 +95,20 @@ def test_cifar_pickle_reader(tmp_path, name, C):
         assert np.array_equal(part.noisy, noisy[idx])
     px = next(tr.batches(4))[0]                           # PIL path on CPU: CHW float, CLIP-normalised
     assert px.shape == (4, 3, 224, 224) and px.dtype == torch.float32
+    # the *_full variants also read the dataset's test split (test_batch / test)
+    n_te = 120
+    hwc_te = rs.randint(0, 256, (n_te, 32, 32, 3), dtype=np.uint8)
+    y_te = rs.randint(0, C, n_te)
+    sub = "cifar-100-python" if name == "cifar100" else "cifar-10-batches-py"
+    with open(os.path.join(str(tmp_path), sub, "test" if name == "cifar100" else "test_batch"), "wb") as f:
+        pickle.dump({b"data": np.ascontiguousarray(hwc_te.transpose(0, 3, 1, 2).reshape(n_te, 3072)),
+                     (b"fine_labels" if name == "cifar100" else b"labels"): [int(v) for v in y_te]}, f)
+    im_te, lab_te = data._read_cifar(str(tmp_path), name, train=False)
+    assert np.array_equal(im_te, hwc_te) and np.array_equal(lab_te, y_te)
+    ftr, fva, fte = data.get_dataset(name + "_full", data_seed=1, percent_flips=0.4, flip_type="asymmetric", data_root=str(tmp_path))
+    i_tr, i_va = ds.split_80_20(n, 1)
+    assert np.array_equal(ftr.images, hwc[i_tr]) and np.array_equal(fva.clean, y[i_va]) and np.array_equal(fte.images, hwc_te)
+    assert np.array_equal(fte.noisy, np.asarray(ds.add_noisy_labels(name + "_full", "asymmetric", 0.4, 1, list(y_te))))
 
 
 def test_pixels_stay_aligned_when_the_mimic_filter_drops_rows(tmp_path):

@@ -261,8 +261,10 @@ def install_stubs(state):
 
     class FakeCIFAR:
         def __init__(self, root=None, train=True, download=False, transform=None):
-            assert train
-            self.x, self.targets = state["img_all"], [int(v) for v in state["y_all"]]
+            if train:
+                self.x, self.targets = state["img_all"], [int(v) for v in state["y_all"]]
+            else:                       # the dataset's own test split (cifar10_full / cifar100_full, utils.py:379-381)
+                self.x, self.targets = state["img_test"], [int(v) for v in state["y_test"]]
 
         def __len__(self):
             return len(self.targets)
@@ -347,13 +349,17 @@ def run_case(name, cfg, dsu, state, workdir):
         fx.update(img_all=img, csv_filename=files.astype(str), csv_label=label, csv_is_clean=is_clean.astype(np.int64),
                   txt_table=txt_table, prefix=np.array(prefix))
     else:
-        C = {"cifar10": 10, "cifar100": 100}[cfg["dataset"]]
-        img, y, txt_table = planted_class_data(cfg["seed"], cfg["n"], C, d)
-        labels = np.array(getattr(dsu, cfg["dataset"] + "_labels"))
+        base = cfg["dataset"].replace("_full", "")
+        C = {"cifar10": 10, "cifar100": 100}[base]
+        img, y, txt_table = planted_class_data(cfg["seed"], cfg["n"] + cfg.get("n_test", 0), C, d)
+        labels = np.array(getattr(dsu, base + "_labels"))
         prefix = cfg.get("prefix", "A photo of a ")
-        state.update(img_all=img, y_all=y, txt_table=txt_table,
+        n_tr = cfg["n"]
+        state.update(img_all=img[:n_tr], y_all=y[:n_tr], img_test=img[n_tr:], y_test=y[n_tr:], txt_table=txt_table,
                      prompt_ids={prefix + l: i for i, l in enumerate(labels)})
-        fx.update(img_all=img, y_all=y, txt_table=txt_table, prefix=np.array(prefix))
+        fx.update(img_all=img[:n_tr], y_all=y[:n_tr], txt_table=txt_table, prefix=np.array(prefix))
+        if cfg.get("n_test"):
+            fx.update(img_test=img[n_tr:], y_test=y[n_tr:])
 
     log = {"adds": [], "searches": []}
     _FakeIndex.log = log
@@ -545,6 +551,10 @@ CASES = {
     **{f"c10_cos_k5_abl_{a}": dict(dataset="cifar10", n=500, d=32, seed=int(os.environ.get("LEMON_GOLDEN_ABL_SEED", sd)),
                                    argv=["--dataset", "cifar10", "--noise_type", "asymmetric", "--knn_k", "5", "--ablation", a])
        for a, sd in (("d1", 61), ("tau_1_2", 41), ("beta", 70), ("tau_1", 43), ("tau_2", 93), ("gamma", 83))},
+    # cifar10_full: train / val from an 80 / 20 split of the training set, test = the dataset's own test split with its own
+    # noise vector (lib/datasets/utils.py:374-391)
+    "c10full_cos_k5": dict(dataset="cifar10_full", n=800, n_test=150, d=32, seed=51,
+                           argv=["--dataset", "cifar10_full", "--noise_type", "symmetric", "--knn_k", "5", "--data_seed", "2"] + SKIP),
     # 'real noise' CSV dataset through the real get_large_scale_dataset / LargeScaleDataset + image files on disk
     "cars_cos_k5_real": dict(dataset="stanford_cars", n=400, d=32, seed=50,
                              argv=["--dataset", "stanford_cars", "--noise_type", "real", "--noise_level", "0", "--real_dataset",
