@@ -289,9 +289,9 @@ def bench_cifar(args, world, rank, dev):
     value = n_scored * world * args.steps / elapsed
     from lemon_amd.ops import gemm_mode as _gm
     gemm_mode = _gm()
-    gemm_note = ("tower GEMMs with k = width (QKV, output projection, fc1): lemon_linear_bf16x6 -- both fp32 operands split EXACTLY into "
-                 "three bf16 parts, the six cross products of order <= 2 summed by one hipBLASLt bf16 GEMM with fp32 accumulation "
-                 "(max relative error vs float64 6e-9, fp32 GEMM 3e-7; LEMON_GEMM=f32 switches it off); fc2 / patch embedding / "
+    gemm_note = ("the four GEMMs of every transformer block (QKV, output projection, fc1, fc2): lemon_linear_bf16x6 -- both fp32 operands "
+                 "split EXACTLY into three bf16 parts, the six cross products of order <= 2 summed by one hipBLASLt bf16 GEMM with fp32 "
+                 "accumulation (max relative error vs float64 6e-9, fp32 GEMM 3e-7; LEMON_GEMM=f32 switches it off); patch embedding / "
                  "projections: lemon_linear_f32; recorded solution per shape, bias / SiLU / residual epilogues"
                  if gemm_mode == "split" else "lemon_linear_f32 (hipBLASLt fp32, recorded solution per shape, SiLU/residual epilogues)")
     line = {
@@ -313,8 +313,8 @@ def bench_cifar(args, world, rank, dev):
         "encoder": {"bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_MFMA_TFLOPS, "gemm_mode": gemm_mode,
                     "achieved": (f_img + f_txt) * n_scored / max(stage["embed_s"], 1e-9) / 1e12,
                     "note": "algorithmic forward FLOPs (img+txt) of the fp32 model / embed stage wall time, against the fp32 MFMA peak; "
-                            "in gemm_mode 'split' the QKV / output-projection / fc1 GEMMs run as 3-way bf16 split GEMMs (fp32-equivalent "
-                            "results, bf16 MFMA peak / 6 = 416.7 TFLOP/s-equivalent), fc2 and the patch embedding stay fp32 GEMMs"},
+                            "in gemm_mode 'split' the four GEMMs of every block run as 3-way bf16 split GEMMs (fp32-equivalent "
+                            "results, bf16 MFMA peak / 6 = 416.7 TFLOP/s-equivalent), the patch embedding and the projections stay fp32 GEMMs"},
     }
     if gemm_mode == "split" and world == 1 and not args.no_f32_gemm_check:
         # the same step once more, untimed region of its own, with every GEMM on the fp32 matrix cores (LEMON_GEMM=f32): what

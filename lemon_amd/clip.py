@@ -158,11 +158,9 @@ class Block(nn.Module):
         return hit[1]
 
     def _forward_split(self, x, causal, rows, ops):
-        """The fused inference path with the three k = width GEMMs of the block (QKV, output projection, fc1) on the bf16
-        matrix cores at fp32-equivalent accuracy (ops.linear_split3: exact 3-way bf16 splits of both operands, six cross
-        products, fp32 accumulate); LayerNorm writes the split operand directly.  fc2 (k = 4 width) stays an fp32 GEMM: its
-        activation operand would need a split pass over the [m, 4 width] MLP activations that costs what the faster GEMM
-        saves (tools/split_gemm_probe.py)."""
+        """The fused inference path with the four GEMMs of the block (QKV, output projection, fc1, fc2) on the bf16 matrix cores
+        at fp32-equivalent accuracy (ops.linear_split3: exact 3-way bf16 splits of both operands, six cross products, fp32
+        accumulate); LayerNorm and attention write the split operand directly, the MLP activations get one split pass."""
         B, L, W = x.shape
         qkv = ops.linear_split3(ops.layer_norm_split3(x, self.ln1.weight, self.ln1.bias, self.ln1.eps), self._w6("qkv", ops), self.qkv.bias)
         hip_attn = W == 64 * self.heads and L <= ops.ATTENTION_MAX_SEQ
@@ -177,9 +175,11 @@ class Block(nn.Module):
         s = ops.QUICK_GELU_SCALE
         h = ops.linear_split3(ops.layer_norm_split3(x, self.ln2.weight, self.ln2.bias, self.ln2.eps), self._w6("fc1", ops),
                               self.fc1.bias * s, act="silu", alpha=s)
-        # (fc2 as a split GEMM was measured as well: its best position-independent solution at k6 = 18 432 takes 1 593 us against
-        # 1 650 us in fp32, and the split pass over the [m, 4 width] activations costs 450 us: 16.7 k scores/s against 17.1 k)
-        return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=x, alpha=1.0 / s)
+        # fc2: one split pass over the [m, mlp] activations (16 B per element, ~370 us at the headline shape) buys a GEMM of
+        # 1 268 us instead of 1 590 us in the tuner -- and 1 820 us inside the step, where the fp32 GEMMs run at lower clocks
+        # than in isolation while the bf16 ones do not: 17.3 k against 16.7 k scores/s on the same box (twice, alternating).
+        # (With only position-independent solutions allowed for this shape the trade was a loss: 1 593 us, 16.7 k vs 17.1 k.)
+        return ops.linear_split3(ops.split3(h), self._w6("fc2", ops), self.fc2.bias, residual=x, alpha=1.0 / s)
 
     def _sdpa(self, qkv, B, L, W, causal):
         q, k, v = qkv.view(B, L, 3, self.heads, W // self.heads).permute(2, 0, 3, 1, 4)
