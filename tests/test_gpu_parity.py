@@ -224,6 +224,7 @@ BF16 = 2
     (1, 1, 8, 1), (5, 3, 16, 5), (130, 1000, 40, 10), (128, 128, 32, 64), (257, 1300, 64, 51),
     (64, 5000, 512, 50), (300, 2049, 768, 5), (1100, 3000, 100, 1), (33, 40000, 96, 51), (700, 9000, 72, 64),
     (150, 3000, 1000, 10), (40, 700, 800, 3),      # d > 768: streaming bf16 kernel (queries not register-resident)
+    (70, 900, 30, 7), (65, 600, 301, 9),           # d % 4 != 0: k_bf16_final re-scores with per-lane row walks (no staging)
 ])
 def test_bf16_filter_bit_exact(hip, oracle, metric, nq, n, d, k):
     rng = np.random.default_rng(nq * 7 + n * 3 + d + k)
@@ -406,8 +407,8 @@ def test_neighbors_record_bf16_algo(hip, oracle):
         assert np.array_equal(got[key].cpu().numpy(), ref[key]), key
 
 
-@pytest.mark.parametrize("d,nq", [(64, 131072 + 77), (300, 196608 + 77), (768, 196608 + 300)])
-def test_bf16_filter_chunked_database_state_carry(hip, oracle, monkeypatch, d, nq):
+@pytest.mark.parametrize("d,nq,metric", [(64, 131072 + 77, "ip"), (300, 196608 + 77, "ip"), (768, 196608 + 300, "ip"), (768, 196608 + 300, "l2")])
+def test_bf16_filter_chunked_database_state_carry(hip, oracle, monkeypatch, d, nq, metric):
     # >= 1024 query panels -> one launch per Infinity-Cache-sized database chunk with the per-query
     # state carried between launches; force tiny chunks (8 tiles) so several launches happen.
     # d = 64: one query block per wave (k_scan_bf16_qs); d = 300 / 768 from 768 panels of 256 queries on: two blocks per
@@ -418,12 +419,12 @@ def test_bf16_filter_chunked_database_state_carry(hip, oracle, monkeypatch, d, n
     Q = hip.normalize_vectors(torch.randn(nq, d, generator=g, device="cuda"))
     out = []
     for algo in (1, BF16):
-        idx = hip.IndexFlatIP(d)
+        idx = (hip.IndexFlatIP if metric == "ip" else hip.IndexFlatL2)(d)
         idx.set_algo(algo)
         idx.add(X)
         out.append(idx.search(Q, 51))
     assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][0], out[1][0])
-    Dr, Ir = oracle.knn("ip", X.cpu().numpy(), Q[:512].cpu().numpy(), 51)
+    Dr, Ir = oracle.knn(metric, X.cpu().numpy(), Q[:512].cpu().numpy(), 51)
     assert np.array_equal(out[1][1][:512].cpu().numpy(), Ir)
 
 
