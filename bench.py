@@ -289,11 +289,18 @@ def bench_cifar(args, world, rank, dev):
     value = n_scored * world * args.steps / elapsed
     from lemon_amd.ops import gemm_mode as _gm
     gemm_mode = _gm()
-    gemm_note = ("the four GEMMs of every transformer block (QKV, output projection, fc1, fc2): lemon_linear_bf16x6 -- both fp32 operands "
-                 "split EXACTLY into three bf16 parts, the six cross products of order <= 2 summed by one hipBLASLt bf16 GEMM with fp32 "
-                 "accumulation (max relative error vs float64 6e-9, fp32 GEMM 3e-7; LEMON_GEMM=f32 switches it off); patch embedding / "
-                 "projections: lemon_linear_f32; recorded solution per shape, bias / SiLU / residual epilogues"
-                 if gemm_mode == "split" else "lemon_linear_f32 (hipBLASLt fp32, recorded solution per shape, SiLU/residual epilogues)")
+    gemm_notes = {
+        "bf16x6": "the four GEMMs of every transformer block (QKV, output projection, fc1, fc2): lemon_linear_bf16x6 -- both fp32 operands "
+                  "split EXACTLY into three bf16 parts, the six cross products of order <= 2 summed by one hipBLASLt bf16 GEMM with fp32 "
+                  "accumulation (delivered error vs float64 at the fp32 GEMM's level, tests/test_gpu_parity.py); patch embedding / projections: lemon_linear_f32; "
+                  "recorded solution per shape, bias / SiLU / residual epilogues; LEMON_GEMM = f32 | bf16x6 | f16x3 selects the mode",
+        "f16x3": "the four GEMMs of every transformer block (QKV, output projection, fc1, fc2): lemon_linear_f16x3 -- both fp32 operands "
+                 "split into two fp16 parts (hi = f16(v), lo = the exact remainder kept to 11 bits: 22 bits + sign), weights pre-scaled by a "
+                 "power of two, hi.hi + hi.lo + lo.hi summed by one hipBLASLt fp16 GEMM with fp32 accumulation (error vs float64 at the "
+                 "fp32 GEMM's level, tests/test_gpu_parity.py); patch embedding / projections: lemon_linear_f32; recorded solution per "
+                 "shape, bias / SiLU / residual epilogues; LEMON_GEMM = f32 | bf16x6 | f16x3 selects the mode",
+        "f32": "lemon_linear_f32 (hipBLASLt fp32, recorded solution per shape, SiLU/residual epilogues)"}
+    gemm_note = gemm_notes[gemm_mode]
     line = {
         "metric": "label-error scores/sec (embed+kNN), CIFAR-100 noise=0.4",
         "value": value, "unit": "scores/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -313,16 +320,17 @@ def bench_cifar(args, world, rank, dev):
         "encoder": {"bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F32_MFMA_TFLOPS, "gemm_mode": gemm_mode,
                     "achieved": (f_img + f_txt) * n_scored / max(stage["embed_s"], 1e-9) / 1e12,
                     "note": "algorithmic forward FLOPs (img+txt) of the fp32 model / embed stage wall time, against the fp32 MFMA peak; "
-                            "in gemm_mode 'split' the four GEMMs of every block run as 3-way bf16 split GEMMs (fp32-equivalent "
-                            "results, bf16 MFMA peak / 6 = 416.7 TFLOP/s-equivalent), the patch embedding and the projections stay fp32 GEMMs"},
+                            "in gemm_mode 'bf16x6' / 'f16x3' the four GEMMs of every block run as split GEMMs on the 16-bit matrix "
+                            "cores (fp32-equivalent results; 16-bit MFMA peak / 6 = 416.7, / 3 = 833 TFLOP/s-equivalent), the patch "
+                            "embedding and the projections stay fp32 GEMMs"},
     }
-    if gemm_mode == "split" and world == 1 and not args.no_f32_gemm_check:
+    if gemm_mode != "f32" and world == 1 and not args.no_f32_gemm_check:
         # the same step once more, untimed region of its own, with every GEMM on the fp32 matrix cores (LEMON_GEMM=f32): what
         # the split GEMMs buy, and the score difference between the two modes on the val split
         os.environ["LEMON_GEMM"] = "f32"
         t32 = {}
         recs32, _ = step(timers=t32)
-        os.environ["LEMON_GEMM"] = "split"
+        os.environ["LEMON_GEMM"] = gemm_mode
         ds_ = (recs32["val"]["score"] - recs["val"]["score"]).abs().max().item()
         line["encoder_f32_gemm_mode"] = {"embed_s": t32["embed_s"], "achieved": (f_img + f_txt) * n_scored / max(t32["embed_s"], 1e-9) / 1e12,
                                          "unit": "TFLOP/s", "max_abs_val_score_diff_vs_split": ds_,

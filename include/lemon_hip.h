@@ -161,8 +161,9 @@ int lemon_linear_f32(const float *x_dev, const float *w_dev, const float *bias_d
  * <= 2 are summed by ONE bf16 GEMM with fp32 accumulation over a 6k-long k axis:
  *     x6_dev [m, 6k] rows = [hi | hi | mid | hi | mid | lo]   (lemon_layernorm_split3, or lemon_split3_f32 with weight = 0)
  *     w6_dev [n, 6k] rows = [hi | mid | hi | lo | mid | hi]   (lemon_split3_f32 with weight = 1; once per weight)
- * k6 = 6k.  The dropped products are O(2^-24) of the result; against float64 the max relative error at the ViT-B/32 tower
- * shapes is 6e-9 (fp32 GEMM: 3e-7) -- tools/split_gemm_probe.py.  y_dev / bias_dev / residual_dev are float32. */
+ * k6 = 6k.  The dropped products are O(2^-24) of the result; what the GEMM delivers is bounded by its fp32 accumulation, like
+ * the fp32 GEMM's own result (max error vs float64, relative to the largest output, 1.3-2.1e-6 at the ViT-B/32 tower shapes;
+ * fp32 GEMM 1.0-2.1e-6 -- tools/split_gemm_probe.py).  y_dev / bias_dev / residual_dev are float32. */
 int lemon_linear_bf16x6(const uint16_t *x6_dev, const uint16_t *w6_dev, const float *bias_dev, const float *residual_dev,
                         int64_t m, int n, int k6, float alpha, int act, float *y_dev, void *stream);
 /* 3-way bf16 split of a row-major float32 matrix [rows, k] (k a multiple of 4) into lemon_linear_bf16x6's operand rows
@@ -171,6 +172,26 @@ int lemon_split3_f32(const float *x_dev, int64_t rows, int k, int weight, uint16
 /* lemon_layernorm_f32 whose result is written as the split activation operand y6_dev [rows, 6 width] bf16 (one pass). */
 int lemon_layernorm_split3(const float *x_dev, const float *weight_dev, const float *bias_dev, float eps, int64_t rows,
                            int width, uint16_t *y6_dev, void *stream);
+/* The same nn.Linear once more, with HALF the matrix work of lemon_linear_bf16x6: every fp32 operand value v is split into
+ * two fp16 parts, hi = f16(v) and lo = v - hi (exact in fp32; kept as f16(lo * 2^11): 11 + 11 significant bits and lo's sign,
+ * |v - hi - lo| <= 2^-23 |v|), and ONE fp16 GEMM with fp32 accumulation over a 3k-long k axis sums hi.hi + hi.lo + lo.hi:
+ *     x3_dev [m, 3k] rows = [hi | hi | lo 2^11]            (lemon_layernorm_f16x3 / lemon_attention_f16x3 / lemon_split_f16x3)
+ *     w3_dev [n, 3k] rows = [hi | lo | hi 2^-11] of w * wscale   (lemon_split_f16x3 with weight = 1; once per weight)
+ * wscale is a power of two chosen by the caller so that max |w| * wscale lies in [2^14, 2^15) (lo and hi 2^-11 of every
+ * weight that matters are then fp16 normals); the caller passes alpha / wscale as `alpha`.  k3 = 3k.  The dropped lo.lo
+ * product is <= 2^-22 (typically 2^-26) of a product: against float64 the result is as accurate as the fp32 GEMM's
+ * (tools/split_gemm_probe.py).  Operand values with |v| >= 65 520 (beyond fp16) turn the outputs they reach into NaN. */
+int lemon_linear_f16x3(const uint16_t *x3_dev, const uint16_t *w3_dev, const float *bias_dev, const float *residual_dev,
+                       int64_t m, int n, int k3, float alpha, int act, float *y_dev, void *stream);
+/* 2-way fp16 split of a row-major float32 matrix [rows, k] (k a multiple of 4) into lemon_linear_f16x3's operand rows
+ * y3_dev [rows, 3k] fp16; weight = 0: activation layout (wscale ignored), 1: weight layout of x * wscale (a power of two). */
+int lemon_split_f16x3(const float *x_dev, int64_t rows, int k, int weight, float wscale, uint16_t *y3_dev, void *stream);
+/* lemon_layernorm_f32 / lemon_attention_f32 whose result is written as the fp16 split activation operand (one pass):
+ * y3_dev [rows, 3 width], out3_dev [batch*seq_len, 3*heads*64], 16-byte aligned. */
+int lemon_layernorm_f16x3(const float *x_dev, const float *weight_dev, const float *bias_dev, float eps, int64_t rows,
+                          int width, uint16_t *y3_dev, void *stream);
+int lemon_attention_f16x3(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
+                          int causal, uint16_t *out3_dev, void *stream);
 /* Recorded solution choices: a "# lemon_linear hipblaslt=<version> arch=<gfx name>" stamp line followed by
  * "m,n,k,epilogue,residual,index,usec" lines.  load returns the number of keys taken -- 0 when the stamp
  * does not match this process's hipBLASLt version / device arch (the file is then ignored) -- and dump the

@@ -124,8 +124,9 @@ class Block(nn.Module):
             # inference on the GPU: every GEMM of the block goes through lemon_linear_f32 (bias, QuickGELU
             # and the residual adds ride in the hipBLASLt epilogue), attention through lemon_attention_f32
             from . import ops
-            if W % 4 == 0 and W <= 1024 and ops.gemm_mode() != "f32":
-                return self._forward_split(x, causal, rows, ops)
+            mode = ops.gemm_mode()
+            if W % 4 == 0 and W <= 1024 and mode != "f32":
+                return self._forward_split(x, causal, rows, ops, mode)
             ln = lambda m, t: ops.layer_norm(t, m.weight, m.bias, m.eps) if t.shape[-1] % 4 == 0 else m(t)
             qkv = ops.linear(ln(self.ln1, x), self.qkv.weight, self.qkv.bias)
             if W == 64 * self.heads and L <= ops.ATTENTION_MAX_SEQ:
@@ -147,39 +148,46 @@ class Block(nn.Module):
         h = h * torch.sigmoid(1.702 * h)          # QuickGELU
         return x + self.fc2(h)
 
-    def _w6(self, name, ops):
-        """The layer's weight as the split bf16 operand [n, 6k], made once per weight version (inference: once)."""
+    def _w_split(self, name, ops, mode):
+        """The layer's weight as the split operand of `mode` ([n, 6k] bf16 / [n, 3k] fp16 of w * wscale) and 1 / wscale, made
+        once per weight version (inference: once)."""
         w = getattr(self, name).weight
         cache = self.__dict__.setdefault("_split_cache", {})
-        hit = cache.get(name)
+        hit = cache.get((name, mode))
         if hit is None or hit[0] != (w.data_ptr(), w._version):
-            hit = ((w.data_ptr(), w._version), ops.split3(w.detach(), weight=True))
-            cache[name] = hit
-        return hit[1]
+            wscale = ops.weight_scale_f16x3(w) if mode == "f16x3" else 1.0
+            hit = ((w.data_ptr(), w._version), ops.split_operand(w.detach(), mode, weight=True, wscale=wscale), 1.0 / wscale)
+            cache[(name, mode)] = hit
+        return hit[1], hit[2]
 
-    def _forward_split(self, x, causal, rows, ops):
-        """The fused inference path with the four GEMMs of the block (QKV, output projection, fc1, fc2) on the bf16 matrix cores
-        at fp32-equivalent accuracy (ops.linear_split3: exact 3-way bf16 splits of both operands, six cross products, fp32
-        accumulate); LayerNorm and attention write the split operand directly, the MLP activations get one split pass."""
+    def _forward_split(self, x, causal, rows, ops, mode):
+        """The fused inference path with the four GEMMs of the block (QKV, output projection, fc1, fc2) on the 16-bit matrix
+        cores at fp32-equivalent accuracy (ops.linear_split: exact splits of both operands -- 3-way bf16, six cross products, or
+        2-way fp16, three --, fp32 accumulate); LayerNorm and attention write the split operand directly, the MLP activations
+        get one split pass."""
         B, L, W = x.shape
-        qkv = ops.linear_split3(ops.layer_norm_split3(x, self.ln1.weight, self.ln1.bias, self.ln1.eps), self._w6("qkv", ops), self.qkv.bias)
+        w, a_ = self._w_split("qkv", ops, mode)
+        qkv = ops.linear_split(ops.layer_norm_split(x, self.ln1.weight, self.ln1.bias, self.ln1.eps, mode), w, self.qkv.bias, alpha=a_)
         hip_attn = W == 64 * self.heads and L <= ops.ATTENTION_MAX_SEQ
         if hip_attn and rows is None:
-            a6 = ops.attention_split3(qkv, self.heads, causal)      # the attention kernel stores the split operand itself
+            a6 = ops.attention_split(qkv, self.heads, causal, mode)      # the attention kernel stores the split operand itself
         else:
             a = ops.attention(qkv, self.heads, causal) if hip_attn else self._sdpa(qkv, B, L, W, causal)
             if rows is not None:
                 a, x = a[rows].contiguous(), x[rows].contiguous()
-            a6 = ops.split3(a)
-        x = ops.linear_split3(a6, self._w6("out", ops), self.out.bias, residual=x)
+            a6 = ops.split_operand(a, mode)
+        w, a_ = self._w_split("out", ops, mode)
+        x = ops.linear_split(a6, w, self.out.bias, residual=x, alpha=a_)
         s = ops.QUICK_GELU_SCALE
-        h = ops.linear_split3(ops.layer_norm_split3(x, self.ln2.weight, self.ln2.bias, self.ln2.eps), self._w6("fc1", ops),
-                              self.fc1.bias * s, act="silu", alpha=s)
-        # fc2: one split pass over the [m, mlp] activations (16 B per element, ~370 us at the headline shape) buys a GEMM of
-        # 1 268 us instead of 1 590 us in the tuner -- and 1 820 us inside the step, where the fp32 GEMMs run at lower clocks
-        # than in isolation while the bf16 ones do not: 17.3 k against 16.7 k scores/s on the same box (twice, alternating).
-        # (With only position-independent solutions allowed for this shape the trade was a loss: 1 593 us, 16.7 k vs 17.1 k.)
-        return ops.linear_split3(ops.split3(h), self._w6("fc2", ops), self.fc2.bias, residual=x, alpha=1.0 / s)
+        w, a_ = self._w_split("fc1", ops, mode)
+        h = ops.linear_split(ops.layer_norm_split(x, self.ln2.weight, self.ln2.bias, self.ln2.eps, mode), w,
+                             self.fc1.bias * s, act="silu", alpha=s * a_)
+        # fc2: one split pass over the [m, mlp] activations (bf16x6: 16 B per element, ~330 us at the headline shape) buys a
+        # GEMM of 1 268 us instead of 1 590 us in the tuner -- and 1 820 us inside the step, where the fp32 GEMMs run at lower
+        # clocks than in isolation while the 16-bit ones do not: 17.3 k against 16.7 k scores/s on the same box (twice,
+        # alternating).  (With only position-independent solutions allowed for this shape the trade was a loss.)
+        w, a_ = self._w_split("fc2", ops, mode)
+        return ops.linear_split(ops.split_operand(h, mode), w, self.fc2.bias, residual=x, alpha=a_ / s)
 
     def _sdpa(self, qkv, B, L, W, causal):
         q, k, v = qkv.view(B, L, 3, self.heads, W // self.heads).permute(2, 0, 3, 1, 4)

@@ -29,8 +29,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int HD = 64;        // head dimension (every CLIP variant the reference loads: 768/12, 512/8, 1024/16)
 constexpr int PITCH = 68;     // LDS row pitch in floats
 
-// SPLIT: `out` is the [B*L, 6*H*64] bf16 activation operand of lemon_linear_bf16x6 (the fp32 result split 3-way at the store)
-template <bool SPLIT>
+// SPLIT 1: `out` is the [B*L, 6*H*64] bf16 activation operand of lemon_linear_bf16x6 (the fp32 result split 3-way at the
+// store); SPLIT 2: the [B*L, 3*H*64] fp16 operand of lemon_linear_f16x3
+template <int SPLIT>
 __global__ __launch_bounds__(576) void k_attention_hd64(const float *__restrict__ qkv, int L, int H, int causal,
                                                         float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -144,15 +145,15 @@ __global__ __launch_bounds__(576) void k_attention_hd64(const float *__restrict_
     if (qi < L) {
         const float inv = 1.0f / l_run;
         float *dst = out + ((b * L + qi) * H + head) * HD;
-        unsigned short *row6 = reinterpret_cast<unsigned short *>(out) + (b * L + qi) * 6 * (int64_t)(H * HD);
+        unsigned short *row6 = reinterpret_cast<unsigned short *>(out) + (b * L + qi) * lemon_split::split_segments(SPLIT) * (int64_t)(H * HD);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int c0 = 8 * g + 4 * h;
             const float4 v0 = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
             const float4 v1 = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
             if (SPLIT) {
-                lemon_split::store_split4<false>(row6, H * HD, (head * HD + c0) >> 2, v0);
-                lemon_split::store_split4<false>(row6, H * HD, (head * HD + 32 + c0) >> 2, v1);
+                lemon_split::store_split4<SPLIT ? SPLIT : 1, false>(row6, H * HD, (head * HD + c0) >> 2, v0);
+                lemon_split::store_split4<SPLIT ? SPLIT : 1, false>(row6, H * HD, (head * HD + 32 + c0) >> 2, v1);
             } else {
                 *reinterpret_cast<float4 *>(dst + c0) = v0;
                 *reinterpret_cast<float4 *>(dst + 32 + c0) = v1;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(576) void k_attention_hd64(const float *__restrict_
 // on the complete row (no running rescale) and K is dead by the time V is needed.  Half the LDS of the general kernel
 // (17 KB at TJ = 2): the CU holds six workgroups instead of four, which is what this latency-bound shape was short of
 // (MFMA pipe busy 0.40, 3.6 TB/s with four).
-template <int TJ, bool SPLIT>
+template <int TJ, int SPLIT>
 __global__ __launch_bounds__(64 * TJ) void k_attention_hd64_short(const float *__restrict__ qkv, int L, int H, int causal,
                                                                   float *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) float sKV[32 * TJ * PITCH];
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(64 * TJ) void k_attention_hd64_short(const float *_
             const float4 v0 = *reinterpret_cast<const float4 *>(&sKV[r * PITCH + 8 * c8]);
             const float4 v1 = *reinterpret_cast<const float4 *>(&sKV[r * PITCH + 8 * c8 + 4]);
             if (SPLIT)
-                lemon_split::store_split8<false>(reinterpret_cast<unsigned short *>(out) + (b * L + r) * 6 * (int64_t)(H * HD), H * HD,
+                lemon_split::store_split8<SPLIT ? SPLIT : 1, false>(reinterpret_cast<unsigned short *>(out) + (b * L + r) * lemon_split::split_segments(SPLIT) * (int64_t)(H * HD), H * HD,
                                                  head * (HD / 8) + c8, v0, v1);
             else {
                 float *dst = out + ((b * L + r) * H + head) * HD + 8 * c8;
@@ -322,7 +323,8 @@ __global__ __launch_bounds__(64 * TJ) void k_attention_hd64_short(const float *_
 
 }  // namespace
 
-static int attention_impl(bool split, const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
+template <int SPLIT>
+static int attention_impl(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
                           int causal, float *out_dev, void *stream) {
     LEMON_REQUIRE(batch >= 0 && seq_len > 0 && heads > 0, "batch >= 0, seq_len > 0, heads > 0");
     LEMON_REQUIRE(head_dim == HD, "head_dim must be 64");
@@ -335,38 +337,36 @@ static int attention_impl(bool split, const float *qkv_dev, int64_t batch, int s
     static const bool short_off = [] { const char *e = getenv("LEMON_ATTN_SHORT"); return e && e[0] == '0'; }();   // tuning knob
     const dim3 grid((unsigned)(batch * heads));
     if (tj <= 2 && !short_off) {
-        if (tj == 1) {
-            if (split) hipLaunchKernelGGL((k_attention_hd64_short<1, true>), grid, dim3(64), 0, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
-            else       hipLaunchKernelGGL((k_attention_hd64_short<1, false>), grid, dim3(64), 0, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
-        } else {
-            if (split) hipLaunchKernelGGL((k_attention_hd64_short<2, true>), grid, dim3(128), 0, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
-            else       hipLaunchKernelGGL((k_attention_hd64_short<2, false>), grid, dim3(128), 0, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
-        }
+        if (tj == 1) hipLaunchKernelGGL((k_attention_hd64_short<1, SPLIT>), grid, dim3(64), 0, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
+        else         hipLaunchKernelGGL((k_attention_hd64_short<2, SPLIT>), grid, dim3(128), 0, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
         LEMON_HIP_CHECK(hipGetLastError());
         return LEMON_OK;
     }
     const size_t lds = (size_t)2 * 32 * tj * PITCH * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attention_hd64<false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attention_hd64<true>),
+        LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attention_hd64<SPLIT>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    if (split) hipLaunchKernelGGL(k_attention_hd64<true>, grid, dim3(64 * tj), lds, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
-    else       hipLaunchKernelGGL(k_attention_hd64<false>, grid, dim3(64 * tj), lds, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
+    hipLaunchKernelGGL(k_attention_hd64<SPLIT>, grid, dim3(64 * tj), lds, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
     LEMON_HIP_CHECK(hipGetLastError());
     return LEMON_OK;
 }
 
 extern "C" int lemon_attention_f32(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
                                    int causal, float *out_dev, void *stream) {
-    return attention_impl(false, qkv_dev, batch, seq_len, heads, head_dim, causal, out_dev, stream);
+    return attention_impl<0>(qkv_dev, batch, seq_len, heads, head_dim, causal, out_dev, stream);
 }
 
 // lemon_attention_f32 whose output is the split activation operand of lemon_linear_bf16x6: out6_dev [batch*seq_len, 6*heads*64] bf16
 extern "C" int lemon_attention_split3(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
                                       int causal, uint16_t *out6_dev, void *stream) {
-    return attention_impl(true, qkv_dev, batch, seq_len, heads, head_dim, causal, reinterpret_cast<float *>(out6_dev), stream);
+    return attention_impl<1>(qkv_dev, batch, seq_len, heads, head_dim, causal, reinterpret_cast<float *>(out6_dev), stream);
+}
+
+// ... of lemon_linear_f16x3: out3_dev [batch*seq_len, 3*heads*64] fp16
+extern "C" int lemon_attention_f16x3(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
+                                     int causal, uint16_t *out3_dev, void *stream) {
+    return attention_impl<2>(qkv_dev, batch, seq_len, heads, head_dim, causal, reinterpret_cast<float *>(out3_dev), stream);
 }

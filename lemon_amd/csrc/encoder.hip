@@ -14,17 +14,17 @@ using namespace lemon_split;
 
 namespace {
 
-template <bool WEIGHT>
-__global__ __launch_bounds__(256) void k_split3_rows(const float *__restrict__ x, int64_t rows, int k, unsigned short *__restrict__ y6) {
+template <int SCHEME, bool WEIGHT>
+__global__ __launch_bounds__(256) void k_split3_rows(const float *__restrict__ x, int64_t rows, int k, unsigned short *__restrict__ y6, float wscale) {
     const int nch = k >> 2;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= rows * nch) return;
     const int64_t r = t / nch;
     const int c = (int)(t - r * nch);
-    store_split4<WEIGHT>(y6 + r * 6 * (int64_t)k, k, c, reinterpret_cast<const float4 *>(x + r * (int64_t)k)[c]);
+    store_split4<SCHEME, WEIGHT>(y6 + r * split_segments(SCHEME) * (int64_t)k, k, c, reinterpret_cast<const float4 *>(x + r * (int64_t)k)[c], wscale);
 }
 
-template <int CH, bool SPLIT = false>   // float4 chunks per lane: width <= 256*CH; SPLIT: y is the [rows, 6 width] bf16 activation operand
+template <int CH, int SPLIT = 0>   // float4 chunks per lane: width <= 256*CH; SPLIT 1 / 2: y is the [rows, 6 width] bf16 / [rows, 3 width] fp16 activation operand
 __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, const float *__restrict__ w,
                                                    const float *__restrict__ b, float eps, int64_t rows, int width,
                                                    float *__restrict__ y) {
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
             o.y = (v[i].y - mean) * rstd * ww.y + bb.y;
             o.z = (v[i].z - mean) * rstd * ww.z + bb.z;
             o.w = (v[i].w - mean) * rstd * ww.w + bb.w;
-            if (SPLIT) store_split4<false>(reinterpret_cast<unsigned short *>(y) + row * 6 * (int64_t)width, width, c, o);
+            if (SPLIT) store_split4<SPLIT ? SPLIT : 1, false>(reinterpret_cast<unsigned short *>(y) + row * split_segments(SPLIT) * (int64_t)width, width, c, o);
             else yr[c] = o;
         }
     }
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
 // LayerNorm for widths that are multiples of 8: every lane owns EIGHT consecutive elements per chunk (two float4), so the
 // split variant stores 16 bytes per segment instead of 8 (94 -> see DESIGN us per 50 000 x 768 rows); the fp32 variant uses
 // the same element-to-lane mapping, so lemon_layernorm_split3 == lemon_split3_f32(lemon_layernorm_f32) bit for bit.
-template <int CH8, bool SPLIT>   // 8-element chunks per lane: width <= 512*CH8
+template <int CH8, int SPLIT>   // 8-element chunks per lane: width <= 512*CH8
 __global__ __launch_bounds__(256) void k_layernorm8(const float *__restrict__ x, const float *__restrict__ w,
                                                     const float *__restrict__ b, float eps, int64_t rows, int width,
                                                     float *__restrict__ y) {
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void k_layernorm8(const float *__restrict__ x,
                 o[hf].z = (v[i][hf].z - mean) * rstd * ww.z + bb.z;
                 o[hf].w = (v[i][hf].w - mean) * rstd * ww.w + bb.w;
             }
-            if (SPLIT) store_split8<false>(reinterpret_cast<unsigned short *>(y) + row * 6 * (int64_t)width, width, c, o[0], o[1]);
+            if (SPLIT) store_split8<SPLIT ? SPLIT : 1, false>(reinterpret_cast<unsigned short *>(y) + row * split_segments(SPLIT) * (int64_t)width, width, c, o[0], o[1]);
             else { yr[2 * c] = o[0]; yr[2 * c + 1] = o[1]; }
         }
     }
@@ -251,9 +251,9 @@ extern "C" int lemon_layernorm_f32(const float *x_dev, const float *weight_dev, 
     hipStream_t stream = (hipStream_t)stream_;
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     if ((width & 7) == 0) {
-        if (width <= 512) hipLaunchKernelGGL((k_layernorm8<1, false>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
-        else if (width <= 1024) hipLaunchKernelGGL((k_layernorm8<2, false>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
-        else hipLaunchKernelGGL((k_layernorm8<4, false>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
+        if (width <= 512) hipLaunchKernelGGL((k_layernorm8<1, 0>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
+        else if (width <= 1024) hipLaunchKernelGGL((k_layernorm8<2, 0>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
+        else hipLaunchKernelGGL((k_layernorm8<4, 0>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
     }
     else if (width <= 512) hipLaunchKernelGGL(k_layernorm<2>, grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
     else if (width <= 1024) hipLaunchKernelGGL(k_layernorm<4>, grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y_dev);
@@ -262,10 +262,11 @@ extern "C" int lemon_layernorm_f32(const float *x_dev, const float *weight_dev, 
     return LEMON_OK;
 }
 
-// LayerNorm whose output is the 3-way bf16 split activation operand of lemon_linear_bf16x6 ([rows, 6 width] bf16): the same
-// arithmetic as lemon_layernorm_f32 (the fp32 result is split, not recomputed), one pass.
-extern "C" int lemon_layernorm_split3(const float *x_dev, const float *weight_dev, const float *bias_dev, float eps,
-                                      int64_t rows, int width, uint16_t *y6_dev, void *stream_) {
+// LayerNorm whose output is the split activation operand of lemon_linear_bf16x6 ([rows, 6 width] bf16) or lemon_linear_f16x3
+// ([rows, 3 width] fp16): the same arithmetic as lemon_layernorm_f32 (the fp32 result is split, not recomputed), one pass.
+template <int SCHEME>
+static int layernorm_split_impl(const float *x_dev, const float *weight_dev, const float *bias_dev, float eps,
+                                int64_t rows, int width, uint16_t *y6_dev, void *stream_) {
     LEMON_REQUIRE(rows >= 0 && width > 0 && (width & 3) == 0 && width <= 2048, "rows >= 0, width a multiple of 4, <= 2048");
     if (rows == 0) return LEMON_OK;
     LEMON_REQUIRE(x_dev && weight_dev && bias_dev && y6_dev, "null pointer");
@@ -275,27 +276,49 @@ extern "C" int lemon_layernorm_split3(const float *x_dev, const float *weight_de
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     float *y = reinterpret_cast<float *>(y6_dev);
     if ((width & 7) == 0 && (((uintptr_t)y6_dev) & 15) == 0) {
-        if (width <= 512) hipLaunchKernelGGL((k_layernorm8<1, true>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
-        else if (width <= 1024) hipLaunchKernelGGL((k_layernorm8<2, true>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
-        else hipLaunchKernelGGL((k_layernorm8<4, true>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
+        if (width <= 512) hipLaunchKernelGGL((k_layernorm8<1, SCHEME>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
+        else if (width <= 1024) hipLaunchKernelGGL((k_layernorm8<2, SCHEME>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
+        else hipLaunchKernelGGL((k_layernorm8<4, SCHEME>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
     }
-    else if (width <= 512) hipLaunchKernelGGL((k_layernorm<2, true>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
-    else if (width <= 1024) hipLaunchKernelGGL((k_layernorm<4, true>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
-    else hipLaunchKernelGGL((k_layernorm<8, true>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
+    else if (width <= 512) hipLaunchKernelGGL((k_layernorm<2, SCHEME>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
+    else if (width <= 1024) hipLaunchKernelGGL((k_layernorm<4, SCHEME>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
+    else hipLaunchKernelGGL((k_layernorm<8, SCHEME>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
     LEMON_HIP_CHECK(hipGetLastError());
     return LEMON_OK;
 }
+extern "C" int lemon_layernorm_split3(const float *x_dev, const float *weight_dev, const float *bias_dev, float eps,
+                                      int64_t rows, int width, uint16_t *y6_dev, void *stream_) {
+    return layernorm_split_impl<1>(x_dev, weight_dev, bias_dev, eps, rows, width, y6_dev, stream_);
+}
+extern "C" int lemon_layernorm_f16x3(const float *x_dev, const float *weight_dev, const float *bias_dev, float eps,
+                                     int64_t rows, int width, uint16_t *y3_dev, void *stream_) {
+    return layernorm_split_impl<2>(x_dev, weight_dev, bias_dev, eps, rows, width, y3_dev, stream_);
+}
 
+template <int SCHEME>
+static int split_rows_impl(const float *x_dev, int64_t rows, int k, int weight, float wscale, uint16_t *y_dev, void *stream_) {
+    LEMON_REQUIRE(rows >= 0 && k > 0 && (k & 3) == 0, "rows >= 0, k a multiple of 4");
+    if (rows == 0) return LEMON_OK;
+    LEMON_REQUIRE(x_dev && y_dev && (((uintptr_t)x_dev) & 15) == 0 && (((uintptr_t)y_dev) & 7) == 0, "aligned pointers");
+    const int64_t threads = rows * (k >> 2);
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    if (weight) hipLaunchKernelGGL((k_split3_rows<SCHEME, true>), grid, block, 0, (hipStream_t)stream_, x_dev, rows, k, y_dev, wscale);
+    else hipLaunchKernelGGL((k_split3_rows<SCHEME, false>), grid, block, 0, (hipStream_t)stream_, x_dev, rows, k, y_dev, wscale);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}
 // 3-way bf16 split of a row-major fp32 matrix [rows, k] into the 6k-long operand rows of lemon_linear_bf16x6:
 // weight = 0: activation layout [hi | hi | mid | hi | mid | lo]; weight = 1: weight layout [hi | mid | hi | lo | mid | hi].
 extern "C" int lemon_split3_f32(const float *x_dev, int64_t rows, int k, int weight, uint16_t *y6_dev, void *stream_) {
-    LEMON_REQUIRE(rows >= 0 && k > 0 && (k & 3) == 0, "rows >= 0, k a multiple of 4");
-    if (rows == 0) return LEMON_OK;
-    LEMON_REQUIRE(x_dev && y6_dev && (((uintptr_t)x_dev) & 15) == 0 && (((uintptr_t)y6_dev) & 7) == 0, "aligned pointers");
-    const int64_t threads = rows * (k >> 2);
-    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
-    if (weight) hipLaunchKernelGGL(k_split3_rows<true>, grid, block, 0, (hipStream_t)stream_, x_dev, rows, k, y6_dev);
-    else hipLaunchKernelGGL(k_split3_rows<false>, grid, block, 0, (hipStream_t)stream_, x_dev, rows, k, y6_dev);
-    LEMON_HIP_CHECK(hipGetLastError());
-    return LEMON_OK;
+    return split_rows_impl<1>(x_dev, rows, k, weight, 1.0f, y6_dev, stream_);
+}
+// 2-way fp16 split of a row-major fp32 matrix [rows, k] into the 3k-long operand rows of lemon_linear_f16x3:
+// weight = 0: activation layout [hi | hi | lo 2^11] of x; weight = 1: weight layout [hi | lo | hi 2^-11] of x * wscale
+// (wscale: a power of two, see lemon_linear_f16x3; ignored for activations).
+extern "C" int lemon_split_f16x3(const float *x_dev, int64_t rows, int k, int weight, float wscale, uint16_t *y3_dev, void *stream_) {
+    if (weight) {
+        int e = 0;
+        LEMON_REQUIRE(wscale > 0.0f && std::frexp(wscale, &e) == 0.5f, "wscale must be a power of two");
+    }
+    return split_rows_impl<2>(x_dev, rows, k, weight, wscale, y3_dev, stream_);
 }

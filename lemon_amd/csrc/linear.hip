@@ -53,7 +53,7 @@ namespace {
         }                                                                                           \
     } while (0)
 
-typedef std::tuple<int64_t, int, int, int, int, int> LinKey;   // m, n, k, epilogue, has_residual, operand type (0 f32, 1 bf16)
+typedef std::tuple<int64_t, int, int, int, int, int> LinKey;   // m, n, k, epilogue, has_residual, operand type (0 f32, 1 bf16, 2 fp16)
 
 struct LinState {
     hipblasLtHandle_t handle = nullptr;
@@ -122,8 +122,9 @@ struct Problem {
 
 // Row-major y[m,n] = x[m,k] W[n,k]^T is, in hipBLASLt's column-major terms, D[n,m] = op_T(A[k,n]) B[k,m]
 // with A = W (ld k), B = x (ld k), C/D = residual/y (ld n); the bias runs along D's rows (n).
-// dt = 1: A (weights) and B (activations) are bf16 -- the 6k-long concatenated split operands of lemon_linear_bf16x6 --
-// C / D / bias / scale type stay fp32, the products accumulate in fp32
+// dt = 1: A (weights) and B (activations) are bf16 -- the 6k-long concatenated split operands of lemon_linear_bf16x6 --,
+// dt = 2: fp16, the 3k-long operands of lemon_linear_f16x3; C / D / bias / scale type stay fp32, the products accumulate in fp32
+inline hipDataType operand_type(int dt) { return dt == 1 ? HIP_R_16BF : dt == 2 ? HIP_R_16F : HIP_R_32F; }
 int make_problem(Problem &p, int64_t m, int n, int k, int epilogue, const float *bias, int dt = 0) {
     LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
     if (dt) {
@@ -136,7 +137,7 @@ int make_problem(Problem &p, int64_t m, int n, int k, int epilogue, const float 
     const hipblasLtEpilogue_t epi = (hipblasLtEpilogue_t)epilogue;
     LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)));
     if (bias) LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
-    const hipDataType ot = dt ? HIP_R_16BF : HIP_R_32F;
+    const hipDataType ot = operand_type(dt);
     LT_CHECK(hipblasLtMatrixLayoutCreate(&p.la, ot, (uint64_t)k, (uint64_t)n, k));
     LT_CHECK(hipblasLtMatrixLayoutCreate(&p.lb, ot, (uint64_t)k, (uint64_t)m, k));
     LT_CHECK(hipblasLtMatrixLayoutCreate(&p.lc, HIP_R_32F, (uint64_t)n, (uint64_t)m, n));
@@ -201,7 +202,7 @@ bool supported(Problem &p, hipblasLtMatmulAlgo_t &algo, float beta) {
 // benchmark the solutions that support this problem; returns the winner (synchronises the stream)
 int tune(const LinKey &key, Problem &p, const void *x, const void *w, const float *residual, int64_t m, int n,
          hipStream_t stream, hipblasLtMatmulAlgo_t *best_out) {
-    const hipDataType ot = std::get<5>(key) ? HIP_R_16BF : HIP_R_32F;
+    const hipDataType ot = operand_type(std::get<5>(key));
     const float beta = residual ? 1.0f : 0.0f;
     float *scratch = nullptr;
     LEMON_HIP_CHECK(hipMalloc((void **)&scratch, (size_t)m * n * sizeof(float)));
@@ -457,13 +458,27 @@ extern "C" int lemon_linear_f32(const float *x_dev, const float *w_dev, const fl
 // operands (x = hi + mid + lo, each part bf16; lemon_split3_f32 / lemon_layernorm_split3) laid out so that ONE bf16 GEMM over
 // the 6k-long k axis sums the six cross products of order <= 2 (hi.hi, hi.mid, mid.hi, hi.lo, mid.mid, lo.hi) in fp32:
 //     x6 row = [hi | hi | mid | hi | mid | lo],   w6 row = [hi | mid | hi | lo | mid | hi].
-// The dropped products are O(2^-24) of the result: measured against float64 the emulation is MORE accurate than the fp32
-// GEMM (6e-9 vs 3e-7 max relative error at the tower shapes, tools/split_gemm_probe.py) and 1.7-2.0x faster.
+// The dropped products are O(2^-24) of the result; the delivered error is bounded by the fp32 accumulation in the matrix pipe,
+// as for the fp32 GEMM (max error vs float64 relative to the largest output 1.3-2.1e-6 at the tower shapes, fp32 GEMM 1.0-2.1e-6;
+// tools/split_gemm_probe.py), at 1.4x the fp32 GEMM's speed.
 // k6 = 6 k.  Same epilogues, same solution policy (keys carry the operand type) as lemon_linear_f32.
 extern "C" int lemon_linear_bf16x6(const uint16_t *x6_dev, const uint16_t *w6_dev, const float *bias_dev, const float *residual_dev,
                                    int64_t m, int n, int k6, float alpha, int act, float *y_dev, void *stream_) {
     LEMON_REQUIRE(k6 % 6 == 0, "k6 must be 6 * k");
     return linear_impl(1, x6_dev, w6_dev, bias_dev, residual_dev, m, n, k6, alpha, act, y_dev, stream_);
+}
+
+// fp32-equivalent linear layer on the fp16 matrix cores with HALF the products of lemon_linear_bf16x6: x3 [m, 3k] and w3 [n, 3k]
+// are the 2-way fp16 splits (lemon_split_f16x3 / lemon_layernorm_f16x3 / lemon_attention_f16x3):
+//     x3 row = [hi | hi | lo 2^11],   w3 row = [hi | lo | hi 2^-11]  of  w * wscale,
+// so ONE fp16 GEMM over the 3k-long k axis sums hi.hi + hi.lo + lo.hi in fp32; the caller passes alpha / wscale as `alpha`.
+// 22 significant bits + the sign of lo per operand and a dropped lo.lo term of <= 2^-22 (typically 2^-26) of a product: against
+// float64 the result is as accurate as the fp32 GEMM's (tools/split_gemm_probe.py).  Operand values beyond the fp16 range
+// (|x| >= 65 520) turn the affected outputs into NaN.  k3 = 3 k.
+extern "C" int lemon_linear_f16x3(const uint16_t *x3_dev, const uint16_t *w3_dev, const float *bias_dev, const float *residual_dev,
+                                  int64_t m, int n, int k3, float alpha, int act, float *y_dev, void *stream_) {
+    LEMON_REQUIRE(k3 % 3 == 0, "k3 must be 3 * k");
+    return linear_impl(2, x3_dev, w3_dev, bias_dev, residual_dev, m, n, k3, alpha, act, y_dev, stream_);
 }
 
 // Results file: first line "# lemon_linear hipblaslt=<int> arch=<name>", then m,n,k,epilogue,residual,index,usec rows.
@@ -508,7 +523,7 @@ extern "C" int lemon_linear_dump_tuned(const char *path) {
     FILE *f = fopen(path, "w");
     if (!f) { lemon_set_error("cannot write %s", path); return LEMON_E_INVALID; }
     fprintf(f, "# lemon_linear hipblaslt=%d arch=%s\n", g_lin.version, g_lin.arch);
-    fprintf(f, "# m,n,k,epilogue,residual,hipblaslt_solution_index,usec[,operand type: 1 = bf16 split operands, k = 6 x the layer's k]   (y = act(x W^T + b) [+ residual])\n");
+    fprintf(f, "# m,n,k,epilogue,residual,hipblaslt_solution_index,usec[,operand type: 1 = bf16 split operands, k = 6 x the layer's k; 2 = fp16 split operands, k = 3 x]   (y = act(x W^T + b) [+ residual])\n");
     int rows = 0;
     for (const auto &kv : g_lin.index) {
         const LinKey &key = kv.first;

@@ -150,59 +150,106 @@ def linear(x, weight, bias=None, residual=None, act=None, alpha=1.0):
     return y
 
 
-# ---- fp32-equivalent GEMMs on the bf16 matrix cores (3-way split operands, lemon_linear_bf16x6) -------------------------
+# ---- fp32-equivalent GEMMs on the 16-bit matrix cores (split operands: lemon_linear_bf16x6 / lemon_linear_f16x3) -----------
+_SCHEMES = {"bf16x6": (torch.bfloat16, 6), "f16x3": (torch.float16, 3)}
+
+
 def gemm_mode():
-    """'split' (default): the four GEMMs of every transformer block run as 3-way bf16 split GEMMs (fp32-equivalent accuracy,
-    1.3-1.5x faster than the tuned fp32 GEMMs); 'f32': every GEMM on the fp32 matrix cores (LEMON_GEMM=f32)."""
+    """How the four GEMMs of every transformer block run (LEMON_GEMM):
+    'f16x3' (default): 2-way fp16 split operands, three cross products, one fp16 GEMM over 3k -- the fp32 GEMM's accuracy
+        (max / rms error vs float64 measured slightly below it), 2.4x faster than the tuned fp32 GEMMs at the tower shapes;
+    'bf16x6' (alias 'split'): 3-way bf16 split operands, six cross products, one bf16 GEMM over 6k (same delivered accuracy --
+        fp32 accumulation bounds both --, no fp16 range limit on the operands, 1.4x faster than fp32);
+    'f32': every GEMM on the fp32 matrix cores."""
     import os
-    return "f32" if os.environ.get("LEMON_GEMM", "split").lower() in ("f32", "fp32", "0") else "split"
+    v = os.environ.get("LEMON_GEMM", DEFAULT_GEMM_MODE).lower()
+    if v in ("f32", "fp32", "0"):
+        return "f32"
+    if v in ("split", "bf16x6"):
+        return "bf16x6"
+    if v in ("f16x3", "fp16x3"):
+        return "f16x3"
+    raise ValueError(f"LEMON_GEMM={v!r}: expected f32, bf16x6 (split) or f16x3")
+
+
+DEFAULT_GEMM_MODE = "f16x3"
+
+
+def weight_scale_f16x3(w):
+    """The power of two that lifts max|w| into [2^14, 2^15) -- the `wscale` of lemon_split_f16x3 (one host read per weight)."""
+    mx = float(w.detach().abs().max())
+    if not (mx > 0.0) or mx != mx or mx == float("inf"):
+        return 1.0
+    import math
+    return 2.0 ** (15 - math.frexp(mx)[1])
+
+
+def split_operand(x, mode="bf16x6", weight=False, wscale=1.0):
+    """float32 [..., k] -> the split operand rows of `mode` ([..., 6k] bf16 or [..., 3k] fp16): activation layout, or the weight
+    layout (f16x3: of x * wscale)."""
+    dtype, seg = _SCHEMES[mode]
+    assert x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0
+    x = x.contiguous()
+    k = x.shape[-1]
+    y = torch.empty(x.shape[:-1] + (seg * k,), dtype=dtype, device=x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        if mode == "bf16x6":
+            _lib.check(lib.lemon_split3_f32(ptr(x), x.numel() // k, k, int(bool(weight)), ptr(y), stream_ptr(x.device)), "lemon_split3_f32")
+        else:
+            _lib.check(lib.lemon_split_f16x3(ptr(x), x.numel() // k, k, int(bool(weight)), float(wscale), ptr(y), stream_ptr(x.device)),
+                       "lemon_split_f16x3")
+    return y
 
 
 def split3(x, weight=False):
     """float32 [..., k] -> bf16 [..., 6k] split operand rows (activation layout, or the weight layout)."""
-    assert x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0
+    return split_operand(x, "bf16x6", weight)
+
+
+def layer_norm_split(x, weight, bias, eps=1e-5, mode="bf16x6"):
+    """LayerNorm whose output is the split activation operand of `mode` (one pass: lemon_layernorm_split3 / _f16x3)."""
+    dtype, seg = _SCHEMES[mode]
+    assert x.is_cuda and x.dtype == torch.float32
     x = x.contiguous()
-    k = x.shape[-1]
-    y = torch.empty(x.shape[:-1] + (6 * k,), dtype=torch.bfloat16, device=x.device)
+    width = x.shape[-1]
+    y = torch.empty(x.shape[:-1] + (seg * width,), dtype=dtype, device=x.device)
     lib = _lib.load()
+    fn = lib.lemon_layernorm_split3 if mode == "bf16x6" else lib.lemon_layernorm_f16x3
     with torch.cuda.device(x.device):
-        _lib.check(lib.lemon_split3_f32(ptr(x), x.numel() // k, k, int(bool(weight)), ptr(y), stream_ptr(x.device)), "lemon_split3_f32")
+        _lib.check(fn(ptr(x), ptr(weight.contiguous()), ptr(bias.contiguous()), float(eps), x.numel() // width, width, ptr(y),
+                      stream_ptr(x.device)), "lemon_layernorm_" + mode)
     return y
 
 
 def layer_norm_split3(x, weight, bias, eps=1e-5):
-    """LayerNorm whose output is the split activation operand [..., 6 width] bf16 (one pass: lemon_layernorm_split3)."""
-    assert x.is_cuda and x.dtype == torch.float32
-    x = x.contiguous()
-    width = x.shape[-1]
-    y = torch.empty(x.shape[:-1] + (6 * width,), dtype=torch.bfloat16, device=x.device)
-    lib = _lib.load()
-    with torch.cuda.device(x.device):
-        _lib.check(lib.lemon_layernorm_split3(ptr(x), ptr(weight.contiguous()), ptr(bias.contiguous()), float(eps),
-                                              x.numel() // width, width, ptr(y), stream_ptr(x.device)), "lemon_layernorm_split3")
-    return y
+    return layer_norm_split(x, weight, bias, eps, "bf16x6")
 
 
-def linear_split3(x6, w6, bias=None, residual=None, act=None, alpha=1.0):
-    """y = act(alpha * x @ W.T + bias) (+ residual), float32, from the split operands x6 [..., 6k], w6 [n, 6k] (bf16)."""
-    assert x6.is_cuda and x6.dtype == torch.bfloat16 and w6.dtype == torch.bfloat16 and x6.shape[-1] == w6.shape[1]
-    x6, w6 = x6.contiguous(), w6.contiguous()
-    k6, n = x6.shape[-1], w6.shape[0]
-    m = x6.numel() // k6
-    y = torch.empty(x6.shape[:-1] + (n,), dtype=torch.float32, device=x6.device)
+def linear_split(xs, ws, bias=None, residual=None, act=None, alpha=1.0):
+    """y = act(alpha * xs . ws^T + bias) (+ residual), float32, from split operands of one scheme (the dtype says which):
+    bf16 [..., 6k] x [n, 6k] or fp16 [..., 3k] x [n, 3k].  f16x3: the caller folds 1 / wscale into alpha."""
+    assert xs.is_cuda and xs.dtype == ws.dtype and xs.dtype in (torch.bfloat16, torch.float16) and xs.shape[-1] == ws.shape[1]
+    xs, ws = xs.contiguous(), ws.contiguous()
+    ks, n = xs.shape[-1], ws.shape[0]
+    m = xs.numel() // ks
+    y = torch.empty(xs.shape[:-1] + (n,), dtype=torch.float32, device=xs.device)
     if residual is not None:
         assert residual.shape == y.shape and residual.dtype == torch.float32
         residual = residual.contiguous()
     if bias is not None:
         bias = bias.contiguous()
     lib = _lib.load()
-    _ensure_linear_tuned(lib, x6.device)
+    _ensure_linear_tuned(lib, xs.device)
     code = {None: ACT_NONE, "silu": ACT_SILU}[act]
-    with torch.cuda.device(x6.device):
-        _lib.check(lib.lemon_linear_bf16x6(ptr(x6), ptr(w6), ptr(bias) if bias is not None else None,
-                                           ptr(residual) if residual is not None else None, m, n, k6, float(alpha), code, ptr(y),
-                                           stream_ptr(x6.device)), "lemon_linear_bf16x6")
+    fn, name = (lib.lemon_linear_bf16x6, "lemon_linear_bf16x6") if xs.dtype == torch.bfloat16 else (lib.lemon_linear_f16x3, "lemon_linear_f16x3")
+    with torch.cuda.device(xs.device):
+        _lib.check(fn(ptr(xs), ptr(ws), ptr(bias) if bias is not None else None, ptr(residual) if residual is not None else None,
+                      m, n, ks, float(alpha), code, ptr(y), stream_ptr(xs.device)), name)
     return y
+
+
+linear_split3 = linear_split
 
 
 def layer_norm(x, weight, bias, eps=1e-5):
@@ -265,18 +312,25 @@ def attention(qkv, heads, causal=False):
     return out
 
 
-def attention_split3(qkv, heads, causal=False):
-    """attention() whose output is the split activation operand [B, L, 6*W] bf16 (lemon_attention_split3)."""
-    assert qkv.is_cuda and qkv.dtype == torch.float32 and qkv.is_contiguous() and qkv.dim() == 3
+def attention_split(qkv, heads, causal=False, mode="bf16x6"):
+    """attention() whose output is the split activation operand of `mode`: [B, L, 6*W] bf16 (lemon_attention_split3) or
+    [B, L, 3*W] fp16 (lemon_attention_f16x3)."""
+    dtype, seg = _SCHEMES[mode]
+    assert qkv.is_cuda and qkv.dtype == torch.float32 and qkv.dim() == 3
+    qkv = qkv.contiguous()
     B, L, W3 = qkv.shape
-    W = W3 // 3
-    assert W3 == 3 * W and W == heads * 64 and L <= ATTENTION_MAX_SEQ
-    out = torch.empty((B, L, 6 * W), dtype=torch.bfloat16, device=qkv.device)
+    assert W3 == 3 * heads * 64 and L <= ATTENTION_MAX_SEQ
+    out = torch.empty((B, L, seg * heads * 64), dtype=dtype, device=qkv.device)
     lib = _lib.load()
+    fn = lib.lemon_attention_split3 if mode == "bf16x6" else lib.lemon_attention_f16x3
     with torch.cuda.device(qkv.device):
-        _lib.check(lib.lemon_attention_split3(ptr(qkv), B, L, heads, 64, int(bool(causal)), ptr(out),
-                                              stream_ptr(qkv.device)), "lemon_attention_split3")
+        _lib.check(fn(ptr(qkv), B, L, heads, 64, int(bool(causal)), ptr(out), stream_ptr(qkv.device)), "lemon_attention_" + mode)
     return out
+
+
+def attention_split3(qkv, heads, causal=False):
+    return attention_split(qkv, heads, causal, "bf16x6")
+
 
 
 def paired_distance(metric, a, b):

@@ -60,7 +60,7 @@ def ragged_ids(n, ctx, vocab, seed):
     return ids, mask
 
 
-@pytest.mark.parametrize("gemm", ["split", "f32"])
+@pytest.mark.parametrize("gemm", ["split", "f16x3", "f32"])
 @pytest.mark.parametrize("arch", ["vit-b-32", "vit-b-16", "vit-l-14"])
 def test_fused_gpu_encoder_vs_hf_clip_at_full_size(hip, arch, gemm, monkeypatch):
     # gemm = "split" (the default): QKV / output projection / fc1 as 3-way bf16 split GEMMs (lemon_linear_bf16x6);

@@ -526,11 +526,43 @@ def test_fused_attention_matches_float64_reference(hip, B, L, H, causal):
 
 @pytest.mark.parametrize("B,L,H,causal", [(3, 50, 12, False), (5, 8, 8, True), (2, 77, 8, True), (2, 197, 12, False)])
 def test_attention_split_output_equals_split_of_attention(hip, B, L, H, causal):
-    # lemon_attention_split3 stores the 3-way split of exactly the values lemon_attention_f32 stores (all three kernels)
-    from lemon_amd.ops import attention, attention_split3, split3
+    # lemon_attention_split3 / _f16x3 store the split of exactly the values lemon_attention_f32 stores (all three kernels)
+    from lemon_amd.ops import attention, attention_split, split_operand
     g = torch.Generator().manual_seed(B * 100 + L)
     qkv = torch.randn(B, L, 3 * H * 64, generator=g).cuda()
-    assert torch.equal(attention_split3(qkv, H, causal), split3(attention(qkv, H, causal)))
+    for scheme in ("bf16x6", "f16x3"):
+        assert torch.equal(attention_split(qkv, H, causal, scheme), split_operand(attention(qkv, H, causal), scheme)), scheme
+
+
+def test_f16x3_parts_and_layernorm_split_equals_layernorm_then_split(hip):
+    # lemon_split_f16x3: activation rows [hi | hi | lo 2^11], weight rows [hi | lo | hi 2^-11] of w * wscale, hi = RNE f16,
+    # lo = the exact fp32 remainder; |v - hi - lo| <= 2^-23 |v| inside the fp16 range; beyond it the parts are not finite
+    from lemon_amd.ops import layer_norm, layer_norm_split, split_operand, weight_scale_f16x3
+    g = torch.Generator().manual_seed(6)
+    x = (torch.randn(37, 96, generator=g) * torch.exp(torch.randn(37, 1, generator=g) * 2)).cuda()
+    x[3, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 65504.0, -65504.0, 1e-3, 4097.5])
+    xd = x.double().cpu()
+    y = split_operand(x, "f16x3").view(37, 3, 96).cpu()
+    hi = x.cpu().to(torch.float16)
+    assert torch.equal(y[:, 0], hi) and torch.equal(y[:, 1], hi)
+    assert torch.equal(y[:, 2], ((x.cpu() - hi.float()) * 2048.0).to(torch.float16))
+    err = (y[:, 0].double() + y[:, 2].double() / 2048.0 - xd).abs()
+    assert bool((err <= xd.abs() * 2.0 ** -23 + 2.0 ** -36).all()), err.max()          # (+ half an fp16 subnormal step / 2^11)
+    w = (torch.randn(64, 96, generator=g) * 0.02).cuda()
+    ws = weight_scale_f16x3(w)
+    assert 2.0 ** 14 <= float(w.abs().max()) * ws < 2.0 ** 15
+    yw = split_operand(w, "f16x3", weight=True, wscale=ws).view(64, 3, 96).cpu()
+    sw = w.cpu() * ws
+    whi = sw.to(torch.float16)
+    assert torch.equal(yw[:, 0], whi) and torch.equal(yw[:, 1], (sw - whi.float()).to(torch.float16))
+    assert torch.equal(yw[:, 2], (whi.float() / 2048.0).to(torch.float16))
+    big = torch.full((1, 8), 7.0e4).cuda()
+    assert not bool(torch.isfinite(split_operand(big, "f16x3").float()).all())          # loud, not clamped
+    lw, lb = torch.randn(96, generator=g).cuda(), torch.randn(96, generator=g).cuda()
+    assert torch.equal(layer_norm_split(x, lw, lb, 1e-5, "f16x3"), split_operand(layer_norm(x, lw, lb), "f16x3"))
+    x8 = torch.randn(5, 768, generator=g).cuda()                                         # the 16-byte-store kernel
+    l8, b8 = torch.randn(768, generator=g).cuda(), torch.randn(768, generator=g).cuda()
+    assert torch.equal(layer_norm_split(x8, l8, b8, 1e-5, "f16x3"), split_operand(layer_norm(x8, l8, b8), "f16x3"))
 
 
 def test_split3_parts_are_exact_and_layernorm_split_equals_layernorm_then_split(hip):
@@ -554,10 +586,11 @@ def test_split3_parts_are_exact_and_layernorm_split_equals_layernorm_then_split(
 
 @pytest.mark.parametrize("m,n,k", [(100, 64, 48), (7, 512, 512), (3000, 2304, 768), (2500, 768, 3072), (5000, 1536, 512), (1, 32, 40)])
 @pytest.mark.parametrize("mode", ["plain", "bias", "bias_gelu", "bias_residual"])
-def test_split_bf16x3_linear_is_at_least_as_accurate_as_the_fp32_gemm(hip, m, n, k, mode):
-    # lemon_linear_bf16x6 against float64: the six-product emulation must meet the bar of the fp32 GEMM test below AND be no
-    # worse than the fp32 GEMM itself on the same operands (measured: ~50x better)
-    from lemon_amd.ops import linear, linear_split3, split3
+@pytest.mark.parametrize("scheme", ["bf16x6", "f16x3"])
+def test_split_bf16x3_linear_is_at_least_as_accurate_as_the_fp32_gemm(hip, m, n, k, mode, scheme):
+    # lemon_linear_bf16x6 / lemon_linear_f16x3 against float64: the emulation must meet the bar of the fp32 GEMM test below AND
+    # be no worse than the fp32 GEMM itself on the same operands (measured: bf16x6 ~50x better)
+    from lemon_amd.ops import linear, linear_split, split_operand, weight_scale_f16x3
     g = torch.Generator().manual_seed(m * 7 + n * 3 + k)
     x, w = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5
     b = torch.randn(n, generator=g) if "bias" in mode else None
@@ -569,13 +602,14 @@ def test_split_bf16x3_linear_is_at_least_as_accurate_as_the_fp32_gemm(hip, m, n,
         ref = ref * torch.sigmoid(1.702 * ref)
     if r is not None:
         ref = ref + r.double()
-    x6, w6 = split3(x.cuda()), split3(w.cuda(), weight=True)
+    ws = weight_scale_f16x3(w) if scheme == "f16x3" else 1.0
+    x6, w6 = split_operand(x.cuda(), scheme), split_operand(w.cuda(), scheme, weight=True, wscale=ws)
     bc, rc = (None if b is None else b.cuda()), (None if r is None else r.cuda())
     if "gelu" in mode:
-        got = linear_split3(x6, w6, 1.702 * bc, None, "silu", alpha=1.702).cpu().double() / 1.702
+        got = linear_split(x6, w6, 1.702 * bc, None, "silu", alpha=1.702 / ws).cpu().double() / 1.702
         f32 = linear(x.cuda(), w.cuda(), 1.702 * bc, None, "silu", alpha=1.702).cpu().double() / 1.702
     else:
-        got = linear_split3(x6, w6, bc, rc).cpu().double()
+        got = linear_split(x6, w6, bc, rc, alpha=1.0 / ws).cpu().double()
         f32 = linear(x.cuda(), w.cuda(), bc, rc).cpu().double()
     e_split, e_f32 = float((got - ref).abs().max()), float((f32 - ref).abs().max())
     assert e_split < 2e-5 * max(1.0, k ** 0.5 / 8), e_split

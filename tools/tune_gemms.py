@@ -27,7 +27,7 @@ for spec in (sys.argv[1:] or ["vit-b-32:1000"]):
     u8 = torch.randint(0, 256, (bs, 32, 32, 3), dtype=torch.uint8, device=dev)
     px = gpu_transform_batch(u8, cfg.image_size, patch=cfg.patch_size)      # patch-major: the patch embedding is a GEMM
     t0 = time.perf_counter()
-    for mode in ("split", "f32"):          # both GEMM modes of lemon_amd/clip.py meet their keys (bf16 split operands / fp32)
+    for mode in os.environ.get("TUNE_MODES", "f16x3,split,f32").split(","):          # all GEMM modes (or the ones asked for) of lemon_amd/clip.py meet their keys (bf16 split operands / fp32)
         os.environ["LEMON_GEMM"] = mode
         with torch.no_grad():
             # text tower: only position-independent solutions (identical prompts must get identical embeddings wherever they
