@@ -186,6 +186,7 @@ def prepare(args):
         d = embedder.model.cfg.embed_dim
         e_img = torch.cat(imgs) if imgs else torch.empty((0, d), device=device)
         e_txt = embedder.embed_texts(torch.cat(toks)) if toks else torch.empty((0, d), device=device)
+        embedder.raise_if_nonfinite()
         meta["lo"] = lo
         if cache.root:
             cache.store(sname, lo, hi, meta["prompts"], e_img, e_txt, meta)

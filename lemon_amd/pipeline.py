@@ -103,6 +103,22 @@ class Embedder:
         # prompts are ~7x shorter than the image token sequence: a 4x larger text micro-batch keeps the
         # text tower's GEMMs at the image tower's row count (and efficiency)
         self.text_batch_size = text_batch_size or 4 * batch_size
+        self._nonfinite = None        # device flag: some embedding so far was not finite (raise_if_nonfinite)
+
+    def _note(self, e):
+        if e.is_cuda and e.shape[0]:
+            bad = ~torch.isfinite(e).all()
+            self._nonfinite = bad if self._nonfinite is None else (self._nonfinite | bad)
+        return e
+
+    def raise_if_nonfinite(self):
+        """One host read for everything embedded since the last call.  The default GEMM mode (LEMON_GEMM=f16x3) carries the fp32
+        operands of the block GEMMs as fp16 pairs: an activation beyond +-65 504 turns into inf / NaN there instead of being
+        clamped, and this is where it is reported."""
+        flag, self._nonfinite = self._nonfinite, None
+        if flag is not None and bool(flag.item()):
+            raise FloatingPointError(f"non-finite embeddings (LEMON_GEMM={ops.gemm_mode()}): with f16x3 an activation left the fp16 "
+                                     "range of the split GEMM operands -- rerun with LEMON_GEMM=bf16x6 (no range limit) or f32")
 
     @torch.no_grad()
     def embed_images(self, pixel_values):
@@ -118,7 +134,7 @@ class Embedder:
                 px = gpu_transform_batch(px, self.model.cfg.image_size, patch=self.model.cfg.patch_size)
             outs.append(self.model.encode_image(px).float())
         e = torch.cat(outs) if outs else torch.empty((0, self.model.cfg.embed_dim), device=self.device)
-        return ops.normalize_vectors(e) if e.shape[0] else e                          # :164 / :233
+        return ops.normalize_vectors(self._note(e)) if e.shape[0] else e              # :164 / :233
 
     @torch.no_grad()
     def embed_texts(self, input_ids):
@@ -129,7 +145,7 @@ class Embedder:
             e = self._embed_texts(uniq)[inv]
         else:
             e = self._embed_texts(input_ids, eot)
-        return ops.normalize_vectors(e) if e.shape[0] else e                          # :163 / :230-232
+        return ops.normalize_vectors(self._note(e)) if e.shape[0] else e              # :163 / :230-232
 
     def _embed_texts(self, ids, eot=None):
         """ids on the device; eot = per-row EOT position on the HOST (one transfer for the whole array instead of a
@@ -206,6 +222,7 @@ def run_hot_path(embedder, data, k=5, dist_type="cosine", hparams=FIXED_HPARAMS,
     emb = {}
     for name, d in data.items():
         emb[name] = (embedder.embed_images(d["pixels"]), embedder.embed_texts(d["ids"]))
+    embedder.raise_if_nonfinite()
     if timers is not None:
         torch.cuda.synchronize(dev)
         timers["embed_s"] = time.perf_counter() - t0

@@ -178,3 +178,31 @@ def test_tier_b_cpu_hf_embeddings_vs_gpu_pipeline(hip, oracle):
     a_ref, a_gpu = oracle.auroc(y, oracle.score(out, strong)), oracle.auroc(y, oracle.score({k_: v.cpu().numpy() for k_, v in recs["val"].items() if k_ != "score"}, strong))
     print(f"tier-B AUROC: fixed hparams {oracle.auroc(y, s_ref):.4f}; beta=gamma=100: oracle {a_ref:.4f} gpu {a_gpu:.4f}")
     assert round(a_ref, 3) == round(a_gpu, 3) and a_ref > 0.6 and oracle.auroc(y, s_ref) > 0.55
+
+
+def test_f16x3_reports_activations_beyond_the_fp16_range(hip, monkeypatch):
+    # LEMON_GEMM=f16x3 carries the block GEMMs' fp32 operands as fp16 pairs: an activation beyond +-65 504 must end in an
+    # error (Embedder.raise_if_nonfinite), never in a clamped, silently different embedding; bf16x6 / f32 have no such limit
+    from lemon_amd.clip import ClipConfig, LemonCLIP
+    from lemon_amd.pipeline import Embedder
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = LemonCLIP(ClipConfig.named("tiny")).eval()
+    px = torch.randn(8, 3, 32, 32).to(dev)
+    outs = {}
+    for scale, modes in ((1.0, (("f32", True), ("bf16x6", True), ("f16x3", True))), (3.0e6, (("f32", True), ("bf16x6", True), ("f16x3", False)))):
+        with torch.no_grad():
+            model.vision.blocks[0].ln1.weight.fill_(scale)           # LayerNorm output ~ scale: 3e6 is beyond fp16
+        for mode, fine in modes:
+            monkeypatch.setenv("LEMON_GEMM", mode)
+            emb = Embedder(model, dev, batch_size=4)
+            e = emb.embed_images(px)
+            if fine:
+                emb.raise_if_nonfinite()
+                assert bool(torch.isfinite(e).all())
+                outs[(scale, mode)] = e
+            else:
+                with pytest.raises(FloatingPointError, match="fp16 range"):
+                    emb.raise_if_nonfinite()
+        assert (outs[(scale, "bf16x6")] - outs[(scale, "f32")]).abs().max() < 5e-6      # (unit-norm embeddings)
+    assert (outs[(1.0, "f16x3")] - outs[(1.0, "f32")]).abs().max() < 5e-6

@@ -33,10 +33,13 @@ for spec in (sys.argv[1:] or ["vit-b-32:1000"]):
             # text tower: only position-independent solutions (identical prompts must get identical embeddings wherever they
             # sit in a micro-batch: the text-side search folds them); image tower: rows are distinct images, the fastest
             # validated solution is taken
-            os.environ["LEMON_LINEAR_ALLOW_POSITION_DEPENDENT"] = "1"
-            model.encode_image(px)
-            os.environ["LEMON_LINEAR_ALLOW_POSITION_DEPENDENT"] = "0"
-            model.encode_text(ids); model.encode_text(ids[:bs])
+            towers = os.environ.get("TUNE_TOWERS", "image,text").split(",")
+            if "image" in towers:
+                os.environ["LEMON_LINEAR_ALLOW_POSITION_DEPENDENT"] = "1"
+                model.encode_image(px)
+            if "text" in towers:
+                os.environ["LEMON_LINEAR_ALLOW_POSITION_DEPENDENT"] = "0"
+                model.encode_text(ids); model.encode_text(ids[:bs])
         torch.cuda.synchronize()
     print(spec, "tuned in", round(time.perf_counter() - t0, 1), "s", flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
