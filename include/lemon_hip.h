@@ -46,8 +46,10 @@ extern "C" {
 /* search algorithm selector for lemon_index_set_algo() */
 #define LEMON_ALGO_AUTO 0
 #define LEMON_ALGO_F32_MFMA 1   /* exact fp32 MFMA scan (v_mfma_f32_32x32x2_f32)                       */
-#define LEMON_ALGO_BF16_FILTER 2 /* bf16 MFMA filter with a rigorous error band + exact fp32 re-rank;  */
-                                 /* returns bit-identical results to LEMON_ALGO_F32_MFMA               */
+#define LEMON_ALGO_BF16_FILTER 2 /* 16-bit MFMA filter with a rigorous error band + exact fp32 re-rank; */
+                                 /* returns bit-identical results to LEMON_ALGO_F32_MFMA.  The filter   */
+                                 /* operands are fp16 copies since round 3 (bf16 before: name kept)     */
+#define LEMON_ALGO_F16_FILTER LEMON_ALGO_BF16_FILTER
 
 typedef struct lemon_index lemon_index_t;
 

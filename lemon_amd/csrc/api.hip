@@ -172,7 +172,7 @@ extern "C" int lemon_index_add(lemon_index_t *idx, const float *x_dev, int64_t n
 }
 
 // ---- LEMON_ALGO_AUTO ----------------------------------------------------------------------
-// The bf16 filter scan is ~5x faster than the fp32 scan on large, "spread out" data, but its work
+// The 16-bit filter scan (knn_bf16.hip; fp16 operands) is ~5x faster than the fp32 scan on large, "spread out" data, but its work
 // grows with the number of database rows whose score lies within the rounding band of a query's
 // k-th best: exact duplicates (class prompts: SURVEY 0.9) or tightly concentrated embeddings put
 // hundreds of rows there and every one of them must be re-scored exactly.  AUTO therefore probes:
@@ -214,7 +214,9 @@ static int lemon_auto_choose(lemon_index_t *idx, const float *q_dev, int64_t nq,
         for (int i = 0; i < S; ++i) xn2max = hx[i] > xn2max ? hx[i] : xn2max;
         int crowded = 0;
         for (int p = 0; p < np; ++p) {
-            const float eps = 0.004f * sqrtf(hq[p] > 0 ? hq[p] : 0.0f) * sqrtf(xn2max);
+            // a-priori size of the scan's band: two fp16 roundings (2^-12 / sqrt(3) of the norms each, measured 1.4e-4) + the
+            // fp32 summation term of band_eps (knn_bf16.hip); the scan itself uses the MEASURED residuals
+            const float eps = (0.0004f + 3.0f * (float)d * 5.9604645e-8f) * sqrtf(hq[p] > 0 ? hq[p] : 0.0f) * sqrtf(xn2max);
             const float band = (idx->metric == LEMON_METRIC_L2) ? 4.0f * eps : 2.0f * eps;
             int c = 0;
             for (int j = 1; j < KP; ++j) {

@@ -1,12 +1,12 @@
-// knn_bf16.hip -- LEMON_ALGO_BF16_FILTER: bf16 MFMA filter scan + exact float32 re-rank.
+// knn_bf16.hip -- LEMON_ALGO_BF16_FILTER: 16-bit MFMA filter scan + exact float32 re-rank.
 //
-// The tile product runs on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate, half the staged bytes)
-// over bf16 (round-to-nearest-even) copies of Q and X.  The approximate score s~ is only a FILTER with
-// a proven error bound
+// The tile product runs on the 16-bit matrix pipe (v_mfma_f32_32x32x16_f16: 16x the fp32 MFMA rate, half the staged bytes)
+// over 16-bit (round-to-nearest-even) copies of Q and X -- fp16 since round 3, bf16 before; file, algorithm and kernel names
+// kept.  The approximate score s~ is only a FILTER with a proven error bound
 //     |s~(q,x) - s(q,x)| <= eps(q) := ||q||*max_j||x_j - xh_j|| + ||q - qh||*max_j||xh_j||     (rounding)
 //                                    + 3*d*2^-24 * ||q||*max_j||x_j||                          (fp32 sums)
 // (identity  sum q x - sum qh xh = sum q (x-xh) + sum (q-qh) xh  + Cauchy-Schwarz; the residual norms
-// are MEASURED when the bf16 copies are made, which is ~2.4x tighter than the a-priori 2^-7 bound),
+// are MEASURED when the 16-bit copies are made: 1.4e-4 of the norms for fp16 on embedding data, 1.1e-3 for bf16),
 // where s is the float32 fmaf-chain score of the numeric contract.
 //
 // Candidate bookkeeping is the fp32 scan's (keys = ord(score)<<32 | ~index, per-query lists, rank-select
@@ -23,7 +23,12 @@
 
 using namespace lemon_knn;
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// The 16-bit filter format is IEEE fp16 (11 significant bits; the first two rounds used bf16, whose 8 bits made the band 5x
+// wider -- the names of the algorithm and of the kernels still say bf16).  Unit-norm embeddings sit far inside its range; the
+// copy kernel saturates at +-65 504 and flushes fp16 subnormals to zero, and whatever that costs in accuracy is in the MEASURED
+// residual the band is built from, so the proof does not depend on the format.
+typedef _Float16 lp16;
+typedef lp16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -36,7 +41,7 @@ constexpr int REFRESH = 96; // light-compact a list after this many new candidat
 // f32 [n,d] -> bf16 [*, dpad_h] (RNE, zero padded columns), one wavefront per row, plus the row's
 // measured rounding residual ||x - xh||^2 and ||xh||^2 (float32 sums; consumers inflate them)
 __global__ __launch_bounds__(256) void k_convert_bf16(const float *__restrict__ src, int64_t n, int d,
-                                                      __bf16 *__restrict__ dst, int dpad_h,
+                                                      lp16 *__restrict__ dst, int dpad_h,
                                                       float *__restrict__ res2, float *__restrict__ hn2) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -48,8 +53,9 @@ __global__ __launch_bounds__(256) void k_convert_bf16(const float *__restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float v = (8 * u + e < d) ? s[8 * u + e] : 0.0f;
-            const __bf16 b = (__bf16)v;
-            const float vb = (float)b;
+            lp16 b = (lp16)fminf(fmaxf(v, -65504.0f), 65504.0f);      // saturate: the residual below then carries the excess
+            float vb = (float)b;
+            if (fabsf(vb) < 6.103515625e-05f) { b = (lp16)0.0f; vb = 0.0f; }   // no fp16 subnormals into the matrix pipe
             const float dv = v - vb;
             e2 = __builtin_fmaf(dv, dv, e2);
             h2 = __builtin_fmaf(vb, vb, h2);
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(256) void k_max_nonneg(const float *__restrict__ v,
 
 struct ScanParamsH {
     ScanParams b;              // qp / xp unused here
-    const __bf16 *qh, *xh;     // [nq_pad, dpad_h], [n_pad, dpad_h]
+    const lp16 *qh, *xh;     // [nq_pad, dpad_h], [n_pad, dpad_h]
     const float *q, *x;        // originals, row-major [nq, d], [n, d]
     const float *qres2, *qhn2; // [nq_pad] measured ||q-qh||^2, ||qh||^2
     const unsigned *xstat;     // device scalars (float bits): [0] max dot(x,x), [1] max ||x-xh||^2, [2] max ||xh||^2
@@ -360,10 +366,10 @@ __global__ __launch_bounds__(NT, 2) void k_scan_bf16(ScanParamsH p) {
             const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tq[swz(arow1, 2 * u + h)]));
             const bf16x8 b0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(brow0, 2 * u + h)]));
             const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(&tx[swz(brow1, 2 * u + h)]));
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc11, 0, 0, 0);
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc11, 0, 0, 0);
         }
 
         const bool tile_done = (kt == KT - 1);
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(NT, 2) void k_scan_bf16(ScanParamsH p) {
 // (393 KB per workgroup at d=768: 64 panels per XCD thrash the 4 MB L2, PMC FETCH_SIZE ~ every staged
 // byte).  Here a wavefront owns 32 queries and keeps their bf16 rows in VGPRs for the whole scan
 // (16*KT x 4 VGPRs = 192 at d=768; one wave per SIMD, 512-register budget), as the B operand of
-// v_mfma_f32_32x32x16_bf16; only X tiles (128 rows x 64 k = 16 KB per stage) stream through LDS as
+// v_mfma_f32_32x32x16_f16; only X tiles (128 rows x 64 k = 16 KB per stage) stream through LDS as
 // the A operand, shared by the 4 waves.  Global traffic per flop halves, the L2 only sees the X
 // stream that every workgroup reads in the same order, and the accumulator layout puts ONE query on
 // each lane (col = lane&31), so the admission threshold is a per-lane scalar: a 16-value v_max3
@@ -594,10 +600,10 @@ __device__ __forceinline__ void qs_dma_stage(const float *__restrict__ src, int 
 // behind its MFMA.  "a" constraints pin both to AGPRs (64 acc + 192 query = all 256); the A
 // fragments, addresses and the epilogue live in VGPRs.  First step of a tile uses C = 0.
 __device__ __forceinline__ void mfma_qs_init(f32x16 &acc, bf16x8 a, const bf16x8 &bq) {
-    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&a"(acc) : "v"(a), "a"(bq));
+    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&a"(acc) : "v"(a), "a"(bq));
 }
 __device__ __forceinline__ void mfma_qs(f32x16 &acc, bf16x8 a, const bf16x8 &bq) {
-    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(bq));
+    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(bq));
 }
 
 // (the metric is a template parameter: the L2 epilogue issues ordinary global loads (|x|^2), and hipcc
@@ -665,7 +671,7 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs(ScanParamsH p) {
     // ---- stationary operand: this lane's query row, all k ----
     bf16x8 qf[KS];
     {
-        const __bf16 *qsrc = p.qh + (q0 + qrow_l) * (int64_t)p.dpad_h + 8 * h;
+        const lp16 *qsrc = p.qh + (q0 + qrow_l) * (int64_t)p.dpad_h + 8 * h;
 #pragma unroll
         for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const bf16x8 *>(qsrc + 16 * s);
     }
@@ -861,15 +867,15 @@ __device__ __forceinline__ void mfma_x(f32x16 &acc, bf16x8 a, const bf16x8 &bq) 
     if (INIT) {
         // (early-clobber: a multi-pass MFMA may write its destination before it has read all of A / B, so the fresh tile
         // must not share registers with the fragments -- hipcc would otherwise reuse a dying fragment's VGPRs for it)
-        if (CV) { if (BA) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(bq));
-                  else    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(bq)); }
-        else    { if (BA) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&a"(acc) : "v"(a), "a"(bq));
-                  else    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&a"(acc) : "v"(a), "v"(bq)); }
+        if (CV) { if (BA) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(bq));
+                  else    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(bq)); }
+        else    { if (BA) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&a"(acc) : "v"(a), "a"(bq));
+                  else    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&a"(acc) : "v"(a), "v"(bq)); }
     } else {
-        if (CV) { if (BA) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(bq));
-                  else    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(bq)); }
-        else    { if (BA) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(bq));
-                  else    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(bq)); }
+        if (CV) { if (BA) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(bq));
+                  else    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(bq)); }
+        else    { if (BA) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(bq));
+                  else    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(bq)); }
     }
 }
 
@@ -948,8 +954,8 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs2(ScanParamsH p) {
     // ---- stationary operands: this lane's two query rows ----
     bf16x8 qa[KS], qb[NR];
     {
-        const __bf16 *src0 = p.qh + (q0 + qrow0) * (int64_t)p.dpad_h + 8 * h;
-        const __bf16 *src1 = p.qh + (q0 + qrow1) * (int64_t)p.dpad_h + 8 * h;
+        const lp16 *src0 = p.qh + (q0 + qrow0) * (int64_t)p.dpad_h + 8 * h;
+        const lp16 *src1 = p.qh + (q0 + qrow1) * (int64_t)p.dpad_h + 8 * h;
         // (loads in groups of eight with a scheduling fence in between: left alone hipcc issues all 84 loads up front,
         // needs 336 registers for them and spills the query rows through scratch on their way into the AccVGPRs)
 #pragma unroll
@@ -1062,7 +1068,7 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs2(ScanParamsH p) {
                     // elsewhere), so every score of a padding row becomes -inf and a valid row's gets +0.  (Masking the 64
                     // accumulator values with VALU code costs 64 live VGPRs + 32 compare masks that this kernel does not have.)
                     const unsigned row = (unsigned)(t_begin + jl) * RT2 + (unsigned)l31;
-                    const unsigned short ninf = 0xff80u, one = 0x3f80u;       // bf16 -inf, 1.0
+                    const unsigned short ninf = 0xfc00u, one = 0x3c00u;       // fp16 -inf, 1.0
                     typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
                     u16x8 m0 = {}, m1 = {}, ones = {};
                     m0[0] = (h == 0 && row >= (unsigned)p.b.n) ? ninf : (unsigned short)0;
@@ -1310,7 +1316,7 @@ static int bf16_pitch(int d) {
     return (int)round_up(d, BKH);
 }
 
-static int convert_rows(const float *src, int64_t n, int d, __bf16 *dst, int dpad_h, float *res2, float *hn2,
+static int convert_rows(const float *src, int64_t n, int d, lp16 *dst, int dpad_h, float *res2, float *hn2,
                         hipStream_t stream) {
     if (n <= 0) return LEMON_OK;
     hipLaunchKernelGGL(k_convert_bf16, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, src, n, d, dst, dpad_h,
@@ -1337,7 +1343,7 @@ static int ensure_bf16_copy(lemon_index_t *idx, hipStream_t stream) {
         const int64_t n_new = idx->n - idx->xh_rows;
         float *res2 = idx->xh_stats, *hn2 = idx->xh_stats + idx->cap;
         int rc = convert_rows(idx->x + idx->xh_rows * idx->d, n_new, idx->d,
-                              reinterpret_cast<__bf16 *>(idx->xh) + idx->xh_rows * dpad_h, dpad_h,
+                              reinterpret_cast<lp16 *>(idx->xh) + idx->xh_rows * dpad_h, dpad_h,
                               res2 + idx->xh_rows, hn2 + idx->xh_rows, stream);
         if (rc) return rc;
         LEMON_HIP_CHECK(hipMemsetAsync(idx->xn2max_dev, 0, 16, stream));
@@ -1419,7 +1425,7 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
         rc = lemon_ensure_search_ws(idx, nq_pad, splits, (int64_t)panels * splits * (bqw / BQ), dpad_h * 2, CAPH, stream);
         if (rc) return rc;
         // bf16 query panel (pad rows zero), chain norms, measured rounding residuals
-        __bf16 *qh = reinterpret_cast<__bf16 *>(idx->ws_qp);
+        lp16 *qh = reinterpret_cast<lp16 *>(idx->ws_qp);
         float *qn = idx->ws_qnorm, *qres2 = idx->ws_qnorm + idx->ws_q, *qhn2 = idx->ws_qnorm + 2 * idx->ws_q;
         LEMON_HIP_CHECK(hipMemsetAsync(qh, 0, (size_t)nq_pad * dpad_h * sizeof(unsigned short), stream));
         LEMON_HIP_CHECK(hipMemsetAsync(idx->ws_qnorm, 0, (size_t)idx->ws_q * 3 * sizeof(float), stream));
@@ -1434,7 +1440,7 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
         p.b.D = D_dev + c0 * k; p.b.I = I_dev + c0 * k;
         p.b.nq = cn; p.b.n = idx->n; p.b.dpad = dpad_h; p.b.kk = k; p.b.metric = idx->metric;
         p.b.n_tiles = n_tiles; p.b.tiles_per_split = tiles_per_split; p.b.splits = splits; p.b.nq_pad = nq_pad;
-        p.qh = qh; p.xh = reinterpret_cast<const __bf16 *>(idx->xh);
+        p.qh = qh; p.xh = reinterpret_cast<const lp16 *>(idx->xh);
         p.q = q_dev + c0 * d; p.x = idx->x; p.qres2 = qres2; p.qhn2 = qhn2; p.xstat = idx->xn2max_dev;
         p.d = d; p.dpad_h = dpad_h; p.phase_dbg = nullptr;
         rc = lemon_parse_ablate("k_scan_bf16_qs", 1 | 4 | 8, &p.ablate);   // bit 1 (value 2) does not exist: see ScanParamsH
