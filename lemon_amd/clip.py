@@ -150,7 +150,7 @@ class Block(nn.Module):
             x = ops.linear(a, self.out.weight, self.out.bias, residual=x)
             # QuickGELU(z) = silu(1.702 z) / 1.702: scale going in (alpha, bias), un-scale in fc2's alpha
             s = ops.QUICK_GELU_SCALE
-            h = ops.linear(ln(self.ln2, x), self.fc1.weight, self.fc1.bias * s, act="silu", alpha=s)
+            h = ops.linear(ln(self.ln2, x), self.fc1.weight, self._fc1_bias_scaled(s), act="silu", alpha=s)
             return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=x, alpha=1.0 / s)
         a = self._sdpa(self.qkv(self.ln1(x)), B, L, W, causal)
         if rows is not None:
@@ -159,6 +159,16 @@ class Block(nn.Module):
         h = self.fc1(self.ln2(x))
         h = h * torch.sigmoid(1.702 * h)          # QuickGELU
         return x + self.fc2(h)
+
+    def _fc1_bias_scaled(self, s):
+        """fc1.bias * s (the QuickGELU scale folded into the SiLU epilogue's input), made once per bias version."""
+        b = self.fc1.bias
+        cache = self.__dict__.setdefault("_split_cache", {})
+        hit = cache.get("fc1_bias_scaled")
+        if hit is None or hit[0] != (b.data_ptr(), b._version, s):
+            hit = ((b.data_ptr(), b._version, s), (b.detach() * s).contiguous())
+            cache["fc1_bias_scaled"] = hit
+        return hit[1]
 
     def _w_split(self, name, ops, mode):
         return split_weight_cached(self, name, getattr(self, name).weight, ops, mode)
@@ -184,7 +194,7 @@ class Block(nn.Module):
         s = ops.QUICK_GELU_SCALE
         w, a_ = self._w_split("fc1", ops, mode)
         h = ops.linear_split(ops.layer_norm_split(x, self.ln2.weight, self.ln2.bias, self.ln2.eps, mode), w,
-                             self.fc1.bias * s, act="silu", alpha=s * a_)
+                             self._fc1_bias_scaled(s), act="silu", alpha=s * a_)
         # fc2: one split pass over the [m, mlp] activations (bf16x6: 16 B per element, ~330 us at the headline shape) buys a
         # GEMM of 1 268 us instead of 1 590 us in the tuner -- and 1 820 us inside the step, where the fp32 GEMMs run at lower
         # clocks than in isolation while the 16-bit ones do not: 17.3 k against 16.7 k scores/s on the same box (twice,

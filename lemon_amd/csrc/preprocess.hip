@@ -11,7 +11,8 @@
 // (v/255 - mean)/std, bit-identical to the PIL + torch pipeline.
 //
 // One workgroup per (image, block of R output rows): horizontal pass for the input rows that block
-// needs into an LDS uint8 tile, vertical pass from LDS, coalesced float stores (NCHW).  Traffic: the
+// needs into an LDS uint8 tile, vertical pass from LDS (four pixels x three channels per work item: three
+// aligned LDS words per tap, the float epilogue from a 768-entry table, 16-byte stores).  Traffic: the
 // uint8 image in (3 KB for CIFAR), 12*S*S bytes out (602 KB): HBM-write bound.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,8 +37,14 @@ __device__ __forceinline__ uint8_t pil_clip8(int acc) {
     return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
+constexpr int LUT_BYTES = 3 * 256 * 4;     // (v/255 - mean[c]) / std[c] for every uint8 value and channel
+constexpr int VTAB_MAX_INTS = 512;         // the block's vertical windows: R x (ymin, count, ks_v taps)
+
 __global__ __launch_bounds__(256) void k_preprocess_u8(PreParams p) {
-    extern __shared__ uint8_t s_tmp[];           // [rows][S*3] horizontally resampled input rows
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    float *s_lut = reinterpret_cast<float *>(s_dyn);                     // [3][256]
+    int *s_vt = reinterpret_cast<int *>(s_dyn + LUT_BYTES);              // [R][2 + ks_v]
+    uint8_t *s_tmp = s_dyn + LUT_BYTES + VTAB_MAX_INTS * 4;              // [rows][S*3] horizontally resampled input rows
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x / p.blocks_per_img;
     const int yb = blockIdx.x % p.blocks_per_img;
@@ -49,6 +56,18 @@ __global__ __launch_bounds__(256) void k_preprocess_u8(PreParams p) {
     const int rows = vmax - vmin;
     const uint8_t *img = p.img + b * (int64_t)p.H * p.W * 3;
 
+    // the float epilogue of a uint8 value is one of 768 numbers: ToTensor's division and Normalize's, done once per value with
+    // exactly the arithmetic of the per-pixel form (two IEEE divisions per output pixel were most of this kernel's time)
+    for (int i = tid; i < 768; i += blockDim.x) {
+        const int c = i >> 8;
+        const float f = (float)(i & 255) / 255.0f;                       // ToTensor
+        s_lut[i] = (f - p.mean[c]) / p.stdv[c];                          // Normalize
+    }
+    const int vstride = 2 + p.ks_v;
+    for (int i = tid; i < (y1 - y0) * vstride; i += blockDim.x) {
+        const int yy = i / vstride, j = i - yy * vstride;
+        s_vt[i] = j < 2 ? p.bnd_v[2 * (y0 + yy) + j] : p.kk_v[(y0 + yy) * p.ks_v + (j - 2)];
+    }
     for (int r = 0; r < rows; ++r) {                                 // uniform outer loops: no per-element div/mod
         const uint8_t *row = img + (int64_t)(vmin + r) * p.W * 3;
         for (int xc = tid; xc < S3; xc += blockDim.x) {
@@ -63,21 +82,53 @@ __global__ __launch_bounds__(256) void k_preprocess_u8(PreParams p) {
     }
     __syncthreads();
 
+    const int P = p.patch, nP = P ? S / P : 0;
+    if ((S & 3) == 0 && (P & 3) == 0) {
+        // four output pixels x three channels per work item: 12 bytes (3 aligned words) of the LDS tile per tap, three 16-byte stores
+        const int q4 = S >> 2;
+        for (int it = tid; it < (y1 - y0) * q4; it += blockDim.x) {
+            const int yy = it / q4, x = 4 * (it - yy * q4), y = y0 + yy;
+            const int *vt = s_vt + yy * vstride;
+            const int ymin = vt[0], n = vt[1];
+            int acc[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) acc[i] = 1 << (PIL_PRECISION_BITS - 1);
+            const uint8_t *src = s_tmp + (ymin - vmin) * S3 + 3 * x;
+            for (int t = 0; t < n; ++t) {
+                const int kt = vt[2 + t];
+                const uint32_t *w = reinterpret_cast<const uint32_t *>(src + t * S3);
+                const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i] += (int)((w0 >> (8 * i)) & 255u) * kt;
+                    acc[4 + i] += (int)((w1 >> (8 * i)) & 255u) * kt;
+                    acc[8 + i] += (int)((w2 >> (8 * i)) & 255u) * kt;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float *lut = s_lut + 256 * c;
+                const float4 v = make_float4(lut[pil_clip8(acc[c])], lut[pil_clip8(acc[3 + c])], lut[pil_clip8(acc[6 + c])], lut[pil_clip8(acc[9 + c])]);
+                // NCHW row, or the row's place inside its patches: out[b][py*nP+px][c*P*P + (y%P)*P + (x%P)]
+                float *dst = P ? p.out + (b * nP * nP + (int64_t)(y / P) * nP + x / P) * (3 * P * P) + c * P * P + (y % P) * P + (x % P)
+                               : p.out + ((b * 3 + c) * S + y) * (int64_t)S + x;
+                *reinterpret_cast<float4 *>(dst) = v;
+            }
+        }
+        return;
+    }
     for (int c = 0; c < 3; ++c) {
-        const float mean = p.mean[c], stdv = p.stdv[c];
+        const float *lut = s_lut + 256 * c;
         for (int y = y0; y < y1; ++y) {
-            const int ymin = p.bnd_v[2 * y], n = p.bnd_v[2 * y + 1];
-            const int32_t *k = p.kk_v + y * p.ks_v;
-            // NCHW row, or the row's place inside its patches: out[b][py*nP+px][c*P*P + (y%P)*P + (x%P)]
-            const int P = p.patch, nP = P ? S / P : 0;
+            const int *vt = s_vt + (y - y0) * vstride;
+            const int ymin = vt[0], n = vt[1];
             float *dst = P ? p.out + (b * nP * nP + (int64_t)(y / P) * nP) * (3 * P * P) + c * P * P + (y % P) * P
                            : p.out + ((b * 3 + c) * S + y) * (int64_t)S;
             for (int x = tid; x < S; x += blockDim.x) {
                 const uint8_t *src = s_tmp + (ymin - vmin) * S3 + 3 * x + c;
                 int acc = 1 << (PIL_PRECISION_BITS - 1);
-                for (int t = 0; t < n; ++t) acc += (int)src[t * S3] * k[t];
-                float f = (float)pil_clip8(acc) / 255.0f;                // ToTensor
-                const float v = (f - mean) / stdv;                       // Normalize
+                for (int t = 0; t < n; ++t) acc += (int)src[t * S3] * vt[2 + t];
+                const float v = lut[pil_clip8(acc)];
                 if (P) dst[(int64_t)(x / P) * (3 * P * P) + (x % P)] = v; else dst[x] = v;
             }
         }
@@ -96,8 +147,10 @@ extern "C" int lemon_preprocess_u8(const uint8_t *img_dev, int64_t batch, int in
     LEMON_REQUIRE(patch >= 0 && (patch == 0 || out_size % patch == 0), "patch must divide out_size");
     if (batch == 0) return LEMON_OK;
     LEMON_REQUIRE(img_dev && kk_h_dev && bnd_h_dev && kk_v_dev && bnd_v_dev && mean3_host && std3_host && out_dev, "null pointer");
-    const size_t lds = (size_t)max_rows_per_block * out_size * 3;
-    LEMON_REQUIRE(lds <= 64 * 1024, "rows_per_block too large: the horizontal tile must fit 64 KB of LDS");
+    LEMON_REQUIRE((int64_t)rows_per_block * (2 + ks_v) <= VTAB_MAX_INTS, "rows_per_block * (2 + ks_v) <= 512");
+    LEMON_REQUIRE((((uintptr_t)out_dev) & 15) == 0, "out_dev must be 16-byte aligned");
+    const size_t lds = LUT_BYTES + VTAB_MAX_INTS * 4 + (((size_t)max_rows_per_block * out_size * 3 + 15) & ~(size_t)15);
+    LEMON_REQUIRE((size_t)max_rows_per_block * out_size * 3 <= 56 * 1024, "rows_per_block too large: the horizontal tile must fit 56 KB of LDS");
     PreParams p;
     p.img = img_dev; p.kk_h = kk_h_dev; p.bnd_h = bnd_h_dev; p.kk_v = kk_v_dev; p.bnd_v = bnd_v_dev; p.out = out_dev;
     p.patch = patch;

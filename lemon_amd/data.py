@@ -106,11 +106,13 @@ def _gpu_transform_plan(h, w, size, device_index):
     rows_per_block = 16
     while True:     # input rows one block's vertical windows span; shrink the block until the tile fits LDS
         spans = [int(b_v[min(y0 + rows_per_block, size) - 1].sum() - b_v[y0, 0]) for y0 in range(0, size, rows_per_block)]
-        if max(spans) * size * 3 <= 64 * 1024 or rows_per_block == 1:
+        # (the kernel's LDS: the uint8 tile <= 56 KB, and the block's vertical windows, rows x (2 + taps) <= 512 ints)
+        fits = max(spans) * size * 3 <= 56 * 1024 and rows_per_block * (2 + kk_v.shape[1]) <= 512
+        if fits or rows_per_block == 1:
             break
         rows_per_block //= 2
-    if max(spans) * size * 3 > 64 * 1024:
-        raise ValueError(f"image {h}x{w}: vertical window of {max(spans)} rows does not fit the LDS tile")
+    if not fits:
+        raise ValueError(f"image {h}x{w}: vertical window of {max(spans)} rows / {kk_v.shape[1]} taps does not fit the LDS tile")
     dev = torch.device("cuda", device_index)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     return dict(kk_h=t(kk_h), b_h=t(b_h), kk_v=t(kk_v), b_v=t(b_v), ks_h=kk_h.shape[1], ks_v=kk_v.shape[1],

@@ -502,6 +502,12 @@ def test_gpu_preprocess_bit_identical_to_pil_pipeline(hip, h, w):
     pm = gpu_transform_batch(torch.from_numpy(imgs).cuda(), 224, patch=32).cpu()
     expect = ref.view(3, 3, 7, 32, 7, 32).permute(0, 2, 4, 1, 3, 5).reshape(3, 49, 3 * 32 * 32)
     assert torch.equal(pm, expect)
+    # an output size that is not a multiple of 4 (the kernel's one-pixel-per-lane form), with and without patches
+    if min(h, w) >= 30:
+        ref30 = torch.stack([generic_transform(Image.fromarray(im), 30) for im in imgs])
+        assert torch.equal(gpu_transform_batch(torch.from_numpy(imgs).cuda(), 30).cpu(), ref30)
+        pm30 = gpu_transform_batch(torch.from_numpy(imgs).cuda(), 30, patch=6).cpu()
+        assert torch.equal(pm30, ref30.view(3, 3, 5, 6, 5, 6).permute(0, 2, 4, 1, 3, 5).reshape(3, 25, 3 * 36))
 
 
 @pytest.mark.gpu
