@@ -194,6 +194,25 @@ int lemon_layernorm_f16x3(const float *x_dev, const float *weight_dev, const flo
                           int width, uint16_t *y3_dev, void *stream);
 int lemon_attention_f16x3(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
                           int causal, uint16_t *out3_dev, void *stream);
+/* The MLP of a transformer block (fc1 -> QuickGELU -> fc2; lib/models/downstream_models.py:37-41 via HF CLIPMLP, in-tree twin
+ * lib/models/chexzero_clip.py:171-183) with the arithmetic of lemon_linear_f16x3 in a HAND-WRITTEN gfx950 kernel whose operands
+ * are tile-major in MFMA fragment order:
+ *     activation operand at_dev: ceil(m / 128) * 128 rows x k, halves [row tile of 128][k / 16][hi, lo 2^11][row block of 32]
+ *                                [k half][row in block][8 k]  (4 bytes per element; rows >= m need not be initialised)
+ *     weight operand wt_dev:     n rows x k of w * wscale, the same with 256-row tiles and parts hi, lo   (lemon_pack_weight_f16x3t)
+ * lemon_layernorm_f16x3t writes the activation operand (the LayerNorm in front of fc1); lemon_linear_f16x3t computes
+ *     act = LEMON_ACT_NONE, out_operand = 0:  out_dev fp32 [m, n] = alpha * x W^T + bias (+ residual)          (fc2)
+ *     act = LEMON_ACT_SILU, out_operand = 1:  out_dev = the activation operand (k' = n) of silu(alpha * x W^T + bias)   (fc1:
+ *         the [m, n] fp32 tensor and the split pass over it never exist)
+ * with n a multiple of 256 and k a multiple of 16; the caller folds 1 / wscale into alpha.  Results are independent of a row's
+ * position in the batch (fixed k order, no split-k).  lemon_unpack_act_f16x3t turns an activation operand back into fp32
+ * (hi + lo 2^-11; tests). */
+int lemon_pack_weight_f16x3t(const float *w_dev, int n, int k, float wscale, uint16_t *wt_dev, void *stream);
+int lemon_layernorm_f16x3t(const float *x_dev, const float *weight_dev, const float *bias_dev, float eps, int64_t rows,
+                           int width, uint16_t *yt_dev, void *stream);
+int lemon_linear_f16x3t(const uint16_t *at_dev, const uint16_t *wt_dev, const float *bias_dev, const float *residual_dev,
+                        int64_t m, int n, int k, float alpha, int act, int out_operand, void *out_dev, void *stream);
+int lemon_unpack_act_f16x3t(const uint16_t *at_dev, int64_t rows, int k, float *y_dev, void *stream);
 /* Recorded solution choices: a "# lemon_linear hipblaslt=<version> arch=<gfx name>" stamp line followed by
  * "m,n,k,epilogue,residual,index,usec" lines.  load returns the number of keys taken -- 0 when the stamp
  * does not match this process's hipBLASLt version / device arch (the file is then ignored) -- and dump the

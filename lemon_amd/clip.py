@@ -173,6 +173,17 @@ class Block(nn.Module):
     def _w_split(self, name, ops, mode):
         return split_weight_cached(self, name, getattr(self, name).weight, ops, mode)
 
+    def _w_tiled(self, name, ops):
+        """The layer's weight as the tile-major fp16 operand of lemon_linear_f16x3t and 1 / wscale, once per weight version."""
+        w = getattr(self, name).weight
+        cache = self.__dict__.setdefault("_split_cache", {})
+        hit = cache.get((name, "tiled"))
+        if hit is None or hit[0] != (w.data_ptr(), w._version):
+            wscale = ops.weight_scale_f16x3(w)
+            hit = ((w.data_ptr(), w._version), ops.pack_weight_t(w.detach(), wscale), 1.0 / wscale)
+            cache[(name, "tiled")] = hit
+        return hit[1], hit[2]
+
     def _forward_split(self, x, causal, rows, ops, mode):
         """The fused inference path with the four GEMMs of the block (QKV, output projection, fc1, fc2) on the 16-bit matrix
         cores at fp32-equivalent accuracy (ops.linear_split: exact splits of both operands -- 3-way bf16, six cross products, or
@@ -192,6 +203,16 @@ class Block(nn.Module):
         w, a_ = self._w_split("out", ops, mode)
         x = ops.linear_split(a6, w, self.out.bias, residual=x, alpha=a_)
         s = ops.QUICK_GELU_SCALE
+        mlp = self.fc1.weight.shape[0]
+        if mode == "f16x3" and rows is None and ops.mlp_mode() == "fused" and ops.mlp_fused_supported(W, mlp):
+            # the MLP in the hand-written GEMM (gemm_f16x3.hip): LayerNorm writes the tile-major operand, fc1's epilogue applies
+            # bias + QuickGELU + the fp16 split and stores fc2's operand, fc2 adds bias and the residual
+            m = x.numel() // W
+            w1, a1 = self._w_tiled("fc1", ops)
+            w2, a2 = self._w_tiled("fc2", ops)
+            at = ops.layer_norm_t(x, self.ln2.weight, self.ln2.bias, self.ln2.eps)
+            ht = ops.linear_t(at, w1, m, mlp, W, self._fc1_bias_scaled(s), act="silu", alpha=s * a1)
+            return ops.linear_t(ht, w2, m, W, mlp, self.fc2.bias, residual=x, alpha=a2 / s, out_shape=x.shape)
         w, a_ = self._w_split("fc1", ops, mode)
         h = ops.linear_split(ops.layer_norm_split(x, self.ln2.weight, self.ln2.bias, self.ln2.eps, mode), w,
                              self._fc1_bias_scaled(s), act="silu", alpha=s * a_)

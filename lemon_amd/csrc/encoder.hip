@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
 // LayerNorm for widths that are multiples of 8: every lane owns EIGHT consecutive elements per chunk (two float4), so the
 // split variant stores 16 bytes per segment instead of 8 (94 -> see DESIGN us per 50 000 x 768 rows); the fp32 variant uses
 // the same element-to-lane mapping, so lemon_layernorm_split3 == lemon_split3_f32(lemon_layernorm_f32) bit for bit.
-template <int CH8, int SPLIT>   // 8-element chunks per lane: width <= 512*CH8
+template <int CH8, int SPLIT>   // 8-element chunks per lane: width <= 512*CH8; SPLIT 3: tile-major fp16 operand of lemon_linear_f16x3t
 __global__ __launch_bounds__(256) void k_layernorm8(const float *__restrict__ x, const float *__restrict__ w,
                                                     const float *__restrict__ b, float eps, int64_t rows, int width,
                                                     float *__restrict__ y) {
@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void k_layernorm8(const float *__restrict__ x,
                 o[hf].z = (v[i][hf].z - mean) * rstd * ww.z + bb.z;
                 o[hf].w = (v[i][hf].w - mean) * rstd * ww.w + bb.w;
             }
-            if (SPLIT) store_split8<SPLIT ? SPLIT : 1, false>(reinterpret_cast<unsigned short *>(y) + row * split_segments(SPLIT) * (int64_t)width, width, c, o[0], o[1]);
+            if (SPLIT == 3) store_tiled8<TILE_A_ROWS, false>(reinterpret_cast<unsigned short *>(y), row, width, c, o[0], o[1]);
+            else if (SPLIT) store_split8<(SPLIT == 1 || SPLIT == 2) ? SPLIT : 1, false>(reinterpret_cast<unsigned short *>(y) + row * split_segments(SPLIT) * (int64_t)width, width, c, o[0], o[1]);
             else { yr[2 * c] = o[0]; yr[2 * c + 1] = o[1]; }
         }
     }
@@ -293,6 +294,24 @@ extern "C" int lemon_layernorm_split3(const float *x_dev, const float *weight_de
 extern "C" int lemon_layernorm_f16x3(const float *x_dev, const float *weight_dev, const float *bias_dev, float eps,
                                      int64_t rows, int width, uint16_t *y3_dev, void *stream_) {
     return layernorm_split_impl<2>(x_dev, weight_dev, bias_dev, eps, rows, width, y3_dev, stream_);
+}
+
+// ... as the tile-major fp16 operand of lemon_linear_f16x3t: yt_dev holds ceil(rows / 128) * 128 x width x 2 halves (rows beyond
+// `rows` are not written; the GEMM never stores what it computes from them)
+extern "C" int lemon_layernorm_f16x3t(const float *x_dev, const float *weight_dev, const float *bias_dev, float eps,
+                                      int64_t rows, int width, uint16_t *yt_dev, void *stream_) {
+    LEMON_REQUIRE(rows >= 0 && width > 0 && (width & 15) == 0 && width <= 2048, "rows >= 0, width a multiple of 16, <= 2048");
+    if (rows == 0) return LEMON_OK;
+    LEMON_REQUIRE(x_dev && weight_dev && bias_dev && yt_dev, "null pointer");
+    LEMON_REQUIRE(((((uintptr_t)x_dev) | ((uintptr_t)weight_dev) | ((uintptr_t)bias_dev) | ((uintptr_t)yt_dev)) & 15) == 0, "aligned pointers");
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    float *y = reinterpret_cast<float *>(yt_dev);
+    if (width <= 512) hipLaunchKernelGGL((k_layernorm8<1, 3>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
+    else if (width <= 1024) hipLaunchKernelGGL((k_layernorm8<2, 3>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
+    else hipLaunchKernelGGL((k_layernorm8<4, 3>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
 }
 
 template <int SCHEME>

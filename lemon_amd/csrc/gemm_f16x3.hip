@@ -1,0 +1,278 @@
+// gemm_f16x3.hip -- hand-written split-fp16 GEMM for the MLP of a transformer block (gfx950 only).
+//
+//   y = act(alpha * x W^T + bias) [+ residual]        fp32 x [m, k], W [n, k] carried as fp16 pairs, fp32 accumulate
+//
+// the arithmetic of lemon_linear_f16x3 (linear.hip: hi.hi + hi.lo + lo.hi on the fp16 matrix cores) in a kernel that knows the
+// operand structure, which the library kernel behind lemon_linear_f16x3 cannot:
+//   * operands are pre-packed TILE-MAJOR in MFMA fragment order (split3.hpp: tiled_off): a stage of the LDS ring is one
+//     contiguous global_load_lds copy, fragment reads are linear ds_read_b128 (no swizzle, no bank conflicts);
+//   * the activation's hi part is staged once (the library's [hi | hi | lo] row stages it twice) and W_hi 2^-11 is made in
+//     registers (four exact v_pk_mul_f16 per fragment): 24 KB per k16 step and workgroup instead of 36 KB;
+//   * the epilogue is ours: fc1's bias + QuickGELU (SiLU with the scale folded into alpha / bias) + the fp16 split are applied
+//     to the accumulators and stored AS THE NEXT GEMM'S OPERAND -- the MFMA output layout and the tile-major operand layout
+//     coincide, a wave's store instruction covers 512 contiguous bytes -- so the [m, mlp] fp32 activation tensor and the split
+//     pass over it (k_split3_rows: 7 % of the headline step) do not exist any more.
+// Workgroup: 128 (m) x 256 (n) output tile, four waves of 64 x 128 (8 accumulator tiles = 128 AccVGPRs), two workgroups per
+// CU (one's epilogue runs under the other's main loop), one k16 step per stage (A_hi, A_lo: 2 x 4 KB, W_hi, W_lo: 2 x 8 KB),
+// ring of 3 stages, 24 MFMAs per wave per barrier.  Tiles are walked in super-blocks of 32 m-tiles x 1 n-tile per XCD: the
+// weight tile column (393 KB per 768 k) stays in that XCD's L2, the activation rows stream.
+// Measured against the library on random operands (tools/micro/gemm_f16x3.hip, profiles/r3/micro_gemm_f16x3.txt): plain
+// epilogue 0.95-0.98 of the library's rate at the MLP shapes; fc1 with the fused epilogue 772 us against 669 + 264 us for
+// library GEMM + split pass.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <cmath>
+
+#include "common.hpp"
+#include "split3.hpp"
+
+using namespace lemon_split;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TM = TILE_A_ROWS, TN = TILE_W_ROWS;       // 128 x 256
+constexpr int IB = TM / 64;                             // 32-row activation blocks per wave (2)
+constexpr int BLKA = TM * 32, BLKW = TN * 32;           // bytes of one segment of one k16 step: 4 KB, 8 KB
+constexpr int STAGE = 2 * BLKA + 2 * BLKW;              // 24 KB
+constexpr int NB = 3, LA = NB - 1;
+constexpr int GM = 32;                                  // m-tiles per super-block (= workgroups an XCD runs at a time / 2)
+constexpr int DMA_PER_STAGE = BLKA / 2048 + 4;          // 1-KB instructions per wave and stage (2 + 4)
+
+struct GemmParams {
+    const char *at, *wt;       // tile-major operands
+    const float *bias;         // [n] or null
+    const float *residual;     // [m, n] fp32 or null (EPI 0)
+    void *out;                 // EPI 0: fp32 [m, n]; EPI 1: tile-major activation operand of the next GEMM (its k = n)
+    int64_t m;
+    int n, ks, m_tiles, n_tiles;
+    float alpha;
+};
+
+__device__ __forceinline__ void mfma(f32x16 &acc, const h16x8 &a, const h16x8 &b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+// 1 KB of LDS-DMA: `SGPR base + 32-bit lane offset`, M0 = LDS destination (nothing else in this kernel uses M0)
+__device__ __forceinline__ void dma1k(const char *src, unsigned voff, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(src), "s"(lds) : "memory");
+}
+__device__ __forceinline__ h16x8 lds128(unsigned addr, int off) {
+    h16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off));
+    return v;
+}
+
+// EPI 0: fp32 row-major (+ residual); EPI 1: SiLU, fp16 split, tile-major operand
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm_f16x3t(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int mt, nt;
+    {   // consecutive workgroup ids go round-robin over the 8 XCDs; an XCD walks super-blocks of GM m-tiles x 1 n-tile
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const int gm_n = (p.m_tiles + GM - 1) / GM;
+        const int blk = (q / GM) * 8 + xcd, pos = q % GM;
+        if (blk >= gm_n * p.n_tiles) return;
+        mt = (blk / p.n_tiles) * GM + pos; nt = blk % p.n_tiles;
+        if (mt >= p.m_tiles) return;
+    }
+    const int KS = p.ks;
+    const char *a_src = p.at + (size_t)mt * KS * 2 * BLKA;
+    const char *w_src = p.wt + (size_t)nt * KS * 2 * BLKW;
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)smem;
+    // DMA shares of a stage: wave w moves A bytes [2 KB w, +2 KB) and W bytes [4 KB w, +4 KB)
+    const unsigned va = (unsigned)(wave * (BLKA / 2) + lane * 16), vw = (unsigned)(wave * (BLKW / 2) + lane * 16);
+    auto issue = [&](int ks, int slot) {
+        const char *as = a_src + (size_t)ks * 2 * BLKA, *ws = w_src + (size_t)ks * 2 * BLKW;
+        const unsigned la = lds0 + slot * STAGE + wave * (BLKA / 2), lw = lds0 + slot * STAGE + 2 * BLKA + wave * (BLKW / 2);
+#pragma unroll
+        for (int j = 0; j < BLKA / 2048; ++j) dma1k(as, va + j * 1024, la + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma1k(ws, vw + j * 1024, lw + j * 1024);
+    };
+    f32x16 acc[4][IB];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < IB; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < LA; ++s)
+        if (s < KS) issue(s, s);
+    // fragment addresses inside a stage: A block (IB wm + i), W block (4 wn + j) of each segment
+    const unsigned fa = lds0 + wm * (IB * 1024) + lane * 16, fw = lds0 + 2 * BLKA + wn * 4096 + lane * 16;
+    h16x8 af[2][IB][2], wf[2][4][3];
+#define READ_FRAGS(set, slot)                                                                                   \
+    do {                                                                                                        \
+        const unsigned pa_ = fa + (slot) * STAGE, pw_ = fw + (slot) * STAGE;                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < IB; ++i_) {                                                     \
+            af[set][i_][0] = lds128(pa_, i_ * 1024); af[set][i_][1] = lds128(pa_, BLKA + i_ * 1024);            \
+        }                                                                                                       \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                      \
+            wf[set][j_][0] = lds128(pw_, j_ * 1024); wf[set][j_][1] = lds128(pw_, BLKW + j_ * 1024);            \
+        }                                                                                                       \
+    } while (0)
+#define DO_MFMAS(set)                                                                                           \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) wf[set][j_][2] = wf[set][j_][0] * (_Float16)0.00048828125f;      /* W_hi 2^-11: exact */ \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) _Pragma("unroll") for (int i_ = 0; i_ < IB; ++i_) mfma(acc[j_][i_], wf[set][j_][0], af[set][i_][0]); \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) _Pragma("unroll") for (int i_ = 0; i_ < IB; ++i_) mfma(acc[j_][i_], wf[set][j_][1], af[set][i_][0]); \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) _Pragma("unroll") for (int i_ = 0; i_ < IB; ++i_) mfma(acc[j_][i_], wf[set][j_][2], af[set][i_][1]); \
+    } while (0)
+    static_assert((LA - 1) * DMA_PER_STAGE == 6, "the counted wait below");
+#define WAIT_STAGE() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")      /* all but the youngest stage in flight have landed */
+#define PIN_ACC() do { _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) _Pragma("unroll") for (int i_ = 0; i_ < IB; ++i_) asm volatile("" : "+a"(acc[j_][i_])); } while (0)
+    if (KS > 1) WAIT_STAGE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    READ_FRAGS(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PIN_ACC();
+    for (int t = 0; t < KS; t += 2) {
+        PIN_ACC();          // (the loop-carried accumulators stay AccVGPRs: left alone hipcc homes them in VGPRs and copies them every step)
+        // ---- step t (fragment set 0); stage t+1's fragments (set 1) are read under its MFMAs ----
+        if (t + LA < KS) issue(t + LA, (t + LA) % NB);       // the slot of stage t-1: everyone is past the barrier behind its reads
+        if (t + 1 < KS) {
+            if (t + LA < KS) WAIT_STAGE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            READ_FRAGS(1, (t + 1) % NB);
+        }
+        DO_MFMAS(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (t + 1 >= KS) break;
+        // ---- step t+1 (set 1) ----
+        if (t + 1 + LA < KS) issue(t + 1 + LA, (t + 1 + LA) % NB);
+        if (t + 2 < KS) {
+            if (t + 1 + LA < KS) WAIT_STAGE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            READ_FRAGS(0, (t + 2) % NB);
+        }
+        DO_MFMAS(1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#undef READ_FRAGS
+#undef DO_MFMAS
+#undef WAIT_STAGE
+#undef PIN_ACC
+    // ---- epilogue: the lane holds row m = l%32 of activation block i and columns n = 8 g + 4 (l/32) + e of weight block j ----
+    const int l31 = lane & 31, h = lane >> 5;
+    const int N = p.n;
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+        const int64_t m = (int64_t)mt * TM + wm * (IB * 32) + i * 32 + l31;
+        if (EPI == 0 && m >= p.m) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n0 = nt * TN + wn * 128 + j * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + 8 * g;
+                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.bias) b = *reinterpret_cast<const float4 *>(p.bias + n);
+                float o[4] = {p.alpha * acc[j][i][4 * g] + b.x, p.alpha * acc[j][i][4 * g + 1] + b.y,
+                              p.alpha * acc[j][i][4 * g + 2] + b.z, p.alpha * acc[j][i][4 * g + 3] + b.w};
+                if (EPI == 0) {
+                    float *y = reinterpret_cast<float *>(p.out) + m * N + n;
+                    if (p.residual) {
+                        const float4 r = *reinterpret_cast<const float4 *>(p.residual + m * N + n);
+                        o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+                    }
+                    *reinterpret_cast<float4 *>(y) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    // the next GEMM's activation operand (its k = this n): lanes l and l+32 fill one 16-byte slot, a wave's store
+                    // instruction covers 512 contiguous bytes.  Rows >= m are computed from whatever the operand's pad rows
+                    // hold and land in the next operand's pad rows: never read into a stored result.
+                    h16x4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = o[e] / (1.0f + __expf(-o[e]));                  // SiLU
+                        unsigned short a_, b_, c_;
+                        split2h<false>(v, a_, b_, c_);
+                        hi[e] = __builtin_bit_cast(_Float16, a_); lo[e] = __builtin_bit_cast(_Float16, c_);
+                    }
+                    unsigned short *base = reinterpret_cast<unsigned short *>(p.out) + tiled_off(TM, m, n, 0, N);
+                    *reinterpret_cast<h16x4 *>(base) = hi;
+                    *reinterpret_cast<h16x4 *>(base + TM * 16) = lo;
+                }
+            }
+        }
+    }
+}
+
+// fp32 [n, k] weight -> tile-major fp16 pairs of w * wscale (one thread per 8 consecutive k)
+__global__ __launch_bounds__(256) void k_pack_weight_t(const float *__restrict__ w, int n, int k, float wscale, unsigned short *__restrict__ wt) {
+    const int nch = k >> 3;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n * nch) return;
+    const int64_t r = t / nch;
+    const int c = (int)(t - r * nch);
+    const float4 *src = reinterpret_cast<const float4 *>(w + r * (int64_t)k + 8 * c);
+    store_tiled8<TILE_W_ROWS, true>(wt, r, k, c, src[0], src[1], wscale);
+}
+
+// tile-major activation operand -> fp32 [rows, k] (hi + lo 2^-11): test / debugging aid
+__global__ __launch_bounds__(256) void k_unpack_act_t(const unsigned short *__restrict__ at, int64_t rows, int k, float *__restrict__ y) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * k) return;
+    const int64_t r = t / k;
+    const int c = (int)(t - r * k);
+    const float hi = f16_val(at[tiled_off(TILE_A_ROWS, r, c, 0, k)]), lo = f16_val(at[tiled_off(TILE_A_ROWS, r, c, 1, k)]);
+    y[t] = hi + lo * 0.00048828125f;
+}
+
+}  // namespace
+
+extern "C" int lemon_pack_weight_f16x3t(const float *w_dev, int n, int k, float wscale, uint16_t *wt_dev, void *stream_) {
+    LEMON_REQUIRE(n > 0 && k > 0 && n % TN == 0 && k % 16 == 0, "n a multiple of 256, k a multiple of 16");
+    LEMON_REQUIRE(w_dev && wt_dev && ((((uintptr_t)w_dev) | ((uintptr_t)wt_dev)) & 15) == 0, "aligned pointers");
+    int e = 0;
+    LEMON_REQUIRE(wscale > 0.0f && std::frexp(wscale, &e) == 0.5f, "wscale must be a power of two");
+    const int64_t threads = (int64_t)n * (k >> 3);
+    hipLaunchKernelGGL(k_pack_weight_t, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, w_dev, n, k, wscale, wt_dev);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}
+
+extern "C" int lemon_unpack_act_f16x3t(const uint16_t *at_dev, int64_t rows, int k, float *y_dev, void *stream_) {
+    LEMON_REQUIRE(rows >= 0 && k > 0 && k % 16 == 0, "rows >= 0, k a multiple of 16");
+    if (rows == 0) return LEMON_OK;
+    LEMON_REQUIRE(at_dev && y_dev, "null pointer");
+    const int64_t threads = rows * k;
+    hipLaunchKernelGGL(k_unpack_act_t, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, at_dev, rows, k, y_dev);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}
+
+extern "C" int lemon_linear_f16x3t(const uint16_t *at_dev, const uint16_t *wt_dev, const float *bias_dev, const float *residual_dev,
+                                   int64_t m, int n, int k, float alpha, int act, int out_operand, void *out_dev, void *stream_) {
+    LEMON_REQUIRE(m >= 0 && n > 0 && k > 0 && n % TN == 0 && k % 16 == 0, "m >= 0, n a multiple of 256, k a multiple of 16");
+    if (m == 0) return LEMON_OK;
+    LEMON_REQUIRE(at_dev && wt_dev && out_dev, "null pointer");
+    LEMON_REQUIRE(((((uintptr_t)at_dev) | ((uintptr_t)wt_dev) | ((uintptr_t)out_dev) | ((uintptr_t)bias_dev) | ((uintptr_t)residual_dev)) & 15) == 0,
+                  "16-byte aligned pointers");
+    LEMON_REQUIRE((act == LEMON_ACT_NONE && !out_operand) || (act == LEMON_ACT_SILU && out_operand && !residual_dev),
+                  "supported forms: act none -> fp32 [m, n] (+ residual); act SiLU -> tile-major operand (no residual)");
+    LEMON_REQUIRE((m + TM - 1) / TM < ((int64_t)1 << 24), "m < 2^31");
+    GemmParams p;
+    p.at = reinterpret_cast<const char *>(at_dev); p.wt = reinterpret_cast<const char *>(wt_dev);
+    p.bias = bias_dev; p.residual = residual_dev; p.out = out_dev;
+    p.m = m; p.n = n; p.ks = k / 16; p.m_tiles = (int)((m + TM - 1) / TM); p.n_tiles = n / TN; p.alpha = alpha;
+    const int64_t blocks = (int64_t)((p.m_tiles + GM - 1) / GM) * p.n_tiles;
+    const int64_t grid = ((blocks + 7) / 8) * GM * 8;
+    LEMON_REQUIRE(grid < ((int64_t)1 << 31), "grid size");
+    const size_t lds = (size_t)NB * STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    if (out_operand) hipLaunchKernelGGL(k_gemm_f16x3t<1>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+    else hipLaunchKernelGGL(k_gemm_f16x3t<0>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}

@@ -120,4 +120,30 @@ __device__ __forceinline__ void store_split8(unsigned short *__restrict__ row, i
     else store_split8_b<WEIGHT>(row, k, c8, v0, v1);
 }
 
+// ---- tile-major fp16 split operands of the hand-written GEMM (gemm_f16x3.hip, lemon_linear_f16x3t) ------------------------
+// Activations: [row tile of 128][k16 step][segment: hi, lo 2^11][row block of 32][k half][row in block][8 k] -- every 32-row x
+// 16-k block is 1 KB in MFMA fragment order (lane = k half * 32 + row), a stage of the GEMM's ring is one contiguous copy.
+// Weights: the same with 256-row tiles and segments hi, lo of w * wscale (hi 2^-11 is made in registers by the GEMM).
+constexpr int TILE_A_ROWS = 128, TILE_W_ROWS = 256;
+__device__ __host__ inline int64_t tiled_off(int tile_rows, int64_t row, int k, int seg, int width) {      // in halves
+    const int64_t tile = row / tile_rows;
+    const int r = (int)(row - tile * tile_rows);
+    return ((tile * (width >> 4) + (k >> 4)) * 2 + seg) * (int64_t)(tile_rows * 16) + (r >> 5) * 512 + ((k >> 3) & 1) * 256 + (r & 31) * 8 + (k & 7);
+}
+// eight consecutive k (chunk c8) of one row -> the two 16-byte slots of its hi and lo parts
+template <int TILE_ROWS, bool WEIGHT>
+__device__ __forceinline__ void store_tiled8(unsigned short *__restrict__ base, int64_t row, int width, int c8, float4 v0, float4 v1, float wscale = 1.0f) {
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    us8 a, d;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        unsigned short a_, b_, c_;
+        split2h<WEIGHT>(WEIGHT ? x[e] * wscale : x[e], a_, b_, c_);
+        a[e] = a_; d[e] = WEIGHT ? b_ : c_;          // weights: lo itself; activations: lo * 2^11
+    }
+    const int64_t o = tiled_off(TILE_ROWS, row, 8 * c8, 0, width);
+    *reinterpret_cast<us8 *>(base + o) = a;
+    *reinterpret_cast<us8 *>(base + o + TILE_ROWS * 16) = d;
+}
+
 }  // namespace lemon_split

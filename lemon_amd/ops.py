@@ -252,6 +252,87 @@ def linear_split(xs, ws, bias=None, residual=None, act=None, alpha=1.0):
 linear_split3 = linear_split
 
 
+# ---- the MLP of a block in the hand-written split-fp16 GEMM (gemm_f16x3.hip: tile-major operands, fused fc1 epilogue) ----
+def mlp_mode():
+    """'fused' (default, with LEMON_GEMM=f16x3): LayerNorm -> fc1 -> QuickGELU -> fc2 as lemon_layernorm_f16x3t + two
+    lemon_linear_f16x3t launches (the [m, mlp] fp32 activation and its split pass never exist); 'lib': the library GEMMs
+    (lemon_linear_f16x3) with the separate split pass (LEMON_MLP=lib)."""
+    import os
+    v = os.environ.get("LEMON_MLP", "fused").lower()
+    if v not in ("fused", "lib"):
+        raise ValueError(f"LEMON_MLP={v!r}: expected fused or lib")
+    return v
+
+
+def mlp_fused_supported(width, mlp):
+    return width % 256 == 0 and mlp % 256 == 0
+
+
+def _tiled_rows(m):
+    return (m + 127) // 128 * 128
+
+
+def pack_weight_t(w, wscale):
+    """float32 [n, k] -> the tile-major fp16 weight operand of lemon_linear_f16x3t (of w * wscale)."""
+    assert w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.shape[0] % 256 == 0 and w.shape[1] % 16 == 0
+    w = w.contiguous()
+    wt = torch.empty((w.shape[0] * w.shape[1] * 2,), dtype=torch.float16, device=w.device)
+    lib = _lib.load()
+    with torch.cuda.device(w.device):
+        _lib.check(lib.lemon_pack_weight_f16x3t(ptr(w), w.shape[0], w.shape[1], float(wscale), ptr(wt), stream_ptr(w.device)),
+                   "lemon_pack_weight_f16x3t")
+    return wt
+
+
+def layer_norm_t(x, weight, bias, eps=1e-5):
+    """LayerNorm whose output is the tile-major fp16 activation operand of lemon_linear_f16x3t (flat fp16 tensor)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 16 == 0
+    x = x.contiguous()
+    width = x.shape[-1]
+    m = x.numel() // width
+    at = torch.empty((_tiled_rows(m) * width * 2,), dtype=torch.float16, device=x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.lemon_layernorm_f16x3t(ptr(x), ptr(weight.contiguous()), ptr(bias.contiguous()), float(eps), m, width, ptr(at),
+                                              stream_ptr(x.device)), "lemon_layernorm_f16x3t")
+    return at
+
+
+def linear_t(at, wt, m, n, k, bias=None, residual=None, act=None, alpha=1.0, out_shape=None):
+    """lemon_linear_f16x3t on tile-major operands: act None -> float32 [m, n] (view `out_shape`) = alpha x W^T + bias (+ residual);
+    act 'silu' -> the tile-major activation operand (k' = n) of silu(alpha x W^T + bias)."""
+    assert at.is_cuda and at.dtype == torch.float16 and wt.dtype == torch.float16
+    assert at.numel() == _tiled_rows(m) * k * 2 and wt.numel() == n * k * 2
+    lib = _lib.load()
+    if bias is not None:
+        bias = bias.contiguous()
+    if act == "silu":
+        assert residual is None
+        out = torch.empty((_tiled_rows(m) * n * 2,), dtype=torch.float16, device=at.device)
+    else:
+        assert act is None
+        out = torch.empty(out_shape if out_shape is not None else (m, n), dtype=torch.float32, device=at.device)
+        assert out.numel() == m * n
+        if residual is not None:
+            assert residual.dtype == torch.float32 and residual.numel() == m * n
+            residual = residual.contiguous()
+    with torch.cuda.device(at.device):
+        _lib.check(lib.lemon_linear_f16x3t(ptr(at), ptr(wt), ptr(bias) if bias is not None else None,
+                                           ptr(residual) if residual is not None else None, m, n, k, float(alpha),
+                                           ACT_SILU if act == "silu" else ACT_NONE, int(act == "silu"), ptr(out), stream_ptr(at.device)),
+                   "lemon_linear_f16x3t")
+    return out
+
+
+def unpack_act_t(at, m, k):
+    """tile-major activation operand -> float32 [m, k] (hi + lo 2^-11)."""
+    y = torch.empty((m, k), dtype=torch.float32, device=at.device)
+    lib = _lib.load()
+    with torch.cuda.device(at.device):
+        _lib.check(lib.lemon_unpack_act_f16x3t(ptr(at), m, k, ptr(y), stream_ptr(at.device)), "lemon_unpack_act_f16x3t")
+    return y
+
+
 def layer_norm(x, weight, bias, eps=1e-5):
     """nn.LayerNorm over the last dimension of a float32 CUDA tensor in one HIP pass (lemon_layernorm_f32)."""
     assert x.is_cuda and x.dtype == torch.float32

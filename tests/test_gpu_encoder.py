@@ -206,3 +206,22 @@ def test_f16x3_reports_activations_beyond_the_fp16_range(hip, monkeypatch):
                     emb.raise_if_nonfinite()
         assert (outs[(scale, "bf16x6")] - outs[(scale, "f32")]).abs().max() < 5e-6      # (unit-norm embeddings)
     assert (outs[(1.0, "f16x3")] - outs[(1.0, "f32")]).abs().max() < 5e-6
+
+
+def test_fused_mlp_and_library_mlp_give_the_same_embeddings(hip, monkeypatch):
+    # LEMON_MLP=fused (gemm_f16x3.hip, the default) vs LEMON_MLP=lib (hipBLASLt + split pass), ViT-B/32, both towers
+    from lemon_amd.clip import ClipConfig, LemonCLIP
+    from lemon_amd.ops import normalize_vectors
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    model = LemonCLIP(ClipConfig.named("vit-b-32")).eval().to(dev)
+    px = torch.randn(70, 3, 224, 224, device=dev)
+    ids = torch.randint(1, 1000, (300, 77), device=dev)
+    ids[:, 9] = model.cfg.eos_token_id
+    out = {}
+    for mode in ("fused", "lib"):
+        monkeypatch.setenv("LEMON_MLP", mode)
+        with torch.no_grad():
+            out[mode] = (normalize_vectors(model.encode_image(px).float()), normalize_vectors(model.encode_text(ids).float()))
+    for a, b in zip(out["fused"], out["lib"]):
+        assert bool(torch.isfinite(a).all()) and float((a - b).abs().max()) < 5e-6

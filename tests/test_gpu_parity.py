@@ -763,3 +763,60 @@ def test_clip_logits_confidence_matches_reference_golden(hip, dist):
     got = clip_logits_confidence(torch.from_numpy(g["img"]).cuda(), torch.from_numpy(g["cls"]).cuda(), g["lab"], dist).cpu().numpy()
     assert np.abs(got - g[f"conf_{dist}"]).max() <= 2e-6, np.abs(got - g[f"conf_{dist}"]).max()
     assert np.all((got > 0) & (got < 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,width,mlp", [(300, 256, 512), (129, 512, 2048), (5000, 768, 3072), (1, 256, 256)])
+def test_fused_mlp_in_the_hand_written_gemm_matches_float64(hip, m, width, mlp):
+    # gemm_f16x3.hip: LayerNorm -> tile-major operand -> fc1 (+ bias, QuickGELU, fp16 split in the epilogue, stored as fc2's
+    # operand) -> fc2 (+ bias, residual) against the same chain in float64, and against the library path (lemon_linear_f16x3 +
+    # split pass).  Rows beyond m of the tile-major operands are uninitialised memory: they must not reach a stored result.
+    from lemon_amd import ops
+    g = torch.Generator().manual_seed(m * 13 + width)
+    x = torch.randn(m, width, generator=g) * 2.0
+    lw, lb = 1.0 + 0.1 * torch.randn(width, generator=g), 0.1 * torch.randn(width, generator=g)
+    w1, b1 = torch.randn(mlp, width, generator=g) / width ** 0.5, 0.1 * torch.randn(mlp, generator=g)
+    w2, b2 = torch.randn(width, mlp, generator=g) / mlp ** 0.5, 0.1 * torch.randn(width, generator=g)
+    s = ops.QUICK_GELU_SCALE
+    xd = x.double()
+    xn = torch.nn.functional.layer_norm(xd, (width,), lw.double(), lb.double(), 1e-5)
+    z = xn @ w1.double().T + b1.double()
+    hd = z * torch.sigmoid(s * z)
+    ref = hd @ w2.double().T + b2.double() + xd
+    xc, lwc, lbc = x.cuda(), lw.cuda(), lb.cuda()
+    poison = torch.full((8 << 20,), float("nan"), device="cuda")        # (so that fresh allocations below are likely to hold NaNs)
+    del poison
+    s1, s2 = ops.weight_scale_f16x3(w1), ops.weight_scale_f16x3(w2)
+    at = ops.layer_norm_t(xc, lwc, lbc, 1e-5)
+    # the LayerNorm operand holds exactly the split of lemon_layernorm_f32's values
+    y3 = ops.split_operand(ops.layer_norm(xc, lwc, lbc, 1e-5), "f16x3").view(m, 3, width)
+    assert torch.equal(ops.unpack_act_t(at, m, width), y3[:, 0].float() + y3[:, 2].float() * (1.0 / 2048.0))
+    ht = ops.linear_t(at, ops.pack_weight_t(w1.cuda(), s1), m, mlp, width, (b1 * s).cuda(), act="silu", alpha=s / s1)
+    h_got = ops.unpack_act_t(ht, m, mlp).cpu().double() / s
+    assert float((h_got - hd).abs().max()) < 2e-5 * max(1.0, width ** 0.5 / 8)
+    got = ops.linear_t(ht, ops.pack_weight_t(w2.cuda(), s2), m, width, mlp, b2.cuda(), residual=xc, alpha=1.0 / (s * s2)).cpu().double()
+    e_fused = float((got - ref).abs().max())
+    assert torch.isfinite(got).all() and e_fused < 3e-5 * max(1.0, mlp ** 0.5 / 8), e_fused
+    # the library path on the same inputs
+    a3 = ops.layer_norm_split(xc, lwc, lbc, 1e-5, "f16x3")
+    h = ops.linear_split(a3, ops.split_operand(w1.cuda(), "f16x3", weight=True, wscale=s1), (b1 * s).cuda(), act="silu", alpha=s / s1)
+    lib = ops.linear_split(ops.split_operand(h, "f16x3"), ops.split_operand(w2.cuda(), "f16x3", weight=True, wscale=s2), b2.cuda(),
+                           residual=xc, alpha=1.0 / (s * s2)).cpu().double()
+    e_lib = float((lib - ref).abs().max())
+    assert e_fused <= 2.0 * e_lib + 2e-6, (e_fused, e_lib)
+
+
+@pytest.mark.gpu
+def test_hand_written_gemm_is_position_independent(hip):
+    # identical rows in, identical rows out, wherever they sit in the batch (the text tower folds identical prompts)
+    from lemon_amd import ops
+    g = torch.Generator().manual_seed(3)
+    row = torch.randn(1, 512, generator=g)
+    x = row.repeat(1000, 1).cuda()
+    lw, lb = torch.ones(512).cuda(), torch.zeros(512).cuda()
+    w1 = (torch.randn(2048, 512, generator=g) / 512 ** 0.5).cuda()
+    w2 = (torch.randn(512, 2048, generator=g) / 2048 ** 0.5).cuda()
+    s1, s2 = ops.weight_scale_f16x3(w1), ops.weight_scale_f16x3(w2)
+    ht = ops.linear_t(ops.layer_norm_t(x, lw, lb), ops.pack_weight_t(w1, s1), 1000, 2048, 512, None, act="silu", alpha=1.0 / s1)
+    y = ops.linear_t(ht, ops.pack_weight_t(w2, s2), 1000, 512, 2048, None, residual=x, alpha=1.0 / s2)
+    assert bool((y == y[0]).all())
