@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
 // LayerNorm for widths that are multiples of 8: every lane owns EIGHT consecutive elements per chunk (two float4), so the
 // split variant stores 16 bytes per segment instead of 8 (94 -> see DESIGN us per 50 000 x 768 rows); the fp32 variant uses
 // the same element-to-lane mapping, so lemon_layernorm_split3 == lemon_split3_f32(lemon_layernorm_f32) bit for bit.
-template <int CH8, int SPLIT>   // 8-element chunks per lane: width <= 512*CH8; SPLIT 3: tile-major fp16 operand of lemon_linear_f16x3t
+template <int CH8, int SPLIT>   // 8-element chunks per lane: width <= 512*CH8
 __global__ __launch_bounds__(256) void k_layernorm8(const float *__restrict__ x, const float *__restrict__ w,
                                                     const float *__restrict__ b, float eps, int64_t rows, int width,
                                                     float *__restrict__ y) {
@@ -128,10 +128,89 @@ __global__ __launch_bounds__(256) void k_layernorm8(const float *__restrict__ x,
                 o[hf].z = (v[i][hf].z - mean) * rstd * ww.z + bb.z;
                 o[hf].w = (v[i][hf].w - mean) * rstd * ww.w + bb.w;
             }
-            if (SPLIT == 3) store_tiled8<TILE_A_ROWS, false>(reinterpret_cast<unsigned short *>(y), row, width, c, o[0], o[1]);
-            else if (SPLIT) store_split8<(SPLIT == 1 || SPLIT == 2) ? SPLIT : 1, false>(reinterpret_cast<unsigned short *>(y) + row * split_segments(SPLIT) * (int64_t)width, width, c, o[0], o[1]);
+            if (SPLIT) store_split8<SPLIT ? SPLIT : 1, false>(reinterpret_cast<unsigned short *>(y) + row * split_segments(SPLIT) * (int64_t)width, width, c, o[0], o[1]);
             else { yr[2 * c] = o[0]; yr[2 * c + 1] = o[1]; }
         }
+    }
+}
+
+// LayerNorm -> tile-major fp16 operand of lemon_linear_f16x3t (split3.hpp: tiled_off).  In that layout the 16-byte slots of
+// CONSECUTIVE ROWS are adjacent, so the wave-per-row mapping above would scatter 16-byte pieces (measured: 125 us against
+// 57 us for the row-major operand at 50 000 x 768).  Here a workgroup normalises eight consecutive rows (two per wave), parks
+// their hi / lo chunks in LDS as [chunk][part][row] and writes them out eight rows = one 128-byte line per chunk and part.
+// Same arithmetic and element-to-lane mapping as k_layernorm8: the operand holds exactly the split of lemon_layernorm_f32.
+template <int CH8>
+__global__ __launch_bounds__(256) void k_layernorm8_t(const float *__restrict__ x, const float *__restrict__ w,
+                                                      const float *__restrict__ b, float eps, int64_t rows, int width,
+                                                      unsigned short *__restrict__ yt) {
+    extern __shared__ __attribute__((aligned(16))) us8 s_t[];          // [8 rows][2 parts x width/8 chunks (+1: odd pitch)] 16-byte slots
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = width >> 3;
+    const int64_t row0 = (int64_t)blockIdx.x * 8;
+    for (int rr = 0; rr < 2; ++rr) {
+        const int rw = 2 * wave + rr;
+        const int64_t row = row0 + rw;
+        if (row >= rows) continue;                                     // (wave-uniform)
+        const float4 *xr = reinterpret_cast<const float4 *>(x + row * (int64_t)width);
+        float4 v[CH8][2];
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < CH8; ++i) {
+            const int c = lane + 64 * i;
+            v[i][0] = v[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < nch) { v[i][0] = xr[2 * c]; v[i][1] = xr[2 * c + 1]; }
+            s += ((v[i][0].x + v[i][0].y) + (v[i][0].z + v[i][0].w)) + ((v[i][1].x + v[i][1].y) + (v[i][1].z + v[i][1].w));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        const float mean = s / (float)width;
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < CH8; ++i) {
+            if (lane + 64 * i < nch) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const float dx = v[i][hf].x - mean, dy = v[i][hf].y - mean, dz = v[i][hf].z - mean, dw = v[i][hf].w - mean;
+                    q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+        const float rstd = rsqrtf(q / (float)width + eps);
+        const float4 *w4 = reinterpret_cast<const float4 *>(w);
+        const float4 *b4 = reinterpret_cast<const float4 *>(b);
+#pragma unroll
+        for (int i = 0; i < CH8; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                float o[8];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const float4 ww = w4[2 * c + hf], bb = b4[2 * c + hf];
+                    o[4 * hf] = (v[i][hf].x - mean) * rstd * ww.x + bb.x;
+                    o[4 * hf + 1] = (v[i][hf].y - mean) * rstd * ww.y + bb.y;
+                    o[4 * hf + 2] = (v[i][hf].z - mean) * rstd * ww.z + bb.z;
+                    o[4 * hf + 3] = (v[i][hf].w - mean) * rstd * ww.w + bb.w;
+                }
+                us8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    unsigned short a_, b_, c_;
+                    split2h<false>(o[e], a_, b_, c_);
+                    hi[e] = a_; lo[e] = c_;
+                }
+                s_t[rw * (2 * nch + 1) + c] = hi;                       // (consecutive lanes, consecutive slots)
+                s_t[rw * (2 * nch + 1) + nch + c] = lo;
+            }
+        }
+    }
+    __syncthreads();
+    const int nrow = rows - row0 < 8 ? (int)(rows - row0) : 8;
+    for (int idx = threadIdx.x; idx < nch * 16; idx += 256) {
+        const int rw = idx & 7, part = (idx >> 3) & 1, c = idx >> 4;
+        if (rw < nrow)
+            *reinterpret_cast<us8 *>(yt + tiled_off(TILE_A_ROWS, row0 + rw, 8 * c, part, width)) = s_t[rw * (2 * nch + 1) + part * nch + c];
     }
 }
 
@@ -305,11 +384,11 @@ extern "C" int lemon_layernorm_f16x3t(const float *x_dev, const float *weight_de
     LEMON_REQUIRE(x_dev && weight_dev && bias_dev && yt_dev, "null pointer");
     LEMON_REQUIRE(((((uintptr_t)x_dev) | ((uintptr_t)weight_dev) | ((uintptr_t)bias_dev) | ((uintptr_t)yt_dev)) & 15) == 0, "aligned pointers");
     hipStream_t stream = (hipStream_t)stream_;
-    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-    float *y = reinterpret_cast<float *>(yt_dev);
-    if (width <= 512) hipLaunchKernelGGL((k_layernorm8<1, 3>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
-    else if (width <= 1024) hipLaunchKernelGGL((k_layernorm8<2, 3>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
-    else hipLaunchKernelGGL((k_layernorm8<4, 3>), grid, block, 0, stream, x_dev, weight_dev, bias_dev, eps, rows, width, y);
+    const dim3 grid((unsigned)((rows + 7) / 8)), block(256);
+    const size_t lds = (size_t)(2 * (width / 8) + 1) * 8 * 16;         // 24.1 KB at width 768
+    if (width <= 512) hipLaunchKernelGGL((k_layernorm8_t<1>), grid, block, lds, stream, x_dev, weight_dev, bias_dev, eps, rows, width, yt_dev);
+    else if (width <= 1024) hipLaunchKernelGGL((k_layernorm8_t<2>), grid, block, lds, stream, x_dev, weight_dev, bias_dev, eps, rows, width, yt_dev);
+    else hipLaunchKernelGGL((k_layernorm8_t<4>), grid, block, lds, stream, x_dev, weight_dev, bias_dev, eps, rows, width, yt_dev);
     LEMON_HIP_CHECK(hipGetLastError());
     return LEMON_OK;
 }

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t(GemmParams p) {
                     h16x4 hi, lo;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float v = o[e] / (1.0f + __expf(-o[e]));                  // SiLU
+                        const float v = o[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-o[e]));      // SiLU (v_exp_f32 / v_rcp_f32: 1 ulp each)
                         unsigned short a_, b_, c_;
                         split2h<false>(v, a_, b_, c_);
                         hi[e] = __builtin_bit_cast(_Float16, a_); lo[e] = __builtin_bit_cast(_Float16, c_);
