@@ -200,12 +200,6 @@ __global__ __launch_bounds__(64 * TJ) void k_attention_hd64_short(const float *_
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int id = tid + i * 64 * TJ, r = id >> 4, c = id & 15;
-            vreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < L) vreg[i] = *reinterpret_cast<const float4 *>(base + (int64_t)r * tok_stride + 4 * c + 2 * H * HD);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int id = tid + i * 64 * TJ, r = id >> 4, c = id & 15;
             *reinterpret_cast<float4 *>(&sKV[r * PITCH + 4 * c]) = qreg[i];
         }
     }
@@ -227,6 +221,14 @@ __global__ __launch_bounds__(64 * TJ) void k_attention_hd64_short(const float *_
     }
     __syncthreads();
 
+    // V is fetched only now, under the score MFMAs: holding it in registers from the start (184 VGPRs) kept a SIMD at two
+    // waves; its latency is covered by the other workgroups of the CU instead
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int id = tid + i * 64 * TJ, r = id >> 4, c = id & 15;
+        vreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < L) vreg[i] = *reinterpret_cast<const float4 *>(base + (int64_t)r * tok_stride + 4 * c + 2 * H * HD);
+    }
     // all score tiles of this lane's query: S^T tile tj = K[32tj.., :] Q^T (two accumulators per tile: even / odd k-steps,
     // so that consecutive MFMAs do not wait for each other)
     f32x16 s[TJ];

@@ -19,6 +19,6 @@ rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_scan|k_bf16_final|k_neighbo
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_scan|k_bf16_final|k_neighbors|k_merge" --output-format csv -d $OUT/pmc_bench_write_$TAG -- python3 $R/bench.py --steps 1 --warmup 0 --no_cpu_baseline --no_knn_1m > /dev/null 2> $OUT/pmc_bench_write_$TAG.err || exit 8
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "k_scan|k_bf16_final|k_neighbors|k_merge|k_attention|k_layernorm|k_vision" --output-format csv -d $OUT/pmc_bench_mfma_$TAG -- python3 $R/bench.py --steps 1 --warmup 0 --no_cpu_baseline --no_knn_1m > /dev/null 2> $OUT/pmc_bench_mfma_$TAG.err || exit 9
 # MFMA utilisation of the tower GEMMs (hipBLASLt `Cijk_...` kernels) and the attention kernels on the FULL headline shape
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "Cijk|k_attention" --output-format csv -d $OUT/pmc_encoder_mfma_$TAG -- python3 $R/bench.py --steps 1 --warmup 0 --no_cpu_baseline --no_knn_1m > /dev/null 2> $OUT/pmc_encoder_mfma_$TAG.err || exit 10
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "Cijk|k_attention|k_gemm_f16x3t" --output-format csv -d $OUT/pmc_encoder_mfma_$TAG -- python3 $R/bench.py --steps 1 --warmup 0 --no_cpu_baseline --no_knn_1m > /dev/null 2> $OUT/pmc_encoder_mfma_$TAG.err || exit 10
 find $OUT -name "*_kernel_trace.csv" -size +20M -delete
 ls $OUT/prof_bench_$TAG/*/ | head -20
