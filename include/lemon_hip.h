@@ -213,6 +213,10 @@ int lemon_layernorm_f16x3t(const float *x_dev, const float *weight_dev, const fl
 int lemon_linear_f16x3t(const uint16_t *at_dev, const uint16_t *wt_dev, const float *bias_dev, const float *residual_dev,
                         int64_t m, int n, int k, float alpha, int act, int out_operand, void *out_dev, void *stream);
 int lemon_unpack_act_f16x3t(const uint16_t *at_dev, int64_t rows, int k, float *y_dev, void *stream);
+/* lemon_attention_f32 whose result is written as that activation operand (rows = batch*seq_len, k = heads*64): the output
+ * projection then runs in the hand-written GEMM too (with QKV: all four GEMMs of a block). */
+int lemon_attention_f16x3t(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
+                           int causal, uint16_t *outt_dev, void *stream);
 /* Recorded solution choices: a "# lemon_linear hipblaslt=<version> arch=<gfx name>" stamp line followed by
  * "m,n,k,epilogue,residual,index,usec" lines.  load returns the number of keys taken -- 0 when the stamp
  * does not match this process's hipBLASLt version / device arch (the file is then ignored) -- and dump the

@@ -170,6 +170,17 @@ class Block(nn.Module):
             cache["fc1_bias_scaled"] = hit
         return hit[1]
 
+    def _mlp_hand(self, x, ops, W, mlp):
+        """x + fc2(QuickGELU(fc1(LayerNorm(x)))) in the hand-written GEMM (gemm_f16x3.hip): LayerNorm writes the tile-major
+        operand, fc1's epilogue applies bias + QuickGELU + the fp16 split and stores fc2's operand, fc2 adds bias and residual."""
+        s = ops.QUICK_GELU_SCALE
+        m = x.numel() // W
+        w1, a1 = self._w_tiled("fc1", ops)
+        w2, a2 = self._w_tiled("fc2", ops)
+        at = ops.layer_norm_t(x, self.ln2.weight, self.ln2.bias, self.ln2.eps)
+        ht = ops.linear_t(at, w1, m, mlp, W, self._fc1_bias_scaled(s), act="silu", alpha=s * a1)
+        return ops.linear_t(ht, w2, m, W, mlp, self.fc2.bias, residual=x, alpha=a2 / s, out_shape=x.shape)
+
     def _w_split(self, name, ops, mode):
         return split_weight_cached(self, name, getattr(self, name).weight, ops, mode)
 
@@ -190,6 +201,18 @@ class Block(nn.Module):
         2-way fp16, three --, fp32 accumulate); LayerNorm and attention write the split operand directly, the MLP activations
         get one split pass."""
         B, L, W = x.shape
+        mlp = self.fc1.weight.shape[0]
+        hand = mode == "f16x3" and rows is None and ops.mlp_mode()
+        if hand == "block" and ops.block_fused_supported(W, mlp, self.heads, L):
+            # QKV and the output projection in the hand-written GEMM as well (LEMON_MLP=block; not the default: see ops.mlp_mode):
+            # LayerNorm and attention write its tile-major operands
+            m = B * L
+            wq, aq = self._w_tiled("qkv", ops)
+            wo, ao = self._w_tiled("out", ops)
+            qkv = ops.linear_t(ops.layer_norm_t(x, self.ln1.weight, self.ln1.bias, self.ln1.eps), wq, m, 3 * W, W, self.qkv.bias,
+                               alpha=aq, out_shape=(B, L, 3 * W))
+            x = ops.linear_t(ops.attention_t(qkv, self.heads, causal), wo, m, W, W, self.out.bias, residual=x, alpha=ao, out_shape=x.shape)
+            return self._mlp_hand(x, ops, W, mlp)
         w, a_ = self._w_split("qkv", ops, mode)
         qkv = ops.linear_split(ops.layer_norm_split(x, self.ln1.weight, self.ln1.bias, self.ln1.eps, mode), w, self.qkv.bias, alpha=a_)
         hip_attn = W == 64 * self.heads and L <= ops.ATTENTION_MAX_SEQ
@@ -203,16 +226,8 @@ class Block(nn.Module):
         w, a_ = self._w_split("out", ops, mode)
         x = ops.linear_split(a6, w, self.out.bias, residual=x, alpha=a_)
         s = ops.QUICK_GELU_SCALE
-        mlp = self.fc1.weight.shape[0]
-        if mode == "f16x3" and rows is None and ops.mlp_mode() == "fused" and ops.mlp_fused_supported(W, mlp):
-            # the MLP in the hand-written GEMM (gemm_f16x3.hip): LayerNorm writes the tile-major operand, fc1's epilogue applies
-            # bias + QuickGELU + the fp16 split and stores fc2's operand, fc2 adds bias and the residual
-            m = x.numel() // W
-            w1, a1 = self._w_tiled("fc1", ops)
-            w2, a2 = self._w_tiled("fc2", ops)
-            at = ops.layer_norm_t(x, self.ln2.weight, self.ln2.bias, self.ln2.eps)
-            ht = ops.linear_t(at, w1, m, mlp, W, self._fc1_bias_scaled(s), act="silu", alpha=s * a1)
-            return ops.linear_t(ht, w2, m, W, mlp, self.fc2.bias, residual=x, alpha=a2 / s, out_shape=x.shape)
+        if hand in ("block", "fused") and ops.mlp_fused_supported(W, mlp):
+            return self._mlp_hand(x, ops, W, mlp)
         w, a_ = self._w_split("fc1", ops, mode)
         h = ops.linear_split(ops.layer_norm_split(x, self.ln2.weight, self.ln2.bias, self.ln2.eps, mode), w,
                              self._fc1_bias_scaled(s), act="silu", alpha=s * a_)

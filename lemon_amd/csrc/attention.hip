@@ -145,15 +145,31 @@ __global__ __launch_bounds__(576) void k_attention_hd64(const float *__restrict_
     if (qi < L) {
         const float inv = 1.0f / l_run;
         float *dst = out + ((b * L + qi) * H + head) * HD;
-        unsigned short *row6 = reinterpret_cast<unsigned short *>(out) + (b * L + qi) * lemon_split::split_segments(SPLIT) * (int64_t)(H * HD);
+        unsigned short *row6 = reinterpret_cast<unsigned short *>(out) + (b * L + qi) * lemon_split::split_segments(SPLIT == 3 ? 2 : SPLIT) * (int64_t)(H * HD);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int c0 = 8 * g + 4 * h;
             const float4 v0 = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
             const float4 v1 = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
-            if (SPLIT) {
-                lemon_split::store_split4<SPLIT ? SPLIT : 1, false>(row6, H * HD, (head * HD + c0) >> 2, v0);
-                lemon_split::store_split4<SPLIT ? SPLIT : 1, false>(row6, H * HD, (head * HD + 32 + c0) >> 2, v1);
+            if (SPLIT == 3) {          // tile-major operand of lemon_linear_f16x3t: four values = half a 16-byte slot of the row
+                unsigned short *ot = reinterpret_cast<unsigned short *>(out);
+                const float vv[2][4] = {{v0.x, v0.y, v0.z, v0.w}, {v1.x, v1.y, v1.z, v1.w}};
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    lemon_split::us4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        unsigned short a_, b_, c_;
+                        lemon_split::split2h<false>(vv[u][e], a_, b_, c_);
+                        hi[e] = a_; lo[e] = c_;
+                    }
+                    const int64_t o = lemon_split::tiled_off(lemon_split::TILE_A_ROWS, b * L + qi, head * HD + 32 * u + c0, 0, H * HD);
+                    *reinterpret_cast<lemon_split::us4 *>(ot + o) = hi;
+                    *reinterpret_cast<lemon_split::us4 *>(ot + o + lemon_split::TILE_A_ROWS * 16) = lo;
+                }
+            } else if (SPLIT) {
+                lemon_split::store_split4<(SPLIT == 1 || SPLIT == 2) ? SPLIT : 1, false>(row6, H * HD, (head * HD + c0) >> 2, v0);
+                lemon_split::store_split4<(SPLIT == 1 || SPLIT == 2) ? SPLIT : 1, false>(row6, H * HD, (head * HD + 32 + c0) >> 2, v1);
             } else {
                 *reinterpret_cast<float4 *>(dst + c0) = v0;
                 *reinterpret_cast<float4 *>(dst + 32 + c0) = v1;
@@ -307,12 +323,16 @@ __global__ __launch_bounds__(64 * TJ) void k_attention_hd64_short(const float *_
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                   // 8 lanes per token row, 8 values each: 16-byte stores in both forms
-        const int id = tid + i * 64 * TJ, r = id >> 3, c8 = id & 7;
+        const int id = tid + i * 64 * TJ;
+        // (tile-major operand: the 16-byte slots of consecutive ROWS are adjacent, so consecutive lanes take consecutive rows)
+        const int r = SPLIT == 3 ? id % (32 * TJ) : id >> 3, c8 = SPLIT == 3 ? id / (32 * TJ) : id & 7;
         if (r < L) {
             const float4 v0 = *reinterpret_cast<const float4 *>(&sKV[r * PITCH + 8 * c8]);
             const float4 v1 = *reinterpret_cast<const float4 *>(&sKV[r * PITCH + 8 * c8 + 4]);
-            if (SPLIT)
-                lemon_split::store_split8<SPLIT ? SPLIT : 1, false>(reinterpret_cast<unsigned short *>(out) + (b * L + r) * lemon_split::split_segments(SPLIT) * (int64_t)(H * HD), H * HD,
+            if (SPLIT == 3)
+                lemon_split::store_tiled8<lemon_split::TILE_A_ROWS, false>(reinterpret_cast<unsigned short *>(out), b * L + r, H * HD, head * (HD / 8) + c8, v0, v1);
+            else if (SPLIT)
+                lemon_split::store_split8<(SPLIT == 1 || SPLIT == 2) ? SPLIT : 1, false>(reinterpret_cast<unsigned short *>(out) + (b * L + r) * lemon_split::split_segments(SPLIT == 3 ? 2 : SPLIT) * (int64_t)(H * HD), H * HD,
                                                  head * (HD / 8) + c8, v0, v1);
             else {
                 float *dst = out + ((b * L + r) * H + head) * HD + 8 * c8;
@@ -371,4 +391,11 @@ extern "C" int lemon_attention_split3(const float *qkv_dev, int64_t batch, int s
 extern "C" int lemon_attention_f16x3(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
                                      int causal, uint16_t *out3_dev, void *stream) {
     return attention_impl<2>(qkv_dev, batch, seq_len, heads, head_dim, causal, reinterpret_cast<float *>(out3_dev), stream);
+}
+
+// ... as the tile-major fp16 activation operand of lemon_linear_f16x3t (the output projection in the hand-written GEMM):
+// outt_dev holds ceil(batch*seq_len / 128) * 128 x heads*64 x 2 halves, 16-byte aligned
+extern "C" int lemon_attention_f16x3t(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
+                                      int causal, uint16_t *outt_dev, void *stream) {
+    return attention_impl<3>(qkv_dev, batch, seq_len, heads, head_dim, causal, reinterpret_cast<float *>(outt_dev), stream);
 }

@@ -254,18 +254,25 @@ linear_split3 = linear_split
 
 # ---- the MLP of a block in the hand-written split-fp16 GEMM (gemm_f16x3.hip: tile-major operands, fused fc1 epilogue) ----
 def mlp_mode():
-    """'fused' (default, with LEMON_GEMM=f16x3): LayerNorm -> fc1 -> QuickGELU -> fc2 as lemon_layernorm_f16x3t + two
-    lemon_linear_f16x3t launches (the [m, mlp] fp32 activation and its split pass never exist); 'lib': the library GEMMs
-    (lemon_linear_f16x3) with the separate split pass (LEMON_MLP=lib)."""
+    """LEMON_MLP, with LEMON_GEMM=f16x3: 'fused' (default): the MLP of every block in the hand-written kernel (gemm_f16x3.hip:
+    LayerNorm writes its tile-major operand, fc1's epilogue writes fc2's; the [m, mlp] fp32 activation and its split pass never
+    exist), QKV and the output projection in the library; 'block': those two in the hand-written kernel as well (measured 2 %
+    SLOWER end to end: 32.7 k vs 33.4 k scores/s -- the plain epilogue has nothing to fuse there and the short-k output
+    projection is epilogue-bound); 'lib': the library GEMMs (lemon_linear_f16x3) with the separate split pass."""
     import os
     v = os.environ.get("LEMON_MLP", "fused").lower()
-    if v not in ("fused", "lib"):
-        raise ValueError(f"LEMON_MLP={v!r}: expected fused or lib")
+    if v not in ("block", "fused", "lib"):
+        raise ValueError(f"LEMON_MLP={v!r}: expected block, fused or lib")
     return v
 
 
 def mlp_fused_supported(width, mlp):
     return width % 256 == 0 and mlp % 256 == 0
+
+
+def block_fused_supported(width, mlp, heads, seq_len):
+    """all four GEMMs of a block in the hand-written kernel: additionally 3 * width a multiple of 256 and the HIP attention"""
+    return mlp_fused_supported(width, mlp) and (3 * width) % 256 == 0 and width == 64 * heads and seq_len <= ATTENTION_MAX_SEQ
 
 
 def _tiled_rows(m):
@@ -321,6 +328,20 @@ def linear_t(at, wt, m, n, k, bias=None, residual=None, act=None, alpha=1.0, out
                                            ptr(residual) if residual is not None else None, m, n, k, float(alpha),
                                            ACT_SILU if act == "silu" else ACT_NONE, int(act == "silu"), ptr(out), stream_ptr(at.device)),
                    "lemon_linear_f16x3t")
+    return out
+
+
+def attention_t(qkv, heads, causal=False):
+    """attention() whose output is the tile-major fp16 activation operand of lemon_linear_f16x3t (rows = B*L, k = heads*64)."""
+    assert qkv.is_cuda and qkv.dtype == torch.float32 and qkv.dim() == 3
+    qkv = qkv.contiguous()
+    B, L, W3 = qkv.shape
+    assert W3 == 3 * heads * 64 and L <= ATTENTION_MAX_SEQ
+    out = torch.empty((_tiled_rows(B * L) * heads * 64 * 2,), dtype=torch.float16, device=qkv.device)
+    lib = _lib.load()
+    with torch.cuda.device(qkv.device):
+        _lib.check(lib.lemon_attention_f16x3t(ptr(qkv), B, L, heads, 64, int(bool(causal)), ptr(out), stream_ptr(qkv.device)),
+                   "lemon_attention_f16x3t")
     return out
 
 

@@ -209,7 +209,8 @@ def test_f16x3_reports_activations_beyond_the_fp16_range(hip, monkeypatch):
 
 
 def test_fused_mlp_and_library_mlp_give_the_same_embeddings(hip, monkeypatch):
-    # LEMON_MLP=fused (gemm_f16x3.hip, the default) vs LEMON_MLP=lib (hipBLASLt + split pass), ViT-B/32, both towers
+    # LEMON_MLP=fused (the MLP in gemm_f16x3.hip, the default) / block (all four GEMMs of a block) vs lib (hipBLASLt + split
+    # pass), ViT-B/32, both towers
     from lemon_amd.clip import ClipConfig, LemonCLIP
     from lemon_amd.ops import normalize_vectors
     dev = torch.device("cuda:0")
@@ -219,9 +220,10 @@ def test_fused_mlp_and_library_mlp_give_the_same_embeddings(hip, monkeypatch):
     ids = torch.randint(1, 1000, (300, 77), device=dev)
     ids[:, 9] = model.cfg.eos_token_id
     out = {}
-    for mode in ("fused", "lib"):
+    for mode in ("block", "fused", "lib"):
         monkeypatch.setenv("LEMON_MLP", mode)
         with torch.no_grad():
             out[mode] = (normalize_vectors(model.encode_image(px).float()), normalize_vectors(model.encode_text(ids).float()))
-    for a, b in zip(out["fused"], out["lib"]):
-        assert bool(torch.isfinite(a).all()) and float((a - b).abs().max()) < 5e-6
+    for mode in ("block", "fused"):
+        for a, b in zip(out[mode], out["lib"]):
+            assert bool(torch.isfinite(a).all()) and float((a - b).abs().max()) < 5e-6, mode

@@ -540,6 +540,16 @@ def test_attention_split_output_equals_split_of_attention(hip, B, L, H, causal):
         assert torch.equal(attention_split(qkv, H, causal, scheme), split_operand(attention(qkv, H, causal), scheme)), scheme
 
 
+@pytest.mark.parametrize("B,L,H,causal", [(3, 50, 12, False), (5, 8, 8, True), (2, 77, 8, True), (2, 197, 12, False), (7, 33, 4, False)])
+def test_attention_tile_major_operand_equals_split_of_attention(hip, B, L, H, causal):
+    # lemon_attention_f16x3t: the tile-major operand of the hand-written GEMM holds exactly the fp16 split of lemon_attention_f32
+    from lemon_amd.ops import attention, attention_t, split_operand, unpack_act_t
+    g = torch.Generator().manual_seed(B * 100 + L)
+    qkv = torch.randn(B, L, 3 * H * 64, generator=g).cuda()
+    y3 = split_operand(attention(qkv, H, causal), "f16x3").view(B * L, 3, H * 64)
+    assert torch.equal(unpack_act_t(attention_t(qkv, H, causal), B * L, H * 64), y3[:, 0].float() + y3[:, 2].float() * (1.0 / 2048.0))
+
+
 def test_f16x3_parts_and_layernorm_split_equals_layernorm_then_split(hip):
     # lemon_split_f16x3: activation rows [hi | hi | lo 2^11], weight rows [hi | lo | hi 2^-11] of w * wscale, hi = RNE f16,
     # lo = the exact fp32 remainder; |v - hi - lo| <= 2^-23 |v| inside the fp16 range; beyond it the parts are not finite
