@@ -233,7 +233,7 @@ def bench_cifar(args, world, rank, dev):
     tb = math.gcd(math.gcd(args.n_train, args.n_val), args.n_test)
     while tb > 8 * args.encoder_batch and tb % 2 == 0:
         tb //= 2
-    text_batch = tb if 2 * args.encoder_batch <= tb <= 8 * args.encoder_batch else None
+    text_batch = tb if min(2 * args.encoder_batch, 4000) <= tb <= 8 * args.encoder_batch else None
     emb = Embedder(model, dev, batch_size=args.encoder_batch, text_dedup=args.text_dedup, text_batch_size=text_batch)
     data = make_cifar_like(args, cfg, rank, dev)
     data["train"]["n_total"] = args.n_train * world
