@@ -161,10 +161,47 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t(GemmParams p) {
     // ---- epilogue: the lane holds row m = l%32 of activation block i and columns n = 8 g + 4 (l/32) + e of weight block j ----
     const int l31 = lane & 31, h = lane >> 5;
     const int N = p.n;
+    if (EPI == 0) {
+        // fp32 row-major result (+ residual): in the accumulator layout a store instruction would touch 32 rows with 32 bytes
+        // each.  Every 32 x 32 accumulator tile therefore goes through a wave-private LDS patch (the ring is free now) and
+        // leaves as full 128-byte lines: 8 lanes per row, 8 rows per instruction, residual loads the same way.
+        __syncthreads();                                               // every wave is done with the ring
+        float *patch = reinterpret_cast<float *>(smem) + wave * (32 * 36);
+        const int prow = lane >> 3, pcol = 4 * (lane & 7);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = nt * TN + wn * 128 + j * 32 + pcol;
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias) b = *reinterpret_cast<const float4 *>(p.bias + n);
+#pragma unroll
+            for (int i = 0; i < IB; ++i) {
+                const int64_t m0 = (int64_t)mt * TM + wm * (IB * 32) + i * 32;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4 *>(patch + l31 * 36 + 8 * g + 4 * h) =
+                        make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+                float4 r[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int64_t m = m0 + 8 * q + prow;
+                    if (p.residual && m < p.m) r[q] = *reinterpret_cast<const float4 *>(p.residual + m * N + n);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t m = m0 + 8 * q + prow;
+                    const float4 v = *reinterpret_cast<const float4 *>(patch + (8 * q + prow) * 36 + pcol);
+                    if (m < p.m)
+                        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + m * N + n) =
+                            make_float4(p.alpha * v.x + b.x + r[q].x, p.alpha * v.y + b.y + r[q].y, p.alpha * v.z + b.z + r[q].z, p.alpha * v.w + b.w + r[q].w);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
         const int64_t m = (int64_t)mt * TM + wm * (IB * 32) + i * 32 + l31;
-        if (EPI == 0 && m >= p.m) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n0 = nt * TN + wn * 128 + j * 32 + 4 * h;
@@ -173,31 +210,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t(GemmParams p) {
                 const int n = n0 + 8 * g;
                 float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (p.bias) b = *reinterpret_cast<const float4 *>(p.bias + n);
-                float o[4] = {p.alpha * acc[j][i][4 * g] + b.x, p.alpha * acc[j][i][4 * g + 1] + b.y,
-                              p.alpha * acc[j][i][4 * g + 2] + b.z, p.alpha * acc[j][i][4 * g + 3] + b.w};
-                if (EPI == 0) {
-                    float *y = reinterpret_cast<float *>(p.out) + m * N + n;
-                    if (p.residual) {
-                        const float4 r = *reinterpret_cast<const float4 *>(p.residual + m * N + n);
-                        o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
-                    }
-                    *reinterpret_cast<float4 *>(y) = make_float4(o[0], o[1], o[2], o[3]);
-                } else {
-                    // the next GEMM's activation operand (its k = this n): lanes l and l+32 fill one 16-byte slot, a wave's store
-                    // instruction covers 512 contiguous bytes.  Rows >= m are computed from whatever the operand's pad rows
-                    // hold and land in the next operand's pad rows: never read into a stored result.
-                    h16x4 hi, lo;
+                const float o[4] = {p.alpha * acc[j][i][4 * g] + b.x, p.alpha * acc[j][i][4 * g + 1] + b.y,
+                                    p.alpha * acc[j][i][4 * g + 2] + b.z, p.alpha * acc[j][i][4 * g + 3] + b.w};
+                // the next GEMM's activation operand (its k = this n): lanes l and l+32 fill one 16-byte slot, a wave's store
+                // instruction covers 512 contiguous bytes.  Rows >= m are computed from whatever the operand's pad rows
+                // hold and land in the next operand's pad rows: never read into a stored result.
+                h16x4 hi, lo;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = o[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-o[e]));      // SiLU (v_exp_f32 / v_rcp_f32: 1 ulp each)
-                        unsigned short a_, b_, c_;
-                        split2h<false>(v, a_, b_, c_);
-                        hi[e] = __builtin_bit_cast(_Float16, a_); lo[e] = __builtin_bit_cast(_Float16, c_);
-                    }
-                    unsigned short *base = reinterpret_cast<unsigned short *>(p.out) + tiled_off(TM, m, n, 0, N);
-                    *reinterpret_cast<h16x4 *>(base) = hi;
-                    *reinterpret_cast<h16x4 *>(base + TM * 16) = lo;
+                for (int e = 0; e < 4; ++e) {
+                    const float v = o[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-o[e]));      // SiLU (v_exp_f32 / v_rcp_f32: 1 ulp each)
+                    unsigned short a_, b_, c_;
+                    split2h<false>(v, a_, b_, c_);
+                    hi[e] = __builtin_bit_cast(_Float16, a_); lo[e] = __builtin_bit_cast(_Float16, c_);
                 }
+                unsigned short *base = reinterpret_cast<unsigned short *>(p.out) + tiled_off(TM, m, n, 0, N);
+                *reinterpret_cast<h16x4 *>(base) = hi;
+                *reinterpret_cast<h16x4 *>(base + TM * 16) = lo;
             }
         }
     }
