@@ -30,6 +30,22 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0          # HBM3E spec peak (6.3 TB/s achievable)
 
 
+def pmc_summary(kernel_substr, fname="bench_default_pmc.csv"):
+    """{counter: row} of the longest-running launch group of a kernel in a COMMITTED PMC summary (profiles/rN/<fname>), + path."""
+    import csv
+    path = next((p for p in (os.path.join(ROOT, "profiles", r, fname) for r in ("r3", "r2", "r1")) if os.path.exists(p)), None)
+    if path is None:
+        return {}, None
+    best = {}
+    for r in csv.DictReader(open(path)):
+        if kernel_substr in r["kernel"] and int(r["grid"]) >= 256 * 256:
+            # (steady-state group: the most launches, then the longest)
+            key = (int(r["launches"]), float(r["dur_ms"]))
+            if r["counter"] not in best or key > best[r["counter"]][0]:
+                best[r["counter"]] = (key, r)
+    return {c: v[1] for c, v in best.items()}, os.path.relpath(path, ROOT)
+
+
 def pmc_traffic(kernel_substr):
     """(bytes, source): HBM-side bytes per launch of the dominant kernel from the COMMITTED rocprofv3 --pmc passes of
     this command (tools/gpu_profile.sh; FETCH_SIZE and WRITE_SIZE in separate runs, KB units, FETCH_SIZE doubled as
@@ -345,12 +361,15 @@ def bench_cifar(args, world, rank, dev):
         sec = prof["kernel_ms"] / 1e3
         tf = prof["algo_flops"] / sec / 1e12
         traffic, traffic_src = pmc_traffic("k_scan_f32")
+        pm_, _ = pmc_summary("k_scan_f32")
         line["roofline"] = {
             "kernel": "k_scan_f32" if info["algo"] == _lib.ALGO_F32_MFMA else "k_scan_bf16",
             "bound": "mfma", "achieved": tf,
             "peak": PEAK_F32_MFMA_TFLOPS if info["algo"] == _lib.ALGO_F32_MFMA else PEAK_BF16_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": tf / (PEAK_F32_MFMA_TFLOPS if info["algo"] == _lib.ALGO_F32_MFMA else PEAK_BF16_MFMA_TFLOPS),
             "traffic": traffic, "traffic_source": traffic_src, "launches": prof["launches"],
+            "mfma_busy_pmc": (float(pm_["SQ_VALU_MFMA_BUSY_CYCLES"]["value_KB"]) / (float(pm_["GRBM_GUI_ACTIVE"]["value_KB"]) / 8.0 * 1024.0)
+                              if "SQ_VALU_MFMA_BUSY_CYCLES" in pm_ and "GRBM_GUI_ACTIVE" in pm_ and info["algo"] == _lib.ALGO_F32_MFMA else None),
             "avg_launch_ms": prof["kernel_ms"] / prof["launches"],
             "text_side": {"distinct_queries": db.index_txt.last_search_info()["nq_distinct"], "launches": prof_txt["launches"],
                           "avg_launch_ms": prof_txt["kernel_ms"] / max(prof_txt["launches"], 1)},
@@ -536,6 +555,17 @@ def bench_knn(args, world, rank, dev):
                                         "note": "MODEL bytes (one DB stream per 128-query panel, SURVEY 8d), not measured "
                                                 "traffic: the kernel is MFMA-bound, `frac` above is the binding fraction"}},
     }
+    if not f32 and n == 1000000 and d == 768:
+        # counter figures of the steady-state chunk launch from the committed PMC passes of THIS command (tools/gpu_profile.sh):
+        # not a measurement of the current run, the source file is named
+        pm, src = pmc_summary("k_scan_bf16_qs2", "knn_1000000x768_pmc.csv")
+        if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+            line["roofline"]["traffic"] = (2.0 * float(pm["FETCH_SIZE"]["value_KB"]) + float(pm["WRITE_SIZE"]["value_KB"])) * 1024.0
+            line["roofline"]["traffic_source"] = src
+            line["roofline"]["traffic_note"] = ("per steady-state chunk launch (FETCH_SIZE x 2 + WRITE_SIZE; fabric reads served by the "
+                                                "Infinity Cache / L2 are counted): compare with avg_launch_ms, not with the whole job")
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in pm and "GRBM_GUI_ACTIVE" in pm:
+            line["roofline"]["mfma_busy_pmc"] = float(pm["SQ_VALU_MFMA_BUSY_CYCLES"]["value_KB"]) / (float(pm["GRBM_GUI_ACTIVE"]["value_KB"]) / 8.0 * 1024.0)
     if not f32:
         sus, src = sustained_bf16_peak()
         if sus:
