@@ -830,3 +830,28 @@ def test_hand_written_gemm_is_position_independent(hip):
     ht = ops.linear_t(ops.layer_norm_t(x, lw, lb), ops.pack_weight_t(w1, s1), 1000, 2048, 512, None, act="silu", alpha=1.0 / s1)
     y = ops.linear_t(ht, ops.pack_weight_t(w2, s2), 1000, 512, 2048, None, residual=x, alpha=1.0 / s2)
     assert bool((y == y[0]).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,k,n", [(70, 48, 256), (200, 16, 512), (129, 80, 256), (1000, 272, 768)])
+def test_hand_written_gemm_odd_k_step_counts(hip, m, k, n):
+    # k / 16 odd or 1: the two-steps-per-iteration main loop leaves through its middle; ring prologue shorter than the ring
+    from lemon_amd import ops
+    g = torch.Generator().manual_seed(m + k + n)
+    x = torch.randn(m, k, generator=g)
+    w, b = torch.randn(n, k, generator=g) / k ** 0.5, 0.1 * torch.randn(n, generator=g)
+    lw, lb = torch.ones(k), torch.zeros(k)
+    xn = torch.nn.functional.layer_norm(x.double(), (k,), lw.double(), lb.double(), 1e-5)
+    z = xn @ w.double().T + b.double()
+    ref = z * torch.sigmoid(z)
+    ws = ops.weight_scale_f16x3(w)
+    at = ops.layer_norm_t(x.cuda(), lw.cuda(), lb.cuda(), 1e-5)
+    ht = ops.linear_t(at, ops.pack_weight_t(w.cuda(), ws), m, n, k, b.cuda(), act="silu", alpha=1.0 / ws)
+    got = ops.unpack_act_t(ht, m, n).cpu().double()
+    assert float((got - ref).abs().max()) < 2e-5
+    # and the fp32 epilogue on the operand just produced (k' = n): y = h W2^T + x2
+    w2 = torch.randn(256, n, generator=g) / n ** 0.5
+    x2 = torch.randn(m, 256, generator=g)
+    ws2 = ops.weight_scale_f16x3(w2)
+    y = ops.linear_t(ht, ops.pack_weight_t(w2.cuda(), ws2), m, 256, n, None, residual=x2.cuda(), alpha=1.0 / ws2).cpu().double()
+    assert float((y - (ref @ w2.double().T + x2.double())).abs().max()) < 3e-5
