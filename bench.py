@@ -311,7 +311,9 @@ def bench_cifar(args, world, rank, dev):
                   "split EXACTLY into three bf16 parts, the six cross products of order <= 2 summed by one hipBLASLt bf16 GEMM with fp32 "
                   "accumulation (delivered error vs float64 at the fp32 GEMM's level, tests/test_gpu_parity.py); patch embedding / projections: lemon_linear_f32; "
                   "recorded solution per shape, bias / SiLU / residual epilogues; LEMON_GEMM = f32 | bf16x6 | f16x3 selects the mode",
-        "f16x3": "the four GEMMs of every transformer block (QKV, output projection, fc1, fc2): lemon_linear_f16x3 -- both fp32 operands "
+        "f16x3": "MLP of every block (LEMON_MLP=fused, default): hand-written split-fp16 GEMM gemm_f16x3.hip (tile-major operands, LDS-DMA ring; "
+                 "fc1's epilogue applies bias + QuickGELU + the fp16 split and stores fc2's operand); QKV, output projection, patch embedding "
+                 "(and the MLP under LEMON_MLP=lib): lemon_linear_f16x3 on hipBLASLt -- both fp32 operands "
                  "split into two fp16 parts (hi = f16(v), lo = the exact remainder kept to 11 bits: 22 bits + sign), weights pre-scaled by a "
                  "power of two, hi.hi + hi.lo + lo.hi summed by one hipBLASLt fp16 GEMM with fp32 accumulation (error vs float64 at the "
                  "fp32 GEMM's level, tests/test_gpu_parity.py); patch embedding / projections: lemon_linear_f32; recorded solution per "
