@@ -184,8 +184,22 @@ __global__ __launch_bounds__(576) void k_attention_hd64(const float *__restrict_
 // on the complete row (no running rescale) and K is dead by the time V is needed.  Half the LDS of the general kernel
 // (17 KB at TJ = 2): the CU holds six workgroups instead of four, which is what this latency-bound shape was short of
 // (MFMA pipe busy 0.40, 3.6 TB/s with four).
-template <int TJ, int SPLIT>
-__global__ __launch_bounds__(64 * TJ) void k_attention_hd64_short(const float *__restrict__ qkv, int L, int H, int causal,
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+// eight fp32 values -> fp16 hi and lo * 2^11 (split3.hpp: split2h): hi + lo 2^-11 carries 22 bits + sign of each value
+__device__ __forceinline__ void split8(const float *v, h16x8 &hi, h16x8 &lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 hh = (_Float16)v[e];
+        hi[e] = hh; lo[e] = (_Float16)((v[e] - (float)hh) * 2048.0f);
+    }
+}
+
+// F16: both products on the fp16 matrix cores as split products (hi.hi in one accumulator, lo.hi + hi.lo in a second one that
+// enters with 2^-11; the dropped lo.lo is 2^-22 of a product): the fp32 form is BOUND by v_mfma_f32_32x32x2_f32 -- 256 of them,
+// 64 cycles each, per wave = 437 us of matrix-pipe time per 131 000-token micro-batch, exactly what the kernel took --, the split
+// form needs 48 MFMAs of 32 cycles and leaves the kernel to its memory traffic.
+template <int TJ, int SPLIT, bool F16>
+__global__ __launch_bounds__(64 * TJ, 3) void k_attention_hd64_short(const float *__restrict__ qkv, int L, int H, int causal,
                                                                   float *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) float sKV[32 * TJ * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -248,22 +262,43 @@ __global__ __launch_bounds__(64 * TJ) void k_attention_hd64_short(const float *_
     // all score tiles of this lane's query: S^T tile tj = K[32tj.., :] Q^T (two accumulators per tile: even / odd k-steps,
     // so that consecutive MFMAs do not wait for each other)
     f32x16 s[TJ];
+    h16x8 qh[4], ql[4];                              // F16: the query's half row as four 8-k fragments, hi and lo parts
+    if (F16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) split8(q + 8 * u, qh[u], ql[u]);
+    }
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) {
         f32x16 sa, sb;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { sa[e] = 0.f; sb[e] = 0.f; }
         const float *krow = &sKV[(32 * tj + l31) * PITCH + 32 * h];
+        if (F16) {
+            // k-slot i of lane half h in step u is d = 32 h + 8 u + i for both operands; sa = hi.hi, sb = (lo.hi + hi.lo) 2^11
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float4 k4 = *reinterpret_cast<const float4 *>(krow + 4 * u);
-            sa = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, q[4 * u], sa, 0, 0, 0);
-            sb = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, q[4 * u + 1], sb, 0, 0, 0);
-            sa = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, q[4 * u + 2], sa, 0, 0, 0);
-            sb = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, q[4 * u + 3], sb, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+                const float4 k0 = *reinterpret_cast<const float4 *>(krow + 8 * u), k1 = *reinterpret_cast<const float4 *>(krow + 8 * u + 4);
+                const float kv[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+                h16x8 kh, kl;
+                split8(kv, kh, kl);
+                sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[u], sa, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[u], sb, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[u], sb, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[tj][e] = sa[e] + sb[e] * 0.00048828125f;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 k4 = *reinterpret_cast<const float4 *>(krow + 4 * u);
+                sa = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, q[4 * u], sa, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, q[4 * u + 1], sb, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, q[4 * u + 2], sa, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, q[4 * u + 3], sb, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[tj][e] = sa[e] + sb[e];
         }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[tj][e] = sa[e] + sb[e];
     }
     // mask (padding keys, causal), row maximum, exponentials, row sum
     const float c_exp = 0.125f * 1.44269504088896340736f;   // 1/sqrt(64) * log2(e)
@@ -299,14 +334,46 @@ __global__ __launch_bounds__(64 * TJ) void k_attention_hd64_short(const float *_
     f32x16 o0, o1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+    if (F16) {
+        // O^T = V^T P^T, 16 keys per step: k-slot i of lane half h in step t of key tile tj is key 32 tj + 16 t + 8 (i / 4) + 4 h
+        // + i % 4 -- exactly the accumulator elements 8 t .. 8 t + 7 the lane holds of P, and the same slots for V's fragments
+        f32x16 c0, c1;                                // the 2^11-scaled cross terms
 #pragma unroll
-    for (int tj = 0; tj < TJ; ++tj)
+        for (int e = 0; e < 16; ++e) { c0[e] = 0.f; c1[e] = 0.f; }
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const float *vrow = &sKV[(32 * tj + (m & 3) + 8 * (m >> 2) + 4 * h) * PITCH + l31];
-            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], s[tj][m], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], s[tj][m], o1, 0, 0, 0);
-        }
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float pv[8], v0[8], v1[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    pv[i] = s[tj][8 * t + i];
+                    const float *vrow = &sKV[(32 * tj + 16 * t + 8 * (i >> 2) + 4 * h + (i & 3)) * PITCH + l31];
+                    v0[i] = vrow[0]; v1[i] = vrow[32];
+                }
+                h16x8 ph, pl, vh, vl;
+                split8(pv, ph, pl);
+                split8(v0, vh, vl);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, c0, 0, 0, 0);
+                split8(v1, vh, vl);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o1, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, c1, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, c1, 0, 0, 0);
+            }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o0[e] += c0[e] * 0.00048828125f; o1[e] += c1[e] * 0.00048828125f; }
+    } else {
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const float *vrow = &sKV[(32 * tj + (m & 3) + 8 * (m >> 2) + 4 * h) * PITCH + l31];
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], s[tj][m], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], s[tj][m], o1, 0, 0, 0);
+            }
+    }
     // the output tile goes back through the LDS buffer (V is dead): 16 lanes then store one token's 256 B (or, SPLIT, the
     // six 128-B bf16 segments of it) instead of 32-B pieces of 32 different rows per store instruction
     __syncthreads();
@@ -359,8 +426,14 @@ static int attention_impl(const float *qkv_dev, int64_t batch, int seq_len, int 
     static const bool short_off = [] { const char *e = getenv("LEMON_ATTN_SHORT"); return e && e[0] == '0'; }();   // tuning knob
     const dim3 grid((unsigned)(batch * heads));
     if (tj <= 2 && !short_off) {
-        if (tj == 1) hipLaunchKernelGGL((k_attention_hd64_short<1, SPLIT>), grid, dim3(64), 0, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
-        else         hipLaunchKernelGGL((k_attention_hd64_short<2, SPLIT>), grid, dim3(128), 0, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
+        static const bool f16_off = [] { const char *e = getenv("LEMON_ATTN_F16"); return e && e[0] == '0'; }();      // A/B knob
+        if (f16_off) {
+            if (tj == 1) hipLaunchKernelGGL((k_attention_hd64_short<1, SPLIT, false>), grid, dim3(64), 0, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
+            else         hipLaunchKernelGGL((k_attention_hd64_short<2, SPLIT, false>), grid, dim3(128), 0, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
+        } else {
+            if (tj == 1) hipLaunchKernelGGL((k_attention_hd64_short<1, SPLIT, true>), grid, dim3(64), 0, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
+            else         hipLaunchKernelGGL((k_attention_hd64_short<2, SPLIT, true>), grid, dim3(128), 0, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
+        }
         LEMON_HIP_CHECK(hipGetLastError());
         return LEMON_OK;
     }
