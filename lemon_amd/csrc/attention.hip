@@ -29,9 +29,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int HD = 64;        // head dimension (every CLIP variant the reference loads: 768/12, 512/8, 1024/16)
 constexpr int PITCH = 68;     // LDS row pitch in floats
 
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+// eight fp32 values -> fp16 hi and lo * 2^11 (split3.hpp: split2h): hi + lo 2^-11 carries 22 bits + sign of each value
+__device__ __forceinline__ void split8(const float *v, h16x8 &hi, h16x8 &lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 hh = (_Float16)v[e];
+        hi[e] = hh; lo[e] = (_Float16)((v[e] - (float)hh) * 2048.0f);
+    }
+}
+
+// ... with lo itself (not scaled): the matrix pipe honours fp16 subnormals (tools/denorm_probe.py), so lo keeps an absolute
+// precision of 2^-25 and all three products can share ONE accumulator (no second tile, no 2^-11 fix-up): the form the
+// general kernel uses, whose register budget (nine waves per workgroup: 168) has no room for cross-term accumulators
+__device__ __forceinline__ void split8u(const float *v, h16x8 &hi, h16x8 &lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 hh = (_Float16)v[e];
+        hi[e] = hh; lo[e] = (_Float16)(v[e] - (float)hh);
+    }
+}
+
 // SPLIT 1: `out` is the [B*L, 6*H*64] bf16 activation operand of lemon_linear_bf16x6 (the fp32 result split 3-way at the
 // store); SPLIT 2: the [B*L, 3*H*64] fp16 operand of lemon_linear_f16x3
-template <int SPLIT>
+// F16: the two products as split products on the fp16 matrix cores (see k_attention_hd64_short)
+template <int SPLIT, bool F16>
 __global__ __launch_bounds__(576) void k_attention_hd64(const float *__restrict__ qkv, int L, int H, int causal,
                                                         float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -84,6 +106,11 @@ __global__ __launch_bounds__(576) void k_attention_hd64(const float *__restrict_
     f32x16 o0, o1;                                 // O^T tiles: output columns 0..31 and 32..63 of query qi
 #pragma unroll
     for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+    h16x8 qh[4], ql[4];
+    if (F16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) split8u(q + 8 * u, qh[u], ql[u]);
+    }
     float m_run = -INFINITY, l_run = 0.f;          // running max (raw dot units) and sum of this query
     const float c_exp = 0.125f * 1.44269504088896340736f;   // 1/sqrt(64) * log2(e)
 
@@ -94,13 +121,26 @@ __global__ __launch_bounds__(576) void k_attention_hd64(const float *__restrict_
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[e] = 0.f;
         const float *krow = &sK[(32 * tj + l31) * PITCH + 32 * h];
+        if (F16) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float4 k4 = *reinterpret_cast<const float4 *>(krow + 4 * u);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, q[4 * u], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, q[4 * u + 1], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, q[4 * u + 2], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, q[4 * u + 3], s, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+                const float4 k0 = *reinterpret_cast<const float4 *>(krow + 8 * u), k1 = *reinterpret_cast<const float4 *>(krow + 8 * u + 4);
+                const float kv[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+                h16x8 kh, kl;
+                split8u(kv, kh, kl);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[u], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[u], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[u], s, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 k4 = *reinterpret_cast<const float4 *>(krow + 4 * u);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, q[4 * u], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, q[4 * u + 1], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, q[4 * u + 2], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, q[4 * u + 3], s, 0, 0, 0);
+            }
         }
         // mask (padding keys, causal) and tile max
         float mt = -INFINITY;
@@ -115,9 +155,12 @@ __global__ __launch_bounds__(576) void k_attention_hd64(const float *__restrict_
         const float m_new = fmaxf(m_run, mt);      // finite from the first tile on (key 0 is visible to every query)
         const float alpha = exp2f((m_run - m_new) * c_exp);
         float lt = 0.f;
+        // (F16: the probabilities carry a factor 2^10 -- their unscaled lo parts then keep full relative precision down to
+        // p = 2^-12 -- which l_run carries as well and the final 1 / l_run removes)
+        const float pbias = F16 ? 10.0f : 0.0f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            s[e] = exp2f((s[e] - m_new) * c_exp);
+            s[e] = exp2f((s[e] - m_new) * c_exp + pbias);
             lt += s[e];
         }
         lt += __shfl_xor(lt, 32);
@@ -134,11 +177,34 @@ __global__ __launch_bounds__(576) void k_attention_hd64(const float *__restrict_
 #pragma unroll
         for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
         // O^T += V^T P^T : k-step m pairs keys (m&3) + 8(m>>2) + 4h of the tile, i.e. s[m] as it lies
+        if (F16) {
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const float *vrow = &sV[(32 * tj + (m & 3) + 8 * (m >> 2) + 4 * h) * PITCH + l31];
-            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], s[m], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], s[m], o1, 0, 0, 0);
+            for (int t = 0; t < 2; ++t) {              // 16 keys per step: slot i of lane half h = key 16 t + 8 (i / 4) + 4 h + i % 4 = s[8 t + i]
+                float pv[8], v0[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pv[i] = s[8 * t + i];
+                h16x8 ph, pl, vh, vl;
+                split8u(pv, ph, pl);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v0[i] = sV[(32 * tj + 16 * t + 8 * (i >> 2) + 4 * h + (i & 3)) * PITCH + l31];
+                split8u(v0, vh, vl);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o0, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o0, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o0, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v0[i] = sV[(32 * tj + 16 * t + 8 * (i >> 2) + 4 * h + (i & 3)) * PITCH + 32 + l31];
+                split8u(v0, vh, vl);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o1, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o1, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o1, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const float *vrow = &sV[(32 * tj + (m & 3) + 8 * (m >> 2) + 4 * h) * PITCH + l31];
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], s[m], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], s[m], o1, 0, 0, 0);
+            }
         }
     }
 
@@ -184,16 +250,6 @@ __global__ __launch_bounds__(576) void k_attention_hd64(const float *__restrict_
 // on the complete row (no running rescale) and K is dead by the time V is needed.  Half the LDS of the general kernel
 // (17 KB at TJ = 2): the CU holds six workgroups instead of four, which is what this latency-bound shape was short of
 // (MFMA pipe busy 0.40, 3.6 TB/s with four).
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-// eight fp32 values -> fp16 hi and lo * 2^11 (split3.hpp: split2h): hi + lo 2^-11 carries 22 bits + sign of each value
-__device__ __forceinline__ void split8(const float *v, h16x8 &hi, h16x8 &lo) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const _Float16 hh = (_Float16)v[e];
-        hi[e] = hh; lo[e] = (_Float16)((v[e] - (float)hh) * 2048.0f);
-    }
-}
-
 // F16: both products on the fp16 matrix cores as split products (hi.hi in one accumulator, lo.hi + hi.lo in a second one that
 // enters with 2^-11; the dropped lo.lo is 2^-22 of a product): the fp32 form is BOUND by v_mfma_f32_32x32x2_f32 -- 256 of them,
 // 64 cycles each, per wave = 437 us of matrix-pipe time per 131 000-token micro-batch, exactly what the kernel took --, the split
@@ -440,11 +496,15 @@ static int attention_impl(const float *qkv_dev, int64_t batch, int seq_len, int 
     const size_t lds = (size_t)2 * 32 * tj * PITCH * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attention_hd64<SPLIT>),
+        LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attention_hd64<SPLIT, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attention_hd64<SPLIT, false>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_attention_hd64<SPLIT>, grid, dim3(64 * tj), lds, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
+    static const bool f16_off_g = [] { const char *e = getenv("LEMON_ATTN_F16"); return e && e[0] == '0'; }();
+    if (f16_off_g) hipLaunchKernelGGL((k_attention_hd64<SPLIT, false>), grid, dim3(64 * tj), lds, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
+    else hipLaunchKernelGGL((k_attention_hd64<SPLIT, true>), grid, dim3(64 * tj), lds, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
     LEMON_HIP_CHECK(hipGetLastError());
     return LEMON_OK;
 }
