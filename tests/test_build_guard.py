@@ -44,6 +44,11 @@ def _kernel_meta(src):
     ("knn_bf16.hip", ["k_scan_bf16_qsILi12ELb0ELb0E", "k_scan_bf16_qsILi8ELb0ELb0E", "k_scan_bf16_qsILi4ELb0ELb0E",
                       "k_scan_bf16_qs2ILi12ELi16ELb0ELb0ELb1E", "k_scan_bf16_qs2ILi12ELi20ELb1ELb0ELb1E",
                       "k_scan_bf16_qs2ILi8ELi0ELb0ELb0ELb1E", "k_bf16_finalILb0ELb1E", "k_bf16_finalILb1ELb1E"]),
+    # the hand-written GEMM (asm LDS-DMA / ds_read / MFMA with pinned accumulators: two workgroups per CU need <= 256 registers)
+    # and the attention kernels (three waves per SIMD)
+    ("gemm_f16x3.hip", ["k_gemm_f16x3tILi0E", "k_gemm_f16x3tILi1E"]),
+    ("attention.hip", ["k_attention_hd64_shortILi2ELi2ELb1E", "k_attention_hd64_shortILi1ELi2ELb1E", "k_attention_hd64_shortILi2ELi0ELb1E",
+                       "k_attention_hd64ILi2ELb1E", "k_attention_hd64ILi0ELb1E"]),
 ])
 def test_scan_kernels_do_not_spill(src, must_be_clean):
     meta = _kernel_meta(src)
@@ -52,3 +57,7 @@ def test_scan_kernels_do_not_spill(src, must_be_clean):
         assert hits, f"{frag} not found among {sorted(meta)[:6]}..."
         for n in hits:
             assert meta[n]["vgpr_spill_count"] == 0 and meta[n]["private_segment_fixed_size"] == 0, (n, meta[n])
+            if "k_gemm_f16x3t" in n:
+                assert meta[n]["vgpr_count"] <= 256, (n, meta[n])          # 128 AccVGPRs + 128 VGPRs: two waves per SIMD
+            if "k_attention_hd64_short" in n:
+                assert meta[n]["vgpr_count"] <= 168, (n, meta[n])          # three waves per SIMD
