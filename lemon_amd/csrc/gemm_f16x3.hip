@@ -39,7 +39,10 @@ constexpr int IB = TM / 64;                             // 32-row activation blo
 constexpr int BLKA = TM * 32, BLKW = TN * 32;           // bytes of one segment of one k16 step: 4 KB, 8 KB
 constexpr int STAGE = 2 * BLKA + 2 * BLKW;              // 24 KB
 constexpr int NB = 3, LA = NB - 1;
-constexpr int GM = 32;                                  // m-tiles per super-block (= workgroups an XCD runs at a time / 2)
+#ifndef LEMON_GEMM_GM
+#define LEMON_GEMM_GM 32
+#endif
+constexpr int GM = LEMON_GEMM_GM;                       // m-tiles per super-block (32 = half the workgroups an XCD runs at a time; 16 / 64 measured no better)
 constexpr int DMA_PER_STAGE = BLKA / 2048 + 4;          // 1-KB instructions per wave and stage (2 + 4)
 
 struct GemmParams {
