@@ -127,13 +127,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t(GemmParams p) {
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) _Pragma("unroll") for (int i_ = 0; i_ < IB; ++i_) mfma(acc[j_][i_], wf[set][j_][1], af[set][i_][0]); \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) _Pragma("unroll") for (int i_ = 0; i_ < IB; ++i_) mfma(acc[j_][i_], wf[set][j_][2], af[set][i_][1]); \
     } while (0)
+    // the wait for a fragment set names its registers as in/out operands: hipcc cannot see that the ds_read asm statements
+    // deliver late, and must not move a use of these registers (the v_pk_mul_f16 above are ordinary code) in front of the wait
+#define WAIT_FRAGS(set)                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                         \
+                 : "+v"(af[set][0][0]), "+v"(af[set][0][1]), "+v"(af[set][1][0]), "+v"(af[set][1][1]),          \
+                   "+v"(wf[set][0][0]), "+v"(wf[set][0][1]), "+v"(wf[set][1][0]), "+v"(wf[set][1][1]),          \
+                   "+v"(wf[set][2][0]), "+v"(wf[set][2][1]), "+v"(wf[set][3][0]), "+v"(wf[set][3][1]) : : "memory")
+    static_assert(IB == 2, "WAIT_FRAGS lists two activation blocks");
     static_assert((LA - 1) * DMA_PER_STAGE == 6, "the counted wait below");
 #define WAIT_STAGE() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")      /* all but the youngest stage in flight have landed */
 #define PIN_ACC() do { _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) _Pragma("unroll") for (int i_ = 0; i_ < IB; ++i_) asm volatile("" : "+a"(acc[j_][i_])); } while (0)
     if (KS > 1) WAIT_STAGE(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     READ_FRAGS(0, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    WAIT_FRAGS(0);
     PIN_ACC();
     for (int t = 0; t < KS; t += 2) {
         PIN_ACC();          // (the loop-carried accumulators stay AccVGPRs: left alone hipcc homes them in VGPRs and copies them every step)
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t(GemmParams p) {
             READ_FRAGS(1, (t + 1) % NB);
         }
         DO_MFMAS(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WAIT_FRAGS(1);
         if (t + 1 >= KS) break;
         // ---- step t+1 (set 1) ----
         if (t + 1 + LA < KS) issue(t + 1 + LA, (t + 1 + LA) % NB);
@@ -155,8 +163,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t(GemmParams p) {
             READ_FRAGS(0, (t + 2) % NB);
         }
         DO_MFMAS(1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WAIT_FRAGS(0);
     }
+#undef WAIT_FRAGS
 #undef READ_FRAGS
 #undef DO_MFMAS
 #undef WAIT_STAGE
