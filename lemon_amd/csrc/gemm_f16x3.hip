@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cmath>
+#include <cstdlib>
+#include <mutex>
 
 #include "common.hpp"
 #include "split3.hpp"
@@ -243,6 +245,199 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t(GemmParams p) {
     }
 }
 
+// ---- the same GEMM on v_mfma_f32_16x16x32_f16 --------------------------------------------------------------------------
+// Same operands, same ring, same tile walk; what changes is the matrix instruction and with it the step: one MFMA now spans
+// k = 32, i.e. TWO k16 slots of the ring -- a lane's 16-byte fragment piece comes from the first slot for lanes 0-31 (k groups
+// 0, 1) and from the second for lanes 32-63 (k groups 2, 3), both inside the unchanged tile-major layout (a 16-row x 32-k
+// fragment = rows (b & 1) 16 .. +15 of a 32-row block, k halves of two consecutive k16 steps; every 16-lane read group still
+// covers 256 contiguous bytes: no bank conflicts).  Why: the board is power-limited on these GEMMs (MFMA-busy 0.55-0.6 at
+// 1.7-1.85 GHz, profiles/r3/encoder_mfma_pmc.csv) and the 16x16x32 form holds a higher clock than 32x32x16 at equal cycles per
+// flop (MI355X_MICROARCH.md, DVFS give-back item 7; tools/micro/mfma_peak.hip: 2 224 vs 1 875 MHz on random operands).
+// Per k32 step and wave (64 x 128 of the output = 4 x 8 accumulator tiles of 16 x 16: 128 AccVGPRs): 24 fragment reads
+// (A 4 blocks x hi, lo; W 8 blocks x hi, lo; in two batches: at most 15 LDS operations may be counted at once), 96 MFMAs; fragments are single-buffered (A 32 + W 64 registers; W_hi 2^-11 is
+// made per block right before its four MFMAs) -- the other workgroup of the CU covers a wave's read phase.  A ring of three k16
+// slots with two consumed per step needs the slots back as soon as they are read: barrier B (both slots landed, everyone's
+// DMA), the reads, barrier B' (everyone's reads done) behind the first weight block's MFMAs, then the DMAs of slots t+3, t+4
+// into the two positions just read, with the rest of the step's MFMAs (84 x 16 cycles, twice that wall with the partner
+// workgroup) to land.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma16(f32x4 &acc, const h16x8 &a, const h16x8 &b) {
+#ifdef LEMON_MFMA16_BUILTIN
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+#else
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+#endif
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int mt, nt;
+    {
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const int gm_n = (p.m_tiles + GM - 1) / GM;
+        const int blk = (q / GM) * 8 + xcd, pos = q % GM;
+        if (blk >= gm_n * p.n_tiles) return;
+        mt = (blk / p.n_tiles) * GM + pos; nt = blk % p.n_tiles;
+        if (mt >= p.m_tiles) return;
+    }
+    const int KS = p.ks;                                    // k16 slots: even (the host checks k % 32 == 0)
+    const char *a_src = p.at + (size_t)mt * KS * 2 * BLKA;
+    const char *w_src = p.wt + (size_t)nt * KS * 2 * BLKW;
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)smem;
+    const unsigned va = (unsigned)(wave * (BLKA / 2) + lane * 16), vw = (unsigned)(wave * (BLKW / 2) + lane * 16);
+    auto issue = [&](int ks, int slot) {
+        const char *as = a_src + (size_t)ks * 2 * BLKA, *ws = w_src + (size_t)ks * 2 * BLKW;
+        const unsigned la = lds0 + slot * STAGE + wave * (BLKA / 2), lw = lds0 + slot * STAGE + 2 * BLKA + wave * (BLKW / 2);
+#pragma unroll
+        for (int j = 0; j < BLKA / 2048; ++j) dma1k(as, va + j * 1024, la + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma1k(ws, vw + j * 1024, lw + j * 1024);
+    };
+    f32x4 acc[8][4];                                        // [weight block c of 16 n][activation block b of 16 m]
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[c][b][e] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < NB; ++s)
+        if (s < KS) issue(s, s);
+    // a lane's piece of a fragment: row r16 of the 16-row block, k group kg of the k32 step = k half (kg & 1) of slot (kg >> 1)
+    const int r16 = lane & 15, kg = lane >> 4;
+    const unsigned lane_off = (unsigned)((kg & 1) * 512 + r16 * 16);
+    const unsigned fa = lds0 + wm * (IB * 1024) + lane_off, fw = lds0 + 2 * BLKA + wn * 4096 + lane_off;
+    const bool upper = lane >= 32;
+    h16x8 af[4][2], wf[8][2];
+    static_assert(NB == 3 && DMA_PER_STAGE == 6, "the slot arithmetic and the counted waits below");
+#define PIN_ACC16() do { _Pragma("unroll") for (int c_ = 0; c_ < 8; ++c_) _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) asm volatile("" : "+a"(acc[c_][b_])); } while (0)
+#define MF_BLOCK(c)                                                                                              \
+    do {                                                                                                         \
+        _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) mfma16(acc[c][b_], wf[c][0], af[b_][0]);               \
+        /* W_hi 2^-11 (exact) is made HERE, four MFMAs ahead of its first use, and pinned to this point of the asm   \
+           sequence: the MFMAs are asm statements, so hipcc pads no wait states between a v_pk_mul_f16 and an MFMA   \
+           that reads its result -- placed right in front of it (where hipcc sinks the multiply if left alone) the   \
+           MFMA read the register before the multiply had written it (wrong his products in the first activation     \
+           block, seen on the GPU; tests/test_build_guard.py now checks the distance on the generated ISA) */        \
+        h16x8 ws_ = wf[c][0] * (_Float16)0.00048828125f;                                                         \
+        asm volatile("" : "+v"(ws_));                                                                            \
+        _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) mfma16(acc[c][b_], wf[c][1], af[b_][0]);               \
+        _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) mfma16(acc[c][b_], ws_, af[b_][1]);                    \
+    } while (0)
+    int p0 = 0, p1 = 1;                                     // ring positions of slots t, t+1
+    PIN_ACC16();
+    for (int t = 0; t < KS; t += 2) {
+        PIN_ACC16();
+        // slots t and t+1 have landed (this wave's share; the barrier makes it everyone's): the only younger DMAs are slot t+2's
+        if (t + 2 < KS) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned sb = (unsigned)((upper ? p1 : p0) * STAGE);
+        const unsigned pa = fa + sb, pw = fw + sb;
+        // LGKM_CNT is a 4-bit counter: never more than 15 LDS reads in flight, or the counted waits below read a wrapped count
+        // (seen: 24 reads issued at once -> `lgkmcnt(14)` fell through with the fragments still on their way).  Two batches:
+        // 14 reads (activations + weight blocks 0-2), wait for the first ten, then the other ten behind at most four.
+#pragma unroll
+        for (int b = 0; b < 4; ++b) af[b][0] = lds128(pa, (b >> 1) * 1024 + (b & 1) * 256);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) af[b][1] = lds128(pa, BLKA + (b >> 1) * 1024 + (b & 1) * 256);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            wf[c][0] = lds128(pw, (c >> 1) * 1024 + (c & 1) * 256);
+            wf[c][1] = lds128(pw, BLKW + (c >> 1) * 1024 + (c & 1) * 256);
+        }
+        // the activation fragments and weight block 0 (LDS returns in order).  As in the 32x32 kernel the waits name the
+        // registers they guard, so that no compiler-scheduled use can move in front of them.
+        asm volatile("s_waitcnt lgkmcnt(4)"
+                     : "+v"(af[0][0]), "+v"(af[1][0]), "+v"(af[2][0]), "+v"(af[3][0]), "+v"(af[0][1]), "+v"(af[1][1]),
+                       "+v"(af[2][1]), "+v"(af[3][1]), "+v"(wf[0][0]), "+v"(wf[0][1]) : : "memory");
+#pragma unroll
+        for (int c = 3; c < 8; ++c) {
+            wf[c][0] = lds128(pw, (c >> 1) * 1024 + (c & 1) * 256);
+            wf[c][1] = lds128(pw, BLKW + (c >> 1) * 1024 + (c & 1) * 256);
+        }
+        MF_BLOCK(0);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(wf[2][0]), "+v"(wf[2][1]), "+v"(wf[3][0]), "+v"(wf[3][1]), "+v"(wf[4][0]),
+                       "+v"(wf[4][1]), "+v"(wf[5][0]), "+v"(wf[5][1]), "+v"(wf[6][0]), "+v"(wf[6][1]), "+v"(wf[7][0]), "+v"(wf[7][1]) : : "memory");
+        __builtin_amdgcn_s_barrier();                       // B': every wave has read both slots
+        if (t + 3 < KS) issue(t + 3, p0);
+        if (t + 4 < KS) issue(t + 4, p1);
+        MF_BLOCK(1); MF_BLOCK(2); MF_BLOCK(3); MF_BLOCK(4); MF_BLOCK(5); MF_BLOCK(6); MF_BLOCK(7);
+        p0 = p0 == 0 ? 2 : p0 - 1;                          // (p + 2) mod 3
+        p1 = p1 == 0 ? 2 : p1 - 1;
+    }
+#undef MF_BLOCK
+#undef PIN_ACC16
+    // ---- epilogue: the lane holds row m = r16 of activation block b and columns n = 4 kg + e of weight block c ----
+    const int N = p.n;
+    if (EPI == 0) {
+        // fp32 row-major (+ residual) in full 128-byte lines: 2 x 2 accumulator tiles (32 m x 32 n) per pass through the
+        // wave-private LDS patch (the ring is free: every wave's reads ended before the last B')
+        float *patch = reinterpret_cast<float *>(smem) + wave * (32 * 36);
+        const int prow = lane >> 3, pcol = 4 * (lane & 7);
+#pragma unroll
+        for (int cp = 0; cp < 4; ++cp) {
+            const int n = nt * TN + wn * 128 + cp * 32 + pcol;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias) bv = *reinterpret_cast<const float4 *>(p.bias + n);
+#pragma unroll
+            for (int bp = 0; bp < 2; ++bp) {
+                const int64_t m0 = (int64_t)mt * TM + wm * (IB * 32) + bp * 32;
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                    for (int bi = 0; bi < 2; ++bi) {
+                        const f32x4 a = acc[2 * cp + ci][2 * bp + bi];
+                        *reinterpret_cast<float4 *>(patch + (bi * 16 + r16) * 36 + ci * 16 + 4 * kg) = make_float4(a[0], a[1], a[2], a[3]);
+                    }
+                float4 r[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int64_t m = m0 + 8 * q + prow;
+                    if (p.residual && m < p.m) r[q] = *reinterpret_cast<const float4 *>(p.residual + m * N + n);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t m = m0 + 8 * q + prow;
+                    const float4 v = *reinterpret_cast<const float4 *>(patch + (8 * q + prow) * 36 + pcol);
+                    if (m < p.m)
+                        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + m * N + n) =
+                            make_float4(p.alpha * v.x + bv.x + r[q].x, p.alpha * v.y + bv.y + r[q].y, p.alpha * v.z + bv.z + r[q].z, p.alpha * v.w + bv.w + r[q].w);
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int64_t m = (int64_t)mt * TM + wm * (IB * 32) + b * 16 + r16;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int n = nt * TN + wn * 128 + c * 16 + 4 * kg;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias) bv = *reinterpret_cast<const float4 *>(p.bias + n);
+            const float o[4] = {p.alpha * acc[c][b][0] + bv.x, p.alpha * acc[c][b][1] + bv.y, p.alpha * acc[c][b][2] + bv.z, p.alpha * acc[c][b][3] + bv.w};
+            // the next GEMM's activation operand (its k = this n): the lane's four values are half a 16-byte slot, a wave's
+            // store instruction covers two runs of 256 contiguous bytes
+            h16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = o[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-o[e]));
+                unsigned short a_, b_, c_;
+                split2h<false>(v, a_, b_, c_);
+                hi[e] = __builtin_bit_cast(_Float16, a_); lo[e] = __builtin_bit_cast(_Float16, c_);
+            }
+            unsigned short *base = reinterpret_cast<unsigned short *>(p.out) + tiled_off(TM, m, n, 0, N);
+            *reinterpret_cast<h16x4 *>(base) = hi;
+            *reinterpret_cast<h16x4 *>(base + TM * 16) = lo;
+        }
+    }
+}
+
 // fp32 [n, k] weight -> tile-major fp16 pairs of w * wscale (one thread per 8 consecutive k)
 __global__ __launch_bounds__(256) void k_pack_weight_t(const float *__restrict__ w, int n, int k, float wscale, unsigned short *__restrict__ wt) {
     const int nch = k >> 3;
@@ -262,6 +457,19 @@ __global__ __launch_bounds__(256) void k_unpack_act_t(const unsigned short *__re
     const int c = (int)(t - r * k);
     const float hi = f16_val(at[tiled_off(TILE_A_ROWS, r, c, 0, k)]), lo = f16_val(at[tiled_off(TILE_A_ROWS, r, c, 1, k)]);
     y[t] = hi + lo * 0.00048828125f;
+}
+
+// ---- host-side state of the launcher ----
+constexpr int MAX_DEVICES = 64;
+std::mutex g_attr_mu;
+bool g_attr_set[MAX_DEVICES] = {};
+int g_mfma_shape = 0;                  // 0: not decided yet ($LEMON_GEMM_MFMA, default 16); tools/micro sets it directly
+int mfma_shape() {
+    if (g_mfma_shape == 0) {
+        const char *e = getenv("LEMON_GEMM_MFMA");
+        g_mfma_shape = (e && atoi(e) == 32) ? 32 : 16;
+    }
+    return g_mfma_shape;
 }
 
 }  // namespace
@@ -305,14 +513,30 @@ extern "C" int lemon_linear_f16x3t(const uint16_t *at_dev, const uint16_t *wt_de
     const int64_t grid = ((blocks + 7) / 8) * GM * 8;
     LEMON_REQUIRE(grid < ((int64_t)1 << 31), "grid size");
     const size_t lds = (size_t)NB * STAGE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    // the 72 KB of dynamic LDS need the attribute on every DEVICE this process launches on (it is per device, not per process)
+    int dev = 0;
+    LEMON_HIP_CHECK(hipGetDevice(&dev));
+    LEMON_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "device index");
+    {
+        std::lock_guard<std::mutex> lock(g_attr_mu);
+        if (!g_attr_set[dev]) {
+            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            g_attr_set[dev] = true;
+        }
     }
-    if (out_operand) hipLaunchKernelGGL(k_gemm_f16x3t<1>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
-    else hipLaunchKernelGGL(k_gemm_f16x3t<0>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+    // matrix instruction: 16x16x32 where the k extent allows whole k32 steps (every tower width does), else 32x32x16;
+    // LEMON_GEMM_MFMA=32 forces the latter (A/B runs)
+    const bool mf16 = mfma_shape() == 16 && p.ks % 2 == 0;
+    if (mf16) {
+        if (out_operand) hipLaunchKernelGGL(k_gemm_f16x3t16<1>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+        else hipLaunchKernelGGL(k_gemm_f16x3t16<0>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+    } else {
+        if (out_operand) hipLaunchKernelGGL(k_gemm_f16x3t<1>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+        else hipLaunchKernelGGL(k_gemm_f16x3t<0>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+    }
     LEMON_HIP_CHECK(hipGetLastError());
     return LEMON_OK;
 }
