@@ -54,8 +54,23 @@ struct GemmParams {
     void *out;                 // EPI 0: fp32 [m, n]; EPI 1: tile-major activation operand of the next GEMM (its k = n)
     int64_t m;
     int n, ks, m_tiles, n_tiles;
+    int gm, gn;                // super-block of the tile walk: gm m-tiles x gn n-tiles per XCD at a time
     float alpha;
 };
+
+// Tile walk.  Consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2); an XCD works through
+// super-blocks of gm x gn tiles, m fastest: the workgroups it runs at a time (2 per CU = 64) then share gm activation tile
+// rows and gn weight tile columns instead of streaming one of the two operands once per tile.
+__device__ __forceinline__ bool tile_of_workgroup(const GemmParams &p, int &mt, int &nt) {
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int per = p.gm * p.gn;
+    const int gm_n = (p.m_tiles + p.gm - 1) / p.gm, gn_n = (p.n_tiles + p.gn - 1) / p.gn;
+    const int blk = (q / per) * 8 + xcd, pos = q % per;
+    if (blk >= gm_n * gn_n) return false;
+    mt = (blk / gn_n) * p.gm + pos % p.gm;
+    nt = (blk % gn_n) * p.gn + pos / p.gm;
+    return mt < p.m_tiles && nt < p.n_tiles;
+}
 
 __device__ __forceinline__ void mfma(f32x16 &acc, const h16x8 &a, const h16x8 &b) {
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
@@ -77,14 +92,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     int mt, nt;
-    {   // consecutive workgroup ids go round-robin over the 8 XCDs; an XCD walks super-blocks of GM m-tiles x 1 n-tile
-        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-        const int gm_n = (p.m_tiles + GM - 1) / GM;
-        const int blk = (q / GM) * 8 + xcd, pos = q % GM;
-        if (blk >= gm_n * p.n_tiles) return;
-        mt = (blk / p.n_tiles) * GM + pos; nt = blk % p.n_tiles;
-        if (mt >= p.m_tiles) return;
-    }
+    if (!tile_of_workgroup(p, mt, nt)) return;
     const int KS = p.ks;
     const char *a_src = p.at + (size_t)mt * KS * 2 * BLKA;
     const char *w_src = p.wt + (size_t)nt * KS * 2 * BLKW;
@@ -275,14 +283,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     int mt, nt;
-    {
-        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-        const int gm_n = (p.m_tiles + GM - 1) / GM;
-        const int blk = (q / GM) * 8 + xcd, pos = q % GM;
-        if (blk >= gm_n * p.n_tiles) return;
-        mt = (blk / p.n_tiles) * GM + pos; nt = blk % p.n_tiles;
-        if (mt >= p.m_tiles) return;
-    }
+    if (!tile_of_workgroup(p, mt, nt)) return;
     const int KS = p.ks;                                    // k16 slots: even (the host checks k % 32 == 0)
     const char *a_src = p.at + (size_t)mt * KS * 2 * BLKA;
     const char *w_src = p.wt + (size_t)nt * KS * 2 * BLKW;
@@ -463,7 +464,16 @@ __global__ __launch_bounds__(256) void k_unpack_act_t(const unsigned short *__re
 constexpr int MAX_DEVICES = 64;
 std::mutex g_attr_mu;
 bool g_attr_set[MAX_DEVICES] = {};
+int g_gm = 0, g_gn = 0;                // tile-walk override (tools/micro); 0: the defaults
 int g_mfma_shape = 0;                  // 0: not decided yet ($LEMON_GEMM_MFMA, default 16); tools/micro sets it directly
+void walk_override() {
+    static bool read = false;
+    if (read) return;
+    read = true;
+    const char *e = getenv("LEMON_GEMM_WALK");
+    int a = 0, b = 0;
+    if (e && sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && a <= 1024 && b <= 64) { g_gm = a; g_gn = b; }
+}
 int mfma_shape() {
     if (g_mfma_shape == 0) {
         const char *e = getenv("LEMON_GEMM_MFMA");
@@ -509,8 +519,20 @@ extern "C" int lemon_linear_f16x3t(const uint16_t *at_dev, const uint16_t *wt_de
     p.at = reinterpret_cast<const char *>(at_dev); p.wt = reinterpret_cast<const char *>(wt_dev);
     p.bias = bias_dev; p.residual = residual_dev; p.out = out_dev;
     p.m = m; p.n = n; p.ks = k / 16; p.m_tiles = (int)((m + TM - 1) / TM); p.n_tiles = n / TN; p.alpha = alpha;
-    const int64_t blocks = (int64_t)((p.m_tiles + GM - 1) / GM) * p.n_tiles;
-    const int64_t grid = ((blocks + 7) / 8) * GM * 8;
+    // super-block of the tile walk: gn = the largest divisor of the n-tile count up to 4 (a gn that does not divide it leaves
+    // every other XCD with half-empty super-blocks: +25 % time measured), gm so that an XCD's 64 resident workgroups cover one
+    // or two super-blocks.  Measured against 32 x 1 at the tower shapes (tools/micro/gemm_ab.hip walk): -1 ... -3 %; the
+    // operand re-fetches this saves (FETCH_SIZE 5.0 GB for fc1 at 32 x 1: the activations once per weight tile column) are
+    // served by the Infinity Cache either way.  LEMON_GEMM_WALK=gm,gn overrides.
+    walk_override();
+    if (g_gm > 0) { p.gm = g_gm; p.gn = g_gn > 0 ? g_gn : 1; }
+    else {
+        p.gn = p.n_tiles % 4 == 0 ? 4 : p.n_tiles % 3 == 0 ? 3 : p.n_tiles % 2 == 0 ? 2 : 1;
+        p.gm = p.gn == 1 ? GM : p.gn == 3 ? 8 : 16;
+    }
+    if (p.gn > p.n_tiles) p.gn = p.n_tiles;
+    const int64_t blocks = (int64_t)((p.m_tiles + p.gm - 1) / p.gm) * ((p.n_tiles + p.gn - 1) / p.gn);
+    const int64_t grid = ((blocks + 7) / 8) * p.gm * p.gn * 8;
     LEMON_REQUIRE(grid < ((int64_t)1 << 31), "grid size");
     const size_t lds = (size_t)NB * STAGE;
     // the 72 KB of dynamic LDS need the attribute on every DEVICE this process launches on (it is per device, not per process)

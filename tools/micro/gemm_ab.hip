@@ -86,6 +86,9 @@ struct Shape { const char *name; int m, n, k, epi; };
 
 int main(int argc, char **argv) {
     if (argc > 1 && !strcmp(argv[1], "debug")) { debug_run(32); debug_run(64); debug_run(128); return 0; }
+    const bool walk = argc > 1 && !strcmp(argv[1], "walk");
+    if (walk) { --argc; ++argv; }
+    if (getenv("GEMM_GM")) { g_gm = atoi(getenv("GEMM_GM")); g_gn = atoi(getenv("GEMM_GN") ? getenv("GEMM_GN") : "1"); }
     const int rounds = argc > 1 ? atoi(argv[1]) : 7, reps = argc > 2 ? atoi(argv[2]) : 10;
     const int M = argc > 3 ? atoi(argv[3]) : 131000;
     const Shape shapes[] = {{"fc1 (SiLU -> operand)", M, 3072, 768, 1}, {"fc2 (+residual)", M, 768, 3072, 0},
@@ -119,6 +122,32 @@ int main(int argc, char **argv) {
             LCHECK(lemon_linear_f16x3t(at, wt, bias, s.epi ? nullptr : res, s.m, s.n, s.k, alpha, s.epi ? LEMON_ACT_SILU : LEMON_ACT_NONE,
                                        s.epi, out[v], nullptr));
         };
+        if (walk) {
+            // tile-walk sweep of the 16x16x32 kernel: interleaved rounds over the (gm, gn) super-block shapes
+            const int nt_ = s.n / 256;
+            const int cfg[][2] = {{32, 1}, {16, 2}, {16, 4}, {8, 8}, {16, nt_}, {8, nt_}, {32, nt_}, {4, nt_}};
+            const int ncfg = sizeof cfg / sizeof cfg[0];
+            std::vector<std::vector<float>> tt(ncfg);
+            for (int r = 0; r < rounds; ++r)
+                for (int c = 0; c < ncfg; ++c) {
+                    g_gm = cfg[c][0]; g_gn = cfg[c][1];
+                    run(1);
+                    CHECK(hipEventRecord(e0));
+                    for (int i = 0; i < reps; ++i) run(1);
+                    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+                    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                    tt[c].push_back(ms / reps * 1e3f);
+                }
+            for (int c = 0; c < ncfg; ++c) {
+                std::sort(tt[c].begin(), tt[c].end());
+                printf("%-24s m=%d n=%d k=%d  walk gm=%2d gn=%2d: median %.1f us (%.0f TFLOP/s fp16) min %.1f us\n", s.name, s.m, s.n, s.k, cfg[c][0],
+                       cfg[c][1], tt[c][tt[c].size() / 2], 2.0 * s.m * (double)s.n * 3.0 * s.k / (tt[c][tt[c].size() / 2] * 1e-6) / 1e12, tt[c][0]);
+            }
+            g_gm = g_gn = 0;
+            fflush(stdout);
+            hipFree(x); hipFree(w); hipFree(bias); hipFree(res); hipFree(at); hipFree(wt); hipFree(out[0]); hipFree(out[1]);
+            continue;
+        }
         run(0); run(1);
         CHECK(hipDeviceSynchronize());
         // ---- check both against float64 on sampled outputs ----
