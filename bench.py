@@ -68,12 +68,53 @@ def pmc_traffic(kernel_substr):
     return (2.0 * float(best["FETCH_SIZE"]["value_KB"]) + float(best["WRITE_SIZE"]["value_KB"])) * 1024.0, os.path.relpath(path, ROOT)
 
 
+def hbm_scan_model_object(panel, achieved_gbs):
+    """SURVEY 8d's scan-model bytes (one DB stream per `panel`-query panel) over the kernel time.  The kernels are MFMA-bound
+    and keep the DB tiles in LDS / L2 across many more queries than one panel, so the MODEL rate can exceed the HBM peak: it is
+    then reported as `model_over_peak` (a statement about the model, not a bandwidth the chip delivered) and `frac` is left out."""
+    o = {"B": panel, "achieved_GBs": achieved_gbs, "peak_GBs": PEAK_HBM_GBS,
+         "note": "MODEL bytes, not measured traffic; the binding fraction is the MFMA one"}
+    if achieved_gbs <= PEAK_HBM_GBS:
+        o["frac"] = achieved_gbs / PEAK_HBM_GBS
+    else:
+        o["model_over_peak"] = achieved_gbs / PEAK_HBM_GBS
+    return o
+
+
+hbm_model_object = hbm_scan_model_object
+
+
+def pmc_gemm_summary():
+    """({traffic, mfma_busy, clock_GHz}, source) of the hand-written GEMM's longest-running launch group in the committed PMC
+    summary of the headline command (profiles/rN/encoder_gemm_pmc.csv, tools/gpu_profile.sh): FETCH_SIZE x 2 + WRITE_SIZE bytes
+    per launch, MFMA-busy fraction and shader clock.  Not a measurement of the current run."""
+    import csv
+    path = next((p for p in (os.path.join(ROOT, "profiles", r, "encoder_gemm_pmc.csv") for r in ("r4",)) if os.path.exists(p)), None)
+    if path is None:
+        return {}, None
+    best = {}
+    for r in csv.DictReader(open(path)):
+        if "k_gemm_f16x3t" in r["kernel"]:
+            key = float(r["dur_ms"]) * int(r["launches"])
+            if r["counter"] not in best or key > best[r["counter"]][0]:
+                best[r["counter"]] = (key, r)
+    g = {c: v[1] for c, v in best.items()}
+    out = {}
+    if "FETCH_SIZE" in g and "WRITE_SIZE" in g:
+        out["traffic"] = (2.0 * float(g["FETCH_SIZE"]["value_KB"]) + float(g["WRITE_SIZE"]["value_KB"])) * 1024.0
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in g and "GRBM_GUI_ACTIVE" in g:
+        act = float(g["GRBM_GUI_ACTIVE"]["value_KB"])
+        out["mfma_busy"] = float(g["SQ_VALU_MFMA_BUSY_CYCLES"]["value_KB"]) / (act / 8.0 * 1024.0)
+        out["clock_GHz"] = act / 8.0 / (float(g["GRBM_GUI_ACTIVE"]["dur_ms"]) * 1e6)
+    return out, os.path.relpath(path, ROOT)
+
+
 def sustained_bf16_peak():
     """(TFLOP/s, source): what bf16 MFMAs on RANDOM register operands sustain on this board with no memory traffic at all
     (tools/micro/mfma_peak.hip; the board's power management lowers the shader clock), read from the COMMITTED output of
     that micro-benchmark -- context for the bf16 scan's `frac` of the data-sheet peak, not a measurement of this run."""
     import re
-    path = next((p for p in (os.path.join(ROOT, "profiles", r, "micro_mfma_peak.txt") for r in ("r3", "r2")) if os.path.exists(p)), None)
+    path = next((p for p in (os.path.join(ROOT, "profiles", r, "micro_mfma_peak.txt") for r in ("r4", "r3", "r2")) if os.path.exists(p)), None)
     if path is None:
         return None, None
     for ln in open(path):
@@ -111,6 +152,9 @@ def parse():
     ap.add_argument("--cpu_sample_queries", type=int, default=2048)
     ap.add_argument("--no_knn_1m", action="store_true",
                     help="skip the extra 1M x 768 self-join object (`knn_1m`) the N=1 headline line carries")
+    ap.add_argument("--rccl_world1", action="store_true",
+                    help="N = 1 only: initialise a one-rank RCCL process group and send the DB all-gathers through ncclAllGather anyway "
+                         "(the line then carries `exchange`)")
     ap.add_argument("--knn_cpu_queries", type=int, default=10000,
                     help="query slice of the kNN workload's CPU baseline (BASELINE.md 3.5: 10 000 queries against the full DB)")
     return ap.parse_args()
@@ -122,15 +166,20 @@ def launch_ranks(args):
     subprocesses with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what torch.distributed.run sets)."""
     import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # the rendezvous port is HANDED to rank 0 as an open listening socket (torch's TCPStore takes `master_listen_fd`): no
+    # bind-close-reuse window in which another process could take the port
+    lsock, port = open_rendezvous_socket()
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env["LEMON_MASTER_HANDOFF"] = "1"
+        if r == 0:
+            env["LEMON_MASTER_LISTEN_FD"] = str(lsock.fileno())
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      pass_fds=(lsock.fileno(),) if r == 0 else ()))
+    lsock.close()                                # rank 0 owns the listening socket now
     # rank 0's line is read by a thread (its pipe must be drained while we poll); every child is polled, and the first
     # non-zero exit terminates the others -- a rank that dies at start-up must not leave the rest in the rendezvous
     import threading
@@ -163,6 +212,41 @@ def launch_ranks(args):
     return 0
 
 
+def rendezvous_store(rank, world):
+    """The TCPStore of this rank's process group, or None for torch's default env:// rendezvous (what torch.distributed.run
+    sets up).  Under bench.py's own launcher (LEMON_MASTER_HANDOFF=1) rank 0 takes over the launcher's LISTENING socket
+    (LEMON_MASTER_LISTEN_FD) and the other ranks connect to its port; a one-rank group without MASTER_PORT lets the OS pick."""
+    import datetime
+    import torch.distributed as dist
+    fd = os.environ.pop("LEMON_MASTER_LISTEN_FD", None)
+    if world == 1 and "MASTER_PORT" not in os.environ:
+        return dist.TCPStore("127.0.0.1", 0, 1, is_master=True, timeout=datetime.timedelta(seconds=120))
+    if os.environ.get("LEMON_MASTER_HANDOFF") != "1":
+        return None
+    port = int(os.environ["MASTER_PORT"])
+    if rank == 0:
+        if fd is not None:
+            try:
+                return dist.TCPStore("127.0.0.1", port, world, is_master=True, timeout=datetime.timedelta(seconds=300),
+                                     master_listen_fd=int(fd), use_libuv=False)
+            except Exception as e:                 # a torch without master_listen_fd: bind the port ourselves
+                print(f"bench.py: listen-socket hand-off failed ({e!r}); binding MASTER_PORT directly", file=sys.stderr)
+                os.close(int(fd))
+        return dist.TCPStore("127.0.0.1", port, world, is_master=True, timeout=datetime.timedelta(seconds=300), use_libuv=False)
+    return dist.TCPStore("127.0.0.1", port, world, is_master=False, timeout=datetime.timedelta(seconds=300), use_libuv=False)
+
+
+def open_rendezvous_socket():
+    """(listening socket, port) for rank 0 to inherit: bound and listening BEFORE any rank starts."""
+    import socket
+    lsock = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    lsock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    lsock.bind(("127.0.0.1", 0))
+    lsock.listen(128)
+    lsock.set_inheritable(True)
+    return lsock, lsock.getsockname()[1]
+
+
 def init_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -173,14 +257,20 @@ def init_dist(args):
         raise SystemExit("bench.py needs a HIP device (torch.cuda.is_available() is False)")
     local = local % max(torch.cuda.device_count(), 1)     # rehearsals: several ranks may share one card
     torch.cuda.set_device(local)
-    if world > 1:
+    # --rccl_world1: a ONE-rank RCCL group, with the all-gathers forced through the collective (pipeline.all_gather_rows):
+    # the exchange step of SURVEY 8e executes on the one-GPU box (ncclCommInitRank, ncclAllGather, the `exchange` report)
+    if world > 1 or args.rccl_world1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("LEMON_DIST_BACKEND", "nccl")    # nccl = RCCL; "gloo" only to rehearse on one card
+        store = rendezvous_store(rank, world)
+        kw = dict(store=store) if store is not None else {}
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), **kw)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        if args.rccl_world1:
+            os.environ["LEMON_FORCE_ALLGATHER"] = "1"
     return world, rank, torch.device("cuda", local)
 
 
@@ -271,25 +361,32 @@ def bench_cifar(args, world, rank, dev):
         p = db.index_txt.profile_read()
         prof_txt["launches"] += p["launches"]; prof_txt["kernel_ms"] += p["kernel_ms"]
 
-    glog = GatherLog() if world > 1 else None   # HIP events around every all-gather of the timed region (read afterwards)
+    glog = GatherLog() if (world > 1 or args.rccl_world1) else None   # HIP events around every all-gather of the timed region (read afterwards)
 
     def step(timers=None, events=False):
         return run_hot_path(emb, data, k=args.knn_k, dist_type=args.dist_type, hparams=FIXED_HPARAMS,
                             world_size=world, rank=rank, algo=algo, timers=timers, profile_index=events,
                             gather_log=glog if events else None)
 
+    from lemon_amd import ops as _ops
     for _ in range(args.warmup):
         step()
     barrier_sync(world, dev)
+    # HIP events bracket every launch of the step's dominant kernel (the hand-written split GEMM) and every scan-kernel launch
+    # of the timed region: recorded on the launch stream inside the library, read back only after the region ends
+    _ops.gemm_profiling(True)
     t0 = time.perf_counter()
     timed = []
+    gemm_prof = {"launches": 0, "kernel_ms": 0.0, "flops": 0.0}
     for _ in range(args.steps):
-        # HIP events bracket every scan-kernel launch of the timed region (recorded on the launch
-        # stream inside the library; read back only after the region ends)
         recs, db = step(events=True)
         timed.append(db)
     barrier_sync(world, dev)
     elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+    gp = _ops.gemm_profile_read()
+    _ops.gemm_profiling(False)
+    for k_ in gemm_prof:
+        gemm_prof[k_] += gp[k_]
     for db_ in timed:
         collect(db_)
     del timed
@@ -311,12 +408,12 @@ def bench_cifar(args, world, rank, dev):
                   "split EXACTLY into three bf16 parts, the six cross products of order <= 2 summed by one hipBLASLt bf16 GEMM with fp32 "
                   "accumulation (delivered error vs float64 at the fp32 GEMM's level, tests/test_gpu_parity.py); patch embedding / projections: lemon_linear_f32; "
                   "recorded solution per shape, bias / SiLU / residual epilogues; LEMON_GEMM = f32 | bf16x6 | f16x3 selects the mode",
-        "f16x3": "MLP of every block (LEMON_MLP=fused, default): hand-written split-fp16 GEMM gemm_f16x3.hip (tile-major operands, LDS-DMA ring; "
-                 "fc1's epilogue applies bias + QuickGELU + the fp16 split and stores fc2's operand); QKV, output projection, patch embedding "
-                 "(and the MLP under LEMON_MLP=lib): lemon_linear_f16x3 on hipBLASLt -- both fp32 operands "
+        "f16x3": f"LEMON_MLP={_ops.mlp_mode()} (block = default: QKV, output projection, fc1, fc2 of every block; fused: fc1, fc2): hand-written split-fp16 GEMM "
+                 "gemm_f16x3.hip (v_mfma_f32_16x16x32_f16, tile-major operands written by LayerNorm / attention / fc1's epilogue, LDS-DMA ring); "
+                 "patch embedding, the pooled-row last block (and what the mode leaves out): lemon_linear_f16x3 on hipBLASLt -- both fp32 operands "
                  "split into two fp16 parts (hi = f16(v), lo = the exact remainder kept to 11 bits: 22 bits + sign), weights pre-scaled by a "
-                 "power of two, hi.hi + hi.lo + lo.hi summed by one hipBLASLt fp16 GEMM with fp32 accumulation (error vs float64 at the "
-                 "fp32 GEMM's level, tests/test_gpu_parity.py); patch embedding / projections: lemon_linear_f32; recorded solution per "
+                 "power of two, hi.hi + hi.lo + lo.hi summed by one fp16 GEMM with fp32 accumulation (error vs float64 at the "
+                 "fp32 GEMM's level, tests/test_gpu_parity.py); final projections: lemon_linear_f32; recorded solution per "
                  "shape, bias / SiLU / residual epilogues; LEMON_GEMM = f32 | bf16x6 | f16x3 selects the mode",
         "f32": "lemon_linear_f32 (hipBLASLt fp32, recorded solution per shape, SiLU/residual epilogues)"}
     gemm_note = gemm_notes[gemm_mode]
@@ -324,7 +421,10 @@ def bench_cifar(args, world, rank, dev):
         "metric": "label-error scores/sec (embed+kNN), CIFAR-100 noise=0.4",
         "value": value, "unit": "scores/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": {"f32": "f32", "f16x3": "f32-equivalent (fp16 x3 split GEMMs: hi.hi + hi.lo + lo.hi, fp32 accumulate; everything else fp32)",
+                  "bf16x6": "f32-equivalent (bf16 x6 split GEMMs, fp32 accumulate; everything else fp32)"}[gemm_mode],
+        "data": "synthetic",
         "config": {
             "workload": f"CIFAR-100 shape per GPU: {args.n_train} train (=DB shard) + {args.n_val} val + {args.n_test} test "
                         f"image/prompt pairs ({'raw 32x32 uint8 images, bicubic resize to 224 + normalise in the step' if args.input == 'u8' else 'preprocessed float pixels'}), CLIP {args.arch} random-init fp32 encoder -> {cfg.embed_dim}-d, "
@@ -355,30 +455,56 @@ def bench_cifar(args, world, rank, dev):
         recs32, _ = step(timers=t32)
         os.environ["LEMON_GEMM"] = gemm_mode
         ds_ = (recs32["val"]["score"] - recs["val"]["score"]).abs().max().item()
+        line["value_f32_gemm_mode"] = n_scored / max(t32["embed_s"] + t32["knn_score_s"], 1e-9)     # scores/s with every GEMM on the fp32 matrix cores
         line["encoder_f32_gemm_mode"] = {"embed_s": t32["embed_s"], "achieved": (f_img + f_txt) * n_scored / max(t32["embed_s"], 1e-9) / 1e12,
                                          "unit": "TFLOP/s", "max_abs_val_score_diff_vs_split": ds_,
                                          "max_abs_val_embedding_diff_vs_split": float((recs32["val"]["emb_img"] - recs["val"]["emb_img"]).abs().max().item())}
         del recs32
+    # ---- roofline: the step's DOMINANT kernel.  With the default GEMM mode that is the hand-written split-fp16 GEMM
+    # (k_gemm_f16x3t16: fc1 / fc2 and, LEMON_MLP=block, QKV / output projection of every block); the kNN scan -- the path's
+    # own kernel, ~1 % of this step -- is reported under "knn".
+    if gemm_prof["launches"]:
+        gsec = gemm_prof["kernel_ms"] / 1e3
+        gtf = gemm_prof["flops"] / gsec / 1e12
+        gp_, gsrc = pmc_gemm_summary()
+        line["roofline"] = {
+            "kernel": "k_gemm_f16x3t16 (lemon_linear_f16x3t: v_mfma_f32_16x16x32_f16, 128 x 256 tiles)",
+            "bound": "mfma", "achieved": gtf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": gtf / PEAK_BF16_MFMA_TFLOPS,
+            "flops_note": "the kernel's executed fp16 arithmetic, 2 m n 3k per launch (three fp16 products per fp32 product), summed over the "
+                          "launches of the timed region / their summed HIP-event durations on the launch stream",
+            "launches": gemm_prof["launches"], "avg_launch_ms": gemm_prof["kernel_ms"] / gemm_prof["launches"],
+            "share_of_timed_region": gsec / max(elapsed, 1e-9),
+            "traffic": gp_.get("traffic"), "traffic_source": gsrc if gp_.get("traffic") is not None else None,
+            "mfma_busy_pmc": gp_.get("mfma_busy"), "clock_GHz_pmc": gp_.get("clock_GHz"), "pmc_source": gsrc,
+            "pmc_note": "counter figures (FETCH_SIZE x 2 + WRITE_SIZE per launch; SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024); "
+                        "GRBM_GUI_ACTIVE / 8 / duration) of this kernel's longest-running launch group in the COMMITTED rocprofv3 passes of this "
+                        "command, not of this run",
+        }
     if prof["launches"]:
         sec = prof["kernel_ms"] / 1e3
         tf = prof["algo_flops"] / sec / 1e12
         traffic, traffic_src = pmc_traffic("k_scan_f32")
         pm_, _ = pmc_summary("k_scan_f32")
-        line["roofline"] = {
-            "kernel": "k_scan_f32" if info["algo"] == _lib.ALGO_F32_MFMA else "k_scan_bf16",
+        f32scan = info["algo"] == _lib.ALGO_F32_MFMA
+        hbm_model = prof["algo_bytes"] / sec / 1e9
+        knn = {
+            "kernel": "k_scan_f32" if f32scan else "k_scan_bf16",
             "bound": "mfma", "achieved": tf,
-            "peak": PEAK_F32_MFMA_TFLOPS if info["algo"] == _lib.ALGO_F32_MFMA else PEAK_BF16_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": tf / (PEAK_F32_MFMA_TFLOPS if info["algo"] == _lib.ALGO_F32_MFMA else PEAK_BF16_MFMA_TFLOPS),
+            "peak": PEAK_F32_MFMA_TFLOPS if f32scan else PEAK_BF16_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": tf / (PEAK_F32_MFMA_TFLOPS if f32scan else PEAK_BF16_MFMA_TFLOPS),
             "traffic": traffic, "traffic_source": traffic_src, "launches": prof["launches"],
             "mfma_busy_pmc": (float(pm_["SQ_VALU_MFMA_BUSY_CYCLES"]["value_KB"]) / (float(pm_["GRBM_GUI_ACTIVE"]["value_KB"]) / 8.0 * 1024.0)
-                              if "SQ_VALU_MFMA_BUSY_CYCLES" in pm_ and "GRBM_GUI_ACTIVE" in pm_ and info["algo"] == _lib.ALGO_F32_MFMA else None),
+                              if "SQ_VALU_MFMA_BUSY_CYCLES" in pm_ and "GRBM_GUI_ACTIVE" in pm_ and f32scan else None),
             "avg_launch_ms": prof["kernel_ms"] / prof["launches"],
+            "share_of_timed_region": sec / max(elapsed, 1e-9),
             "text_side": {"distinct_queries": db.index_txt.last_search_info()["nq_distinct"], "launches": prof_txt["launches"],
                           "avg_launch_ms": prof_txt["kernel_ms"] / max(prof_txt["launches"], 1)},
-            "hbm_scan_model": {"B": info["query_panel"], "achieved_GBs": prof["algo_bytes"] / sec / 1e9,
-                               "peak_GBs": PEAK_HBM_GBS, "frac": prof["algo_bytes"] / sec / 1e9 / PEAK_HBM_GBS},
+            "hbm_scan_model": hbm_model_object(info["query_panel"], hbm_model),
         }
-    if world > 1:
+        line["knn"] = knn
+        if "roofline" not in line:            # GEMM modes without the hand-written kernel: the scan is what this file can time
+            line["roofline"] = knn
+    if world > 1 or args.rccl_world1:
         line["exchange"] = exchange_report(glog, world, info, db, args.steps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"], line["auroc_check"] = cpu_baseline_cifar(args, cfg, model, data, recs, db, n_scored)
@@ -485,14 +611,120 @@ def cpu_baseline_cifar(args, cfg, model, data, recs, db, n_scored):
         auroc["variants"][name] = {"gpu": ag, "oracle": ao, "equal_to_3_decimals": bool(round(ag, 3) == round(ao, 3)),
                                    "max_abs_score_diff": float(np.abs(sg - so).max())}
     auroc["informative"] = bool(max(v["gpu"] for v in auroc["variants"].values()) > 0.6)
-    base = {
+    port = {
         "value": 1.0 / per_sample, "unit": "scores/s", "cores": cores, "kind": "port",
         "sample": f"{ni} images through PIL generic_transform (time / {cores} cores) and {ni} image+prompt pairs through the same CLIP module on CPU fp32 (torch, {cores} threads) "
                   f"+ oracle kNN/neighbours/score for {nqs} val queries against the full {args.n_train}-row DB "
                   f"(OpenMP, {cores} threads); per-sample times added and inverted; train embedded once as on the GPU",
         "preprocess_s_per_sample": t_pre, "embed_s_per_sample": t_embed, "knn_score_s_per_sample": t_knn,
     }
+    base = cpu_reference_style(args, cfg, data, recs, db, n_scored, cores, t_pre)
+    base["port_oracle"] = port
     return base, auroc
+
+
+def cpu_reference_style(args, cfg, data, recs, db, n_scored, cores, t_pre):
+    """The CPU baseline SURVEY 8d / BASELINE.md section 3 define, leg by leg, on this host's cores (oracle/reference_loop.py):
+      encoder   HF transformers CLIPModel (the class lib/models/downstream_models.py:30-41 wraps) of the same architecture,
+                fp32 on CPU, batch 128, 512 image + prompt pairs timed (random-init weights: same FLOPs);
+      kNN       float32 torch.mm of a 128-query batch against the full DB + exact top-k (the faiss IndexFlat stand-in,
+                run_lemon.py:235-236), both modalities;
+      scoring   (a) the faithful per-sample Python loop (run_lemon.py:238-307, O(N) membership test included), (b) numpy vectorised.
+    `value` = reference-equivalent end to end: every scored sample preprocessed and embedded, the train split embedded TWICE
+    (run_lemon.py:137-161 and :198-233), searched in 128-query batches and scored by the loop; extrapolated per sample."""
+    import torch as _t
+    from oracle import reference_loop as rl
+    _t.set_num_threads(cores)
+    legs = {}
+    # ---- encoder: HF CLIPModel on CPU ----
+    n_enc, bs = 512, 128
+    try:
+        from transformers import CLIPConfig, CLIPModel
+        hcfg = CLIPConfig(projection_dim=cfg.embed_dim,
+                          vision_config=dict(hidden_size=cfg.vision.width, num_hidden_layers=cfg.vision.layers, num_attention_heads=cfg.vision.heads,
+                                             intermediate_size=cfg.vision.mlp, image_size=cfg.image_size, patch_size=cfg.patch_size),
+                          text_config=dict(hidden_size=cfg.text.width, num_hidden_layers=cfg.text.layers, num_attention_heads=cfg.text.heads,
+                                           intermediate_size=cfg.text.mlp, vocab_size=cfg.vocab_size, max_position_embeddings=cfg.context_length,
+                                           eos_token_id=2, bos_token_id=0, pad_token_id=1))
+        _t.manual_seed(0)
+        hf = CLIPModel(hcfg).eval()
+        px = _t.randn(n_enc, 3, cfg.image_size, cfg.image_size)
+        ids = data["val"]["ids"][:n_enc].cpu().long()
+        if ids.shape[0] < n_enc:
+            ids = ids.repeat((n_enc + ids.shape[0] - 1) // ids.shape[0], 1)[:n_enc]
+        mask = (_t.arange(ids.shape[1])[None, :] <= ids.argmax(-1)[:, None]).long()
+        with _t.no_grad():
+            hf.get_image_features(pixel_values=px[:8]); hf.get_text_features(input_ids=ids[:8], attention_mask=mask[:8])     # warm
+            t0 = time.perf_counter()
+            for i in range(0, n_enc, bs):
+                hf.get_image_features(pixel_values=px[i:i + bs])
+            t_img = (time.perf_counter() - t0) / n_enc
+            t0 = time.perf_counter()
+            for i in range(0, n_enc, bs):
+                hf.get_text_features(input_ids=ids[i:i + bs], attention_mask=mask[i:i + bs])
+            t_txt = (time.perf_counter() - t0) / n_enc
+        del hf
+        legs["encoder"] = {"kind": "HF transformers CLIPModel, fp32 on CPU, batch 128 (lib/models/downstream_models.py:30-41)", "samples": n_enc,
+                           "image_s_per_sample": t_img, "text_s_per_sample": t_txt, "pairs_per_s": 1.0 / (t_img + t_txt)}
+        t_embed = t_img + t_txt
+    except Exception as e:       # transformers missing / incompatible: say so, fall back to the module timed in the port
+        legs["encoder"] = {"kind": "unavailable", "error": repr(e)[:200]}
+        t_embed = None
+    # ---- kNN + scoring on the very embeddings the GPU scored ----
+    img_tr, txt_tr = db.img.cpu(), db.txt.cpu()
+    dists_tr = (1 - (txt_tr * img_tr).sum(1)) if args.dist_type == "cosine" else ((txt_tr - img_tr) ** 2).sum(1)
+    ii, it = rl.FlatIndexTorch(img_tr.shape[1], args.dist_type), rl.FlatIndexTorch(img_tr.shape[1], args.dist_type)
+    t0 = time.perf_counter()
+    ii.add(img_tr.numpy()); it.add(txt_tr.numpy())
+    t_add = time.perf_counter() - t0
+    n_tr_q = min(2048, recs["train"]["emb_img"].shape[0])
+    n_va_q = min(1024, recs["val"]["emb_img"].shape[0])
+    splits = (("train", recs["train"], n_tr_q), ("val", recs["val"], n_va_q))
+    in_compr = np.arange(img_tr.shape[0])                           # single GPU: the DB is the whole train split, in order
+    t_search = t_loop = t_vec = 0.0
+    nq_tot = 0
+    agree = True
+    for sname, rv, nq in splits:
+        qi, qt = rv["emb_img"][:nq].cpu(), rv["emb_txt"][:nq].cpu()
+        kk = args.knn_k + (sname == "train")
+        t0 = time.perf_counter()
+        for lo in range(0, nq, 128):
+            ii.search(qi[lo:lo + 128].numpy(), kk); it.search(qt[lo:lo + 128].numpy(), kk)
+        t_search += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        logs = rl.per_sample_loop(sname, qi, qt, img_tr, txt_tr, dists_tr, ii, it, args.knn_k, 128, in_compr, args.dist_type)
+        t_loop += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        vec = rl.vectorised(sname, qi.numpy(), qt.numpy(), img_tr.numpy(), txt_tr.numpy(), dists_tr.numpy(), ii, it, args.knn_k, 128,
+                            np.ones(nq, bool), args.dist_type)
+        t_vec += time.perf_counter() - t0
+        nq_tot += nq
+        # against the GPU records: image-side neighbour sets (all-distinct queries: no ties) and d_1
+        agree = agree and bool(np.array_equal(np.sort(rl.stack(logs, "I_n"), 1), np.sort(rv["I_n"][:nq].cpu().numpy(), 1)))
+        agree = agree and bool(np.allclose(rl.stack(logs, "d_1"), rv["d_1"][:nq].cpu().numpy(), atol=1e-5))
+    t_loop_only = max(t_loop - t_search, 0.0)
+    legs["knn"] = {"kind": "float32 torch.mm + exact top-k per 128-query batch, both modalities (faiss IndexFlat stand-in, run_lemon.py:235-236)",
+                   "queries": nq_tot, "db_rows": int(img_tr.shape[0]), "s_per_query": t_search / nq_tot, "queries_per_s": nq_tot / t_search,
+                   "index_add_s": t_add}
+    legs["scoring_python_loop"] = {"kind": "faithful per-sample Python loop incl. the O(N) membership test (run_lemon.py:238-307); search time subtracted",
+                                   "samples": nq_tot, "s_per_sample": t_loop_only / nq_tot}
+    legs["scoring_vectorised"] = {"kind": "numpy vectorised twin of the loop, searches included", "samples": nq_tot,
+                                  "s_per_sample": t_vec / nq_tot}
+    embeds_per_scored = (2 * args.n_train + args.n_val + args.n_test) / n_scored          # the reference embeds train twice
+    if t_embed is None:
+        return {"value": None, "unit": "scores/s", "cores": cores, "kind": "port", "legs": legs, "sample": "HF CLIPModel unavailable"}
+    per_ref = (t_pre + t_embed) * embeds_per_scored + t_search / nq_tot + t_loop_only / nq_tot
+    per_vec = (t_pre + t_embed) * embeds_per_scored + t_vec / nq_tot
+    return {
+        "value": 1.0 / per_ref, "unit": "scores/s", "cores": cores, "kind": "port",
+        "sample": f"reference-style CPU path restated (oracle/reference_loop.py), per-sample times of bounded samples added and inverted: PIL "
+                  f"generic_transform (time / {cores} cores) + HF CLIPModel fp32 batch 128 on {n_enc} image+prompt pairs, both x {embeds_per_scored:.1f} "
+                  f"(train embedded twice, as upstream) + torch.mm/top-k search of {nq_tot} queries (128 per call) against the {int(img_tr.shape[0])}-row DB "
+                  f"+ the per-sample Python loop on those queries; torch {cores} threads",
+        "value_with_vectorised_scoring": 1.0 / per_vec,
+        "embeds_per_scored_sample": embeds_per_scored, "preprocess_s_per_sample": t_pre, "legs": legs,
+        "neighbours_and_d1_agree_with_gpu_on_sample": agree,
+    }
 
 
 def bench_knn(args, world, rank, dev):
@@ -509,7 +741,7 @@ def bench_knn(args, world, rank, dev):
     algo = {"auto": None, "f32": _lib.ALGO_F32_MFMA, "bf16": _lib.ALGO_BF16_FILTER}[args.algo]
     prof = {"launches": 0, "kernel_ms": 0.0, "algo_flops": 0.0, "algo_bytes": 0.0}
 
-    glog = GatherLog() if world > 1 else None
+    glog = GatherLog() if (world > 1 or args.rccl_world1) else None
 
     def step(events):
         lg = glog if events else None
@@ -552,10 +784,7 @@ def bench_knn(args, world, rank, dev):
                      "achieved": prof["algo_flops"] / sec / 1e12, "peak": peak, "unit": "TFLOP/s",
                      "frac": prof["algo_flops"] / sec / 1e12 / peak, "traffic": None,
                      "launches": prof["launches"], "avg_launch_ms": prof["kernel_ms"] / max(prof["launches"], 1),
-                     "hbm_scan_model": {"B": info["query_panel"], "achieved_GBs": prof["algo_bytes"] / sec / 1e9,
-                                        "peak_GBs": PEAK_HBM_GBS, "frac": prof["algo_bytes"] / sec / 1e9 / PEAK_HBM_GBS,
-                                        "note": "MODEL bytes (one DB stream per 128-query panel, SURVEY 8d), not measured "
-                                                "traffic: the kernel is MFMA-bound, `frac` above is the binding fraction"}},
+                     "hbm_scan_model": hbm_scan_model_object(info["query_panel"], prof["algo_bytes"] / sec / 1e9)},
     }
     if not f32 and n == 1000000 and d == 768:
         # counter figures of the steady-state chunk launch from the committed PMC passes of THIS command (tools/gpu_profile.sh):
@@ -573,7 +802,7 @@ def bench_knn(args, world, rank, dev):
         if sus:
             line["roofline"]["peak_sustained_random_operands"] = {"value": sus, "unit": "TFLOP/s", "source": src,
                                                                   "frac": prof["algo_flops"] / sec / 1e12 / sus}
-    if world > 1:
+    if world > 1 or args.rccl_world1:
         line["exchange"] = exchange_report(glog, world, info, db, args.steps)
     if cpu is not None:
         line["cpu_baseline"] = cpu
@@ -603,13 +832,15 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)               # before any GPU call in this process
+    if args.rccl_world1 and args.gpus != 1:
+        raise SystemExit("bench.py: --rccl_world1 is the one-GPU rehearsal of the exchange step (use it with --gpus 1)")
     world, rank, dev = init_dist(args)
     from lemon_amd import _lib
     _lib.load()                                   # fail loudly if the HIP library is missing
     line = bench_cifar(args, world, rank, dev) if args.workload == "cifar100" else bench_knn(args, world, rank, dev)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.rccl_world1:
         import torch.distributed as dist
         dist.destroy_process_group()
 

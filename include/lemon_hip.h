@@ -213,6 +213,13 @@ int lemon_layernorm_f16x3t(const float *x_dev, const float *weight_dev, const fl
 int lemon_linear_f16x3t(const uint16_t *at_dev, const uint16_t *wt_dev, const float *bias_dev, const float *residual_dev,
                         int64_t m, int n, int k, float alpha, int act, int out_operand, void *out_dev, void *stream);
 int lemon_unpack_act_f16x3t(const uint16_t *at_dev, int64_t rows, int k, float *y_dev, void *stream);
+/* Timing of the hand-written GEMM (no reference counterpart; bench.py's roofline object): while profiling is on every
+ * lemon_linear_f16x3t launch of this process is bracketed by HIP events on its launch stream (a pool of 8 192 pairs, made
+ * on the first call; launches beyond it are not bracketed).  profile_read waits for the recorded events, returns the number
+ * of bracketed launches, their summed durations and their summed arithmetic (2 m n 3k: the three fp16 products the kernel
+ * executes per fp32 product), and rewinds the pool. */
+int lemon_linear_f16x3t_set_profiling(int on);
+int lemon_linear_f16x3t_profile_read(int64_t *launches, double *kernel_ms, double *flops);
 /* lemon_attention_f32 whose result is written as that activation operand (rows = batch*seq_len, k = heads*64): the output
  * projection then runs in the hand-written GEMM too (with QKV: all four GEMMs of a block). */
 int lemon_attention_f16x3t(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,

@@ -15,7 +15,7 @@ OBJ = os.path.join(CSRC, "_obj")
 SO = os.path.join(HERE, "liblemon_hip.so")
 SOURCES = ["api.hip", "rowwise.hip", "knn_f32.hip", "knn_bf16.hip", "attention.hip", "linear.hip", "preprocess.hip",
            "gridf1.hip", "dedup.hip", "encoder.hip", "gemm_f16x3.hip"]
-HEADERS = ["common.hpp", "knn_common.hpp", "split3.hpp", os.path.join("..", "..", "include", "lemon_hip.h")]
+HEADERS = ["common.hpp", "knn_common.hpp", "split3.hpp", "scan_plan.hpp", os.path.join("..", "..", "include", "lemon_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 

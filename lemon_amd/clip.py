@@ -204,7 +204,7 @@ class Block(nn.Module):
         mlp = self.fc1.weight.shape[0]
         hand = mode == "f16x3" and rows is None and ops.mlp_mode()
         if hand == "block" and ops.block_fused_supported(W, mlp, self.heads, L):
-            # QKV and the output projection in the hand-written GEMM as well (LEMON_MLP=block; not the default: see ops.mlp_mode):
+            # QKV and the output projection in the hand-written GEMM as well (LEMON_MLP=block, the default: see ops.mlp_mode):
             # LayerNorm and attention write its tile-major operands
             m = B * L
             wq, aq = self._w_tiled("qkv", ops)

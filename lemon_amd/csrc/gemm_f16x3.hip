@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
+#include <vector>
 
 #include "common.hpp"
 #include "split3.hpp"
@@ -464,6 +465,15 @@ __global__ __launch_bounds__(256) void k_unpack_act_t(const unsigned short *__re
 constexpr int MAX_DEVICES = 64;
 std::mutex g_attr_mu;
 bool g_attr_set[MAX_DEVICES] = {};
+// optional timing of every launch (lemon_linear_f16x3t_set_profiling): HIP events on the launch stream from a pool made once,
+// read back (and the pool rewound) by lemon_linear_f16x3t_profile_read -- bench.py's roofline object for the step's dominant kernel
+struct GemmProf {
+    bool on = false;
+    std::vector<hipEvent_t> ev;        // pairs
+    std::vector<double> flops;
+    size_t used = 0;                   // events handed out
+} g_prof;
+constexpr size_t PROF_POOL = 2 * 8192;
 int g_gm = 0, g_gn = 0;                // tile-walk override (tools/micro); 0: the defaults
 int g_mfma_shape = 0;                  // 0: not decided yet ($LEMON_GEMM_MFMA, default 16); tools/micro sets it directly
 void walk_override() {
@@ -552,6 +562,16 @@ extern "C" int lemon_linear_f16x3t(const uint16_t *at_dev, const uint16_t *wt_de
     // matrix instruction: 16x16x32 where the k extent allows whole k32 steps (every tower width does), else 32x32x16;
     // LEMON_GEMM_MFMA=32 forces the latter (A/B runs)
     const bool mf16 = mfma_shape() == 16 && p.ks % 2 == 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_attr_mu);
+        if (g_prof.on && g_prof.used + 2 <= g_prof.ev.size()) {
+            ev0 = g_prof.ev[g_prof.used]; ev1 = g_prof.ev[g_prof.used + 1];
+            g_prof.used += 2;
+            g_prof.flops.push_back(2.0 * (double)m * (double)n * 3.0 * (double)k);      // the kernel's own arithmetic: three fp16 products
+        }
+    }
+    if (ev0) LEMON_HIP_CHECK(hipEventRecord(ev0, (hipStream_t)stream_));
     if (mf16) {
         if (out_operand) hipLaunchKernelGGL(k_gemm_f16x3t16<1>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
         else hipLaunchKernelGGL(k_gemm_f16x3t16<0>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
@@ -560,5 +580,30 @@ extern "C" int lemon_linear_f16x3t(const uint16_t *at_dev, const uint16_t *wt_de
         else hipLaunchKernelGGL(k_gemm_f16x3t<0>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
     }
     LEMON_HIP_CHECK(hipGetLastError());
+    if (ev1) LEMON_HIP_CHECK(hipEventRecord(ev1, (hipStream_t)stream_));
+    return LEMON_OK;
+}
+
+extern "C" int lemon_linear_f16x3t_set_profiling(int on) {
+    std::lock_guard<std::mutex> lock(g_attr_mu);
+    if (on && g_prof.ev.empty()) {
+        g_prof.ev.resize(PROF_POOL);
+        for (auto &e : g_prof.ev) LEMON_HIP_CHECK(hipEventCreate(&e));
+    }
+    g_prof.on = on != 0;
+    return LEMON_OK;
+}
+
+extern "C" int lemon_linear_f16x3t_profile_read(int64_t *launches, double *kernel_ms, double *flops) {
+    LEMON_REQUIRE(launches && kernel_ms && flops, "null pointer");
+    std::lock_guard<std::mutex> lock(g_attr_mu);
+    *launches = (int64_t)(g_prof.used / 2); *kernel_ms = 0.0; *flops = 0.0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        LEMON_HIP_CHECK(hipEventSynchronize(g_prof.ev[i + 1]));
+        float ms = 0.0f;
+        LEMON_HIP_CHECK(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
+        *kernel_ms += ms; *flops += g_prof.flops[i / 2];
+    }
+    g_prof.used = 0; g_prof.flops.clear();
     return LEMON_OK;
 }

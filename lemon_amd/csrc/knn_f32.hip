@@ -16,6 +16,7 @@
 // fabric traffic: one query-panel slice + one database tile per unit, shared through the L2 only between
 // workgroups that walk the same tiles in step.
 #include "knn_common.hpp"
+#include "scan_plan.hpp"
 #include <algorithm>
 #include <vector>
 
@@ -571,63 +572,7 @@ void lemon_plan_splits(int panels, int n_tiles, int *splits_out, int *tiles_per_
 // one panel each -- they walk the same tiles in step -- and the other workgroups share the tails [u, T); T < u: every
 // workgroup first takes floor(u / T) whole panels (again from tile 0, in step), the rest is shared out.  A segment is
 // (panel, first tile, tiles, piece number in the panel); workgroup b owns segments plan[b] .. plan[b+1].
-struct LemonPlan {
-    std::vector<int> seg_begin;      // [grid + 1]
-    std::vector<int> pieces;         // [panels]
-    std::vector<int> segs;           // 4 ints per segment
-    int grid = 0, splits = 1;
-};
-
-// `c` = what a segment costs on top of its tiles (pipeline refill, the cold start of its candidate lists, the final
-// selection), in tile times: shares are equal in COST, not in tiles -- a workgroup that collects four tails would
-// otherwise finish 5 % after one that walks a single head (measured: lives 16.9 ms against 16.0-16.3 ms).
-static void plan_group(const std::vector<int> &wgs, const std::vector<int> &pnls, int T, int c, std::vector<std::vector<int>> &wg_segs,
-                       std::vector<int> &pieces) {
-    const int m = (int)wgs.size(), n = (int)pnls.size();
-    if (m == 0 || n == 0) return;
-    const int64_t total = (int64_t)n * T;
-    const int64_t u = (total + m - 1) / m;
-    // budget per workgroup: tiles + c per segment; about one segment per panel and one more per workgroup boundary
-    int64_t budget;
-    std::vector<int64_t> room;
-    auto put = [&](int w, int panel, int t0, int nt) {
-        std::vector<int> &v = wg_segs[wgs[w]];
-        v.push_back(panel); v.push_back(t0); v.push_back(nt); v.push_back(pieces[panel]++);
-        room[w] -= nt + c;
-    };
-    std::vector<std::pair<int, int>> pool;   // (panel, first tile) of what the aligned part leaves, panel-major
-    if ((int64_t)T >= u) {                   // heads [0, h) of one panel per workgroup, tails to the pool
-        int64_t h = (total + (int64_t)c * n + m - 1) / m;      // h + c = (n (T - h) + c m) / (m - n)
-        if (h > T || n == m) h = T;
-        budget = h + c;
-        room.assign(m, budget);
-        for (int i = 0; i < n; ++i) {
-            put(i, pnls[i], 0, (int)h);      // n <= m here (n T <= m u and T >= u)
-            if ((int64_t)T > h) pool.push_back(std::make_pair(pnls[i], (int)h));
-        }
-    } else {                                 // whole panels per workgroup while they fit the budget, the rest to the pool
-        budget = ((int64_t)n * (T + c) + m - 1) / m + c;
-        room.assign(m, budget);
-        const int a = (int)(budget / (T + c)) > 0 ? (int)(budget / (T + c)) : 1;
-        int next = 0;
-        for (int w = 0; w < m; ++w)
-            for (int j = 0; j < a && next < n; ++j) put(w, pnls[next++], 0, T);
-        for (; next < n; ++next) pool.push_back(std::make_pair(pnls[next], 0));
-    }
-    int w = 0;
-    for (auto &pt : pool) {                  // share the pool out in order: every workgroup is filled up to its budget
-        int t0 = pt.second;
-        while (t0 < T) {
-            while (w < m - 1 && room[w] <= c) ++w;
-            int64_t fit = room[w] - c;
-            if (fit < 1 || w == m - 1) fit = T;              // the last workgroup takes whatever is left
-            const int nt = (int)std::min<int64_t>(fit, T - t0);
-            put(w, pt.first, t0, nt);
-            t0 += nt;
-        }
-    }
-}
-
+// (the planner itself is plain C++ in scan_plan.hpp: it is also built with gcc under ASan / UBSan and fuzzed on the CPU)
 static void lemon_plan_segments(int panels, int n_tiles, LemonPlan &plan) {
     static const int slots = [] {
         int dev = 0, cus = 256;
@@ -636,29 +581,7 @@ static void lemon_plan_segments(int panels, int n_tiles, LemonPlan &plan) {
     }();
     static const int xcds = [] { const char *e = getenv("LEMON_XCDS"); return e && atoi(e) > 0 ? atoi(e) : 8; }();   // 1 = not XCD-aware
     static const int seg_cost = [] { const char *e = getenv("LEMON_SEG_COST"); return e ? atoi(e) : 3; }();   // tile times per segment
-    const int64_t units = (int64_t)panels * n_tiles;
-    int64_t g = units / 8;                               // every workgroup keeps >= 8 tiles
-    if (g < 1) g = 1;
-    if (g > slots) g = slots;
-    const int X = (panels >= 8 * xcds && g >= 8 * xcds) ? xcds : 1;   // few panels: one group, still aligned
-    std::vector<std::vector<int>> wg_segs((size_t)g);
-    plan.pieces.assign((size_t)panels, 0);
-    for (int x = 0; x < X; ++x) {
-        std::vector<int> wgs, pnls;
-        for (int b = x; b < (int)g; b += X) wgs.push_back(b);
-        for (int q = x; q < panels; q += X) pnls.push_back(q);
-        plan_group(wgs, pnls, n_tiles, seg_cost, wg_segs, plan.pieces);
-    }
-    plan.grid = (int)g;
-    plan.seg_begin.assign((size_t)g + 1, 0);
-    plan.segs.clear();
-    for (int b = 0; b < (int)g; ++b) {
-        plan.seg_begin[b] = (int)(plan.segs.size() / 4);
-        plan.segs.insert(plan.segs.end(), wg_segs[b].begin(), wg_segs[b].end());
-    }
-    plan.seg_begin[g] = (int)(plan.segs.size() / 4);
-    plan.splits = 1;
-    for (int c : plan.pieces) plan.splits = c > plan.splits ? c : plan.splits;
+    lemon_plan_segments_host(panels, n_tiles, slots, xcds, seg_cost, plan);
 }
 
 extern "C" int lemon_debug_scan_plan(int panels, int n_tiles, int *grid, int *splits, int *seg_begin, int cap_wgs, int *pieces,

@@ -254,13 +254,13 @@ linear_split3 = linear_split
 
 # ---- the MLP of a block in the hand-written split-fp16 GEMM (gemm_f16x3.hip: tile-major operands, fused fc1 epilogue) ----
 def mlp_mode():
-    """LEMON_MLP, with LEMON_GEMM=f16x3: 'fused' (default): the MLP of every block in the hand-written kernel (gemm_f16x3.hip:
-    LayerNorm writes its tile-major operand, fc1's epilogue writes fc2's; the [m, mlp] fp32 activation and its split pass never
-    exist), QKV and the output projection in the library; 'block': those two in the hand-written kernel as well (measured 2 %
-    SLOWER end to end: 32.7 k vs 33.4 k scores/s -- the plain epilogue has nothing to fuse there and the short-k output
-    projection is epilogue-bound); 'lib': the library GEMMs (lemon_linear_f16x3) with the separate split pass."""
+    """LEMON_MLP, with LEMON_GEMM=f16x3: 'block' (default): all four GEMMs of a block in the hand-written kernel (gemm_f16x3.hip):
+    LayerNorm and attention write its tile-major operands, fc1's epilogue writes fc2's -- with the 16x16x32 kernel of round 4
+    this is the fastest mode (35.6 k scores/s against 35.4 k for 'fused' on the same box; in round 3, with the 32x32x16 kernel,
+    it was 2 % slower); 'fused': only the MLP there, QKV and the output projection in the library (lemon_linear_f16x3);
+    'lib': the library GEMMs throughout, with the separate split pass."""
     import os
-    v = os.environ.get("LEMON_MLP", "fused").lower()
+    v = os.environ.get("LEMON_MLP", "block").lower()
     if v not in ("block", "fused", "lib"):
         raise ValueError(f"LEMON_MLP={v!r}: expected block, fused or lib")
     return v
@@ -329,6 +329,19 @@ def linear_t(at, wt, m, n, k, bias=None, residual=None, act=None, alpha=1.0, out
                                            ACT_SILU if act == "silu" else ACT_NONE, int(act == "silu"), ptr(out), stream_ptr(at.device)),
                    "lemon_linear_f16x3t")
     return out
+
+
+def gemm_profiling(on):
+    """HIP events around every lemon_linear_f16x3t launch from now on (bench.py: the roofline of the step's dominant kernel)."""
+    _lib.check(_lib.load().lemon_linear_f16x3t_set_profiling(int(bool(on))), "lemon_linear_f16x3t_set_profiling")
+
+
+def gemm_profile_read():
+    """{launches, kernel_ms, flops} of the bracketed launches since the last read (waits for them; rewinds the event pool)."""
+    n, ms, fl = ctypes.c_int64(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+    _lib.check(_lib.load().lemon_linear_f16x3t_profile_read(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)),
+               "lemon_linear_f16x3t_profile_read")
+    return {"launches": int(n.value), "kernel_ms": float(ms.value), "flops": float(fl.value)}
 
 
 def attention_t(qkv, heads, causal=False):

@@ -61,12 +61,15 @@ class GatherLog:
         return {"allgather_ms": total, "arrays": arrays}
 
 
-def all_gather_rows(t, n_total, group=None, log=None, name="rows"):
+def all_gather_rows(t, n_total, group=None, log=None, name="rows", force=False):
     """All-gather row shards (possibly ragged: last shard short/empty) into global row order.
     One RCCL all_gather per array; shards are padded to ceil(n/W) rows.  `log`: a GatherLog that
-    receives the collective's HIP-event bracket."""
+    receives the collective's HIP-event bracket.  A one-rank group returns the shard itself unless `force` (or
+    LEMON_FORCE_ALLGATHER=1) sends it through the collective anyway -- how the RCCL path is exercised on a one-GPU box."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return t
+    if dist.get_world_size(group) == 1 and not (force or os.environ.get("LEMON_FORCE_ALLGATHER") == "1"):
         return t
     W = dist.get_world_size(group)
     per = (n_total + W - 1) // W

@@ -128,7 +128,8 @@ void lo_knn(int metric, const float *X, int64_t n, int d,
     float *XT = NULL, *xn = NULL;
     /* transposed 8-row blocks: XT[b][kk][lane] so that 8 independent chains run in one vector */
     if (n > 0) {
-        XT = (float *)aligned_alloc(64, (size_t)nb * d * 8 * sizeof(float));
+        /* (C11: the size passed to aligned_alloc must be a multiple of the alignment -- found by the ASan build, tests/test_sanitizers.py) */
+        XT = (float *)aligned_alloc(64, (((size_t)nb * d * 8 * sizeof(float)) + 63) / 64 * 64);
         xn = (float *)malloc((size_t)nb * 8 * sizeof(float));
         #pragma omp parallel for schedule(static)
         for (int64_t b = 0; b < nb; ++b)

@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liblemon_oracle.so")
+# LEMON_ORACLE_SO: another build of lemon_oracle.c to load instead (tests/test_sanitizers.py: the ASan + UBSan build)
+_SO = os.environ.get("LEMON_ORACLE_SO") or os.path.join(_HERE, "liblemon_oracle.so")
 
 METRIC_IP = 0
 METRIC_L2 = 1
@@ -21,6 +22,8 @@ _METRICS = {"cosine": METRIC_IP, "ip": METRIC_IP, "euclidean": METRIC_L2, "l2": 
 
 
 def build(force=False):
+    if os.environ.get("LEMON_ORACLE_SO"):
+        return _SO
     src = os.path.join(_HERE, "lemon_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liblemon_oracle.so"],

@@ -209,7 +209,7 @@ def test_f16x3_reports_activations_beyond_the_fp16_range(hip, monkeypatch):
 
 
 def test_fused_mlp_and_library_mlp_give_the_same_embeddings(hip, monkeypatch):
-    # LEMON_MLP=fused (the MLP in gemm_f16x3.hip, the default) / block (all four GEMMs of a block) vs lib (hipBLASLt + split
+    # LEMON_MLP=block (all four GEMMs of a block in gemm_f16x3.hip, the default) / fused (the MLP only) vs lib (hipBLASLt + split
     # pass), ViT-B/32, both towers
     from lemon_amd.clip import ClipConfig, LemonCLIP
     from lemon_amd.ops import normalize_vectors
