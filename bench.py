@@ -683,7 +683,8 @@ def cpu_reference_style(args, cfg, data, recs, db, n_scored, cores, t_pre):
     in_compr = np.arange(img_tr.shape[0])                           # single GPU: the DB is the whole train split, in order
     t_search = t_loop = t_vec = 0.0
     nq_tot = 0
-    agree = True
+    rows_same = 0
+    d1_diff = 0.0
     for sname, rv, nq in splits:
         qi, qt = rv["emb_img"][:nq].cpu(), rv["emb_txt"][:nq].cpu()
         kk = args.knn_k + (sname == "train")
@@ -699,9 +700,10 @@ def cpu_reference_style(args, cfg, data, recs, db, n_scored, cores, t_pre):
                             np.ones(nq, bool), args.dist_type)
         t_vec += time.perf_counter() - t0
         nq_tot += nq
-        # against the GPU records: image-side neighbour sets (all-distinct queries: no ties) and d_1
-        agree = agree and bool(np.array_equal(np.sort(rl.stack(logs, "I_n"), 1), np.sort(rv["I_n"][:nq].cpu().numpy(), 1)))
-        agree = agree and bool(np.allclose(rl.stack(logs, "d_1"), rv["d_1"][:nq].cpu().numpy(), atol=1e-5))
+        # against the GPU records: image-side neighbour sets and d_1.  (torch.mm's float32 summation order is not the chain order
+        # of the exact scan: a near-tie at the k-th place can fall the other way, so the share of identical rows is reported)
+        rows_same += int((np.sort(rl.stack(logs, "I_n"), 1) == np.sort(rv["I_n"][:nq].cpu().numpy(), 1)).all(1).sum())
+        d1_diff = max(d1_diff, float(np.abs(rl.stack(logs, "d_1") - rv["d_1"][:nq].cpu().numpy()).max()))
     t_loop_only = max(t_loop - t_search, 0.0)
     legs["knn"] = {"kind": "float32 torch.mm + exact top-k per 128-query batch, both modalities (faiss IndexFlat stand-in, run_lemon.py:235-236)",
                    "queries": nq_tot, "db_rows": int(img_tr.shape[0]), "s_per_query": t_search / nq_tot, "queries_per_s": nq_tot / t_search,
@@ -723,7 +725,7 @@ def cpu_reference_style(args, cfg, data, recs, db, n_scored, cores, t_pre):
                   f"+ the per-sample Python loop on those queries; torch {cores} threads",
         "value_with_vectorised_scoring": 1.0 / per_vec,
         "embeds_per_scored_sample": embeds_per_scored, "preprocess_s_per_sample": t_pre, "legs": legs,
-        "neighbours_and_d1_agree_with_gpu_on_sample": agree,
+        "agreement_with_gpu_on_sample": {"rows_with_identical_image_neighbour_sets": rows_same / nq_tot, "max_abs_d1_diff": d1_diff},
     }
 
 

@@ -109,9 +109,17 @@ int lemon_preprocess_u8(const uint8_t *img_dev, int64_t batch, int in_h, int in_
  * lib/models/chexzero_clip.py:191-212 with the causal mask of :348-354 for text).
  * qkv_dev [batch, seq_len, 3, heads, head_dim] float32 = the fused q/k/v projection output;
  * out_dev [batch, seq_len, heads*head_dim] = softmax(q k^T / sqrt(head_dim) [+ causal]) v with heads
- * concatenated, ready for the output projection.  head_dim must be 64, seq_len <= 288. */
+ * concatenated, ready for the output projection.  head_dim must be 64, seq_len <= 288.
+ * Arithmetic (all lemon_attention_* entry points): by default the two products run as SPLIT products on the fp16 matrix cores
+ * -- q, k, v and the probabilities are carried as fp16 pairs (hi = f16(v), lo = the remainder: 22 bits + sign, fp32
+ * accumulate; error vs float64 at the level of the all-fp32 form).  RANGE: |q|, |k|, |v| must stay below 65 520, beyond that
+ * the fp16 parts are inf and the result NaN (loud, not wrong); PRECISION: the short kernels (seq_len <= 64) scale lo by 2^11
+ * (full relative precision), the general kernel stores lo unscaled (absolute precision 2^-25: values below 2^-3 keep less than
+ * 22 bits, still >= 2^-25 absolute).  lemon_attention_set_f16(0) switches the process to v_mfma_f32_32x32x2_f32 for both
+ * products (no range limit, the fp32 GEMM modes select it; returns the previous setting); $LEMON_ATTN_F16=0 starts there. */
 int lemon_attention_f32(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
                         int causal, float *out_dev, void *stream);
+int lemon_attention_set_f16(int on);
 /* The same attention with the result written as the 3-way bf16 split activation operand of lemon_linear_bf16x6 (below):
  * out6_dev [batch*seq_len, 6*heads*64] bf16, 16-byte aligned.  The fp32 result is split at the store, not recomputed. */
 int lemon_attention_split3(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
@@ -219,6 +227,10 @@ int lemon_unpack_act_f16x3t(const uint16_t *at_dev, int64_t rows, int k, float *
  * of bracketed launches, their summed durations and their summed arithmetic (2 m n 3k: the three fp16 products the kernel
  * executes per fp32 product), and rewinds the pool. */
 int lemon_linear_f16x3t_set_profiling(int on);
+/* The matrix instruction of lemon_linear_f16x3t: 16 = v_mfma_f32_16x16x32_f16 (default wherever k is a multiple of 32), 32 =
+ * v_mfma_f32_32x32x16_f16 (always used for the other k), 0 = back to the default ($LEMON_GEMM_MFMA).  Same arithmetic, another
+ * summation order inside a k32 step; process-wide, for A/B runs and tests.  Returns the previous setting (>= 0) or an error. */
+int lemon_linear_f16x3t_set_mfma(int shape);
 int lemon_linear_f16x3t_profile_read(int64_t *launches, double *kernel_ms, double *flops);
 /* lemon_attention_f32 whose result is written as that activation operand (rows = batch*seq_len, k = heads*64): the output
  * projection then runs in the hand-written GEMM too (with QKV: all four GEMMs of a block). */

@@ -137,6 +137,7 @@ class Block(nn.Module):
             # and the residual adds ride in the hipBLASLt epilogue), attention through lemon_attention_f32
             from . import ops
             mode = ops.gemm_mode()
+            ops.select_attention_arithmetic(mode)
             if W % 4 == 0 and W <= 1024 and mode != "f32":
                 return self._forward_split(x, causal, rows, ops, mode)
             ln = lambda m, t: ops.layer_norm(t, m.weight, m.bias, m.eps) if t.shape[-1] % 4 == 0 else m(t)

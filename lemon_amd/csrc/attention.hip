@@ -18,6 +18,9 @@
 #include <stdint.h>
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <algorithm>
 
 #include "common.hpp"
 #include "split3.hpp"
@@ -239,6 +242,261 @@ __global__ __launch_bounds__(576) void k_attention_hd64(const float *__restrict_
             } else {
                 *reinterpret_cast<float4 *>(dst + c0) = v0;
                 *reinterpret_cast<float4 *>(dst + 32 + c0) = v1;
+            }
+        }
+    }
+}
+
+
+// ---- long sequences (64 < L <= 288), split-fp16 arithmetic: K and V are split ONCE, at staging ---------------------------------
+// k_attention_hd64<.., true> keeps K and V in LDS as fp32 and every wave re-splits the rows it reads into fp16 pairs: at
+// L = 197 that is 7 x the conversion work (4 VALU instructions per element against 24 MFMAs per key tile: the kernel was
+// VALU-bound, 2.06 TB/s), its Q rows are fetched one 16-byte piece per lane and line (64 lines per load instruction) and its
+// output leaves as 32-byte pieces of 32 rows.  Here:
+//   * the loading thread converts its K / V chunk to fp16 hi / lo planes before the LDS store (same bytes in LDS, no
+//     conversion in the loop); K planes are read row-wise (ds_read_b128: 8 d of one key), V planes are read TRANSPOSED by
+//     ds_read_b64_tr_b16 (4 keys x 16 d per 16-lane group, delivered key-major per d column: the V^T operand of the P.V
+//     product without a transposed store and without 2-byte gathers);
+//   * 128-byte rows, no padding (four planes of 288 rows = 147 KB), conflict-free by XOR: K chunk ^= (row / 2) % 8, V 64-byte
+//     half ^= (row / 2) % 2 (the four rows of a transposed block then cover all 64 banks once per 32-lane half);
+//   * Q goes through LDS once (fp32, in the V region before V is stored): 16 lanes fetch one token's 256 B, every lane picks up
+//     its own half row; the output tile goes back through the K region and leaves 256 B (or the split operand's 128-byte
+//     segments) per 16 / 8 lanes.
+// Arithmetic, summation order and therefore the bits are those of k_attention_hd64<SPLIT, true> (unscaled lo parts, one
+// accumulator per product, probabilities carried with a factor 2^10): tests compare the two kernels for equality.
+typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) fp16x4v lds_fp16x4v;
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split4u(const float4 v, h16x4 &hi, h16x4 &lo) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 hh = (_Float16)x[e];
+        hi[e] = hh; lo[e] = (_Float16)(x[e] - (float)hh);
+    }
+}
+
+// Key blocks: for 6 <= TJ <= 8 (L = 161 .. 256, e.g. the 197 tokens of ViT-B/16) the keys are staged in TWO blocks of ceil(TJ / 2)
+// tiles: the four planes then take 64 KB instead of 115 KB at L = 197, so that TWO workgroups share a CU and one's staging (global
+// loads, conversions, barriers) runs under the other's MFMA loop: 239 -> 214 us per 256 x 197 x 12 batch (2.9 TB/s; the first
+// general kernel: 301 us).  PMC at that point (tools/r4_attn_pmc.sh): waves wait half their cycles (SQ_WAIT_ANY / SQ_WAVE_CYCLES
+// 0.50), the vector ALU is busy 0.48 of the time and the matrix pipe 0.24 -- the softmax's vector work per key tile (exponentials,
+// the fp16 split of the probabilities) is now what the MFMAs wait for.
+template <int SPLIT>
+__global__ __launch_bounds__(576, 4) void k_attention_hd64_f16(const float *__restrict__ qkv, int L, int H, int causal,
+                                                            float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    const int TJ = (L + 31) >> 5, Lp = 32 * TJ;
+    const int TB = (TJ <= 5 || TJ > 8) ? TJ : (TJ + 1) >> 1; // key tiles per block (TJ = 9: two workgroups of nine waves do not fit a CU's
+                                                             // registers -- five waves on a SIMD at 128 each --, so the split would only add barriers)
+    const int KB = 32 * TB;                                   // keys per block
+    char *sKh = smem_c, *sKl = smem_c + KB * 128, *sVh = smem_c + 2 * KB * 128, *sVl = smem_c + 3 * KB * 128;
+    float *sQ = reinterpret_cast<float *>(smem_c);           // fp32 [Lp][64] staging of Q (before the first block) and of the output
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int64_t b = blockIdx.x / H;
+    const int head = blockIdx.x % H;
+    const int64_t tok_stride = (int64_t)3 * H * HD;
+    const float *base = qkv + b * L * tok_stride + head * HD;
+    const int nthr = 64 * TJ;                                // = blockDim.x
+    // fp32 staging image: 256-byte rows, 16-byte chunk c of row r at chunk c ^ (r % 16) (conflict-free row-per-lane reads)
+    auto stage_off = [](int r, int c) { return r * 64 + 4 * (c ^ (r & 15)); };
+    const unsigned tok_bytes = (unsigned)(3 * H * HD * 4);     // (L <= 288 tokens of <= 2^20 bytes: offsets inside a head's slice fit 32 bits)
+    constexpr int CH = 5;                                    // 16-byte chunks per thread and staging pass: one pass covers a key block
+                                                             // when there are two (32 TB 16 / (64 TJ) <= 4.6), two passes the single block of TJ <= 5
+    // a key block -> fp16 hi / lo planes: K and V rows [kb KB, kb KB + KB) of the head (zero beyond L), rows local to the block
+    auto stage_block = [&](int kb) {
+        for (int p0 = 0; p0 < KB * 16; p0 += CH * nthr) {
+            // K, then V (one operand's chunks in registers at a time: with both, the second block's staging -- accumulators
+            // and query fragments live -- spilled)
+#pragma unroll
+            for (int kv = 0; kv < 2; ++kv) {
+                float4 reg[CH];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const int id = p0 + tid + i * nthr, r = kb * KB + (id >> 4), c = id & 15;
+                    reg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    // (wave-uniform 64-bit base + 32-bit byte offset: one address register per chunk)
+                    if (id < KB * 16 && r < L)
+                        reg[i] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base + (kv + 1) * H * HD) + ((unsigned)r * tok_bytes + 16u * (unsigned)c));
+                }
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const int id = p0 + tid + i * nthr, r = id >> 4, c = id & 15;
+                    if (id < KB * 16) {
+                        h16x4 hi, lo;
+                        split4u(reg[i], hi, lo);
+                        const int o = kv == 0 ? r * 128 + ((((c >> 1) ^ ((r >> 1) & 7))) << 4) + (c & 1) * 8
+                                              : r * 128 + ((c * 8) ^ (((r >> 1) & 1) << 6));
+                        *reinterpret_cast<h16x4 *>((kv == 0 ? sKh : sVh) + o) = hi;
+                        *reinterpret_cast<h16x4 *>((kv == 0 ? sKl : sVl) + o) = lo;
+                    }
+                }
+            }
+        }
+    };
+    // ---- Q through LDS: 16 lanes fetch one token's 256 B, every lane then picks up its own half row ----
+    {
+        float4 qreg[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int id = tid + i * nthr, r = id >> 4, c = id & 15;
+            qreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < L) qreg[i] = *reinterpret_cast<const float4 *>(base + (int64_t)r * tok_stride + 4 * c);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int id = tid + i * nthr, r = id >> 4, c = id & 15;
+            *reinterpret_cast<float4 *>(&sQ[stage_off(r, c)]) = qreg[i];
+        }
+    }
+    __syncthreads();
+    const int qi = 32 * wave + l31;
+    h16x8 qh[4], ql[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float4 a = *reinterpret_cast<const float4 *>(&sQ[stage_off(qi, 8 * h + 2 * u)]);
+        const float4 c4 = *reinterpret_cast<const float4 *>(&sQ[stage_off(qi, 8 * h + 2 * u + 1)]);
+        const float qv[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+        split8u(qv, qh[u], ql[u]);
+    }
+    __syncthreads();                                          // every lane has its query: the buffer now takes the first key block
+    stage_block(0);
+    __syncthreads();
+
+    // per-lane address parts.  K: row l31 of the key tile, chunk (4h + u) ^ ((l31 / 2) % 8).  V (transposed read, lane 4q + p of
+    // the 16-lane group g supplies row q, columns 4p .. 4p+3 of the block): row 4h + q of the 8-key group, columns 16 (g % 2) + 4p
+    // (+ 32 for the second output half: byte 64 = one XOR), 64-byte half ^= (row / 2) % 2 = q / 2
+    int koff[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) koff[u] = l31 * 128 + (((4 * h + u) ^ ((l31 >> 1) & 7)) << 4);
+    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int voff0 = (4 * (g16 >> 1) + q4) * 128 + (((16 * (g16 & 1) + 4 * p4) * 2) ^ ((q4 >> 1) << 6));
+    const int voff1 = voff0 ^ 64;
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c_exp = 0.125f * 1.44269504088896340736f;     // 1/sqrt(64) * log2(e)
+    const int tj_end = causal ? (wave + 1 < TJ ? wave + 1 : TJ) : TJ;
+    for (int kb = 0; kb * TB < TJ; ++kb) {
+        if (kb > 0) {                                         // the next key block takes the buffer (every thread stages, every wave waits)
+            __syncthreads();                                  // all waves are past their last read of the previous block
+            stage_block(kb);
+            __syncthreads();
+        }
+        const int t_hi = (kb + 1) * TB < tj_end ? (kb + 1) * TB : tj_end;
+        for (int tj = kb * TB; tj < t_hi; ++tj) {
+            const int tl = tj - kb * TB;                      // tile inside the block
+            f32x16 s;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = 0.f;
+            const char *kh_t = sKh + tl * 4096, *kl_t = sKl + tl * 4096;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const h16x8 kh = *reinterpret_cast<const h16x8 *>(kh_t + koff[u]);
+                const h16x8 kl = *reinterpret_cast<const h16x8 *>(kl_t + koff[u]);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[u], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[u], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[u], s, 0, 0, 0);
+            }
+            // masks only where a tile can hold a masked key: the last tile (keys >= L) and, causal, the wave's diagonal tile
+            // (wave-uniform branch; the loop runs with every lane active, as the transposed reads below require)
+            if (32 * tj + 32 > L || (causal && tj == wave)) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int j = 32 * tj + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const bool ok = j < L && (!causal || j <= qi);
+                    s[e] = ok ? s[e] : -INFINITY;
+                }
+            }
+            float mt = s[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mt = fmaxf(mt, s[e]);
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float m_new = fmaxf(m_run, mt);
+            const float alpha = exp2f((m_run - m_new) * c_exp);
+            float lt = 0.f;
+            // (v_exp_f32 directly: arguments are <= 10, a result below 2^-126 -- p < 2^-136 -- may come out as 0 instead of a
+            // denormal, which neither the sums, >= 2^10, nor the fp16 parts of p can see)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                s[e] = __builtin_amdgcn_exp2f((s[e] - m_new) * c_exp + 10.0f);     // probabilities x 2^10 (l_run carries the factor, 1 / l_run removes it)
+                lt += s[e];
+            }
+            lt += __shfl_xor(lt, 32);
+            l_run = l_run * alpha + lt;
+            m_run = m_new;
+            if (!__all(alpha == 1.0f)) {                      // the running maximum moved for some query of the wave
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+            }
+            const char *vh_t = sVh + tl * 4096, *vl_t = sVl + tl * 4096;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float pv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pv[i] = s[8 * t + i];
+                h16x8 ph, pl;
+                split8u(pv, ph, pl);
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int vo = (half ? voff1 : voff0) + t * 2048;
+                    // k-slots 0-3 = keys 16t + 4h + 0..3, k-slots 4-7 = keys 16t + 8 + 4h + 0..3 of the tile, at d = 32 half + l31
+                    const fp16x4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4v *)(vh_t + vo));
+                    const fp16x4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4v *)(vh_t + vo + 1024));
+                    const fp16x4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4v *)(vl_t + vo));
+                    const fp16x4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4v *)(vl_t + vo + 1024));
+                    h16x8 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        vh[e] = (_Float16)a0[e]; vh[4 + e] = (_Float16)a1[e];
+                        vl[e] = (_Float16)b0[e]; vl[4 + e] = (_Float16)b1[e];
+                    }
+                    if (half == 0) {
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o0, 0, 0, 0);
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o0, 0, 0, 0);
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o0, 0, 0, 0);
+                    } else {
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o1, 0, 0, 0);
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o1, 0, 0, 0);
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o1, 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // the output tile goes through the buffer (every wave is past its last key tile)
+    float *sO = sQ;
+    __syncthreads();
+    {
+        const float inv = 1.0f / l_run;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = 8 * g + 4 * h;                     // columns c0 .. c0+3 (and 32 + c0 ..) of query qi
+            *reinterpret_cast<float4 *>(&sO[stage_off(qi, c0 >> 2)]) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            *reinterpret_cast<float4 *>(&sO[stage_off(qi, 8 + (c0 >> 2))]) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                             // 8 lanes per token row, 8 values each: 16-byte stores in every form
+        const int id = tid + i * nthr;
+        const int r = SPLIT == 3 ? id % Lp : id >> 3, c8 = SPLIT == 3 ? id / Lp : id & 7;
+        if (r < L) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(&sO[stage_off(r, 2 * c8)]);
+            const float4 v1 = *reinterpret_cast<const float4 *>(&sO[stage_off(r, 2 * c8 + 1)]);
+            if (SPLIT == 3)
+                lemon_split::store_tiled8<lemon_split::TILE_A_ROWS, false>(reinterpret_cast<unsigned short *>(out), b * L + r, H * HD, head * (HD / 8) + c8, v0, v1);
+            else if (SPLIT)
+                lemon_split::store_split8<(SPLIT == 1 || SPLIT == 2) ? SPLIT : 1, false>(reinterpret_cast<unsigned short *>(out) + (b * L + r) * lemon_split::split_segments(SPLIT == 3 ? 2 : SPLIT) * (int64_t)(H * HD), H * HD,
+                                                 head * (HD / 8) + c8, v0, v1);
+            else {
+                float *dst = out + ((b * L + r) * H + head) * HD + 8 * c8;
+                *reinterpret_cast<float4 *>(dst) = v0;
+                *reinterpret_cast<float4 *>(dst + 4) = v1;
             }
         }
     }
@@ -468,6 +726,20 @@ __global__ __launch_bounds__(64 * TJ, 3) void k_attention_hd64_short(const float
 
 }  // namespace
 
+// Arithmetic of the two products: 1 = split products on the fp16 matrix cores (q, k, v and the probabilities carried as fp16
+// pairs: inputs must stay inside +-65 504, see include/lemon_hip.h), 0 = v_mfma_f32_32x32x2_f32 (no range limit).
+// Process-wide, set by lemon_attention_set_f16 (the host mirror selects it per GEMM mode); $LEMON_ATTN_F16=0 starts with 0.
+static int g_attn_f16 = [] { const char *e = getenv("LEMON_ATTN_F16"); return (e && e[0] == '0') ? 0 : 1; }();
+
+static int g_attn_old_general = 0;      // lemon_attention_set_f16(2): fp16 arithmetic with the FIRST general kernel (tests: bit equality)
+
+extern "C" int lemon_attention_set_f16(int on) {
+    g_attn_old_general = on == 2;
+    const int prev = g_attn_f16;
+    g_attn_f16 = on ? 1 : 0;
+    return prev;
+}
+
 template <int SPLIT>
 static int attention_impl(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
                           int causal, float *out_dev, void *stream) {
@@ -482,7 +754,7 @@ static int attention_impl(const float *qkv_dev, int64_t batch, int seq_len, int 
     static const bool short_off = [] { const char *e = getenv("LEMON_ATTN_SHORT"); return e && e[0] == '0'; }();   // tuning knob
     const dim3 grid((unsigned)(batch * heads));
     if (tj <= 2 && !short_off) {
-        static const bool f16_off = [] { const char *e = getenv("LEMON_ATTN_F16"); return e && e[0] == '0'; }();      // A/B knob
+        const bool f16_off = g_attn_f16 == 0;
         if (f16_off) {
             if (tj == 1) hipLaunchKernelGGL((k_attention_hd64_short<1, SPLIT, false>), grid, dim3(64), 0, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
             else         hipLaunchKernelGGL((k_attention_hd64_short<2, SPLIT, false>), grid, dim3(128), 0, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
@@ -493,16 +765,38 @@ static int attention_impl(const float *qkv_dev, int64_t batch, int seq_len, int 
         LEMON_HIP_CHECK(hipGetLastError());
         return LEMON_OK;
     }
-    const size_t lds = (size_t)2 * 32 * tj * PITCH * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attention_hd64<SPLIT, true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attention_hd64<SPLIT, false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    // 64 < L <= 288.  Split-fp16 arithmetic: the kernel that splits K and V once at staging (k_attention_hd64_f16);
+    // LEMON_ATTN_GENERAL=old keeps the first version (fp32 K / V in LDS, re-split by every wave) for A/B runs and the equality test
+    static const bool old_general = [] { const char *e = getenv("LEMON_ATTN_GENERAL"); return e && !strcmp(e, "old"); }();
+    const bool staged = g_attn_f16 != 0 && !old_general && !g_attn_old_general;
+    // staged kernel: four planes of one key block (ceil(tj / 2) tiles when tj > 5), but never less than the fp32 [32 tj][64]
+    // image Q and the output pass through
+    const int tb = (tj <= 5 || tj > 8) ? tj : (tj + 1) / 2;
+    const size_t lds_staged = std::max((size_t)4 * 32 * tb * 128, (size_t)32 * tj * 256);
+    const size_t lds = staged ? lds_staged : (size_t)2 * 32 * tj * PITCH * sizeof(float);
+    {   // the attribute is per DEVICE (and per instantiation): one flag per device index, under a lock
+        static std::mutex mu;
+        static bool attr_set[64] = {};
+        int dev = 0;
+        LEMON_HIP_CHECK(hipGetDevice(&dev));
+        LEMON_REQUIRE(dev >= 0 && dev < 64, "device index");
+        std::lock_guard<std::mutex> lock(mu);
+        if (!attr_set[dev]) {
+            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attention_hd64<SPLIT, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attention_hd64<SPLIT, false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attention_hd64_f16<SPLIT>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set[dev] = true;
+        }
     }
-    static const bool f16_off_g = [] { const char *e = getenv("LEMON_ATTN_F16"); return e && e[0] == '0'; }();
+    if (staged) {
+        hipLaunchKernelGGL((k_attention_hd64_f16<SPLIT>), grid, dim3(64 * tj), lds, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
+        LEMON_HIP_CHECK(hipGetLastError());
+        return LEMON_OK;
+    }
+    const bool f16_off_g = g_attn_f16 == 0;
     if (f16_off_g) hipLaunchKernelGGL((k_attention_hd64<SPLIT, false>), grid, dim3(64 * tj), lds, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
     else hipLaunchKernelGGL((k_attention_hd64<SPLIT, true>), grid, dim3(64 * tj), lds, (hipStream_t)stream, qkv_dev, seq_len, heads, causal, out_dev);
     LEMON_HIP_CHECK(hipGetLastError());

@@ -584,6 +584,13 @@ extern "C" int lemon_linear_f16x3t(const uint16_t *at_dev, const uint16_t *wt_de
     return LEMON_OK;
 }
 
+extern "C" int lemon_linear_f16x3t_set_mfma(int shape) {
+    LEMON_REQUIRE(shape == 0 || shape == 16 || shape == 32, "shape: 16, 32 or 0 (the default: $LEMON_GEMM_MFMA, else 16)");
+    const int prev = mfma_shape();
+    g_mfma_shape = shape;
+    return prev;
+}
+
 extern "C" int lemon_linear_f16x3t_set_profiling(int on) {
     std::lock_guard<std::mutex> lock(g_attr_mu);
     if (on && g_prof.ev.empty()) {

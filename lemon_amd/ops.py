@@ -154,6 +154,42 @@ def linear(x, weight, bias=None, residual=None, act=None, alpha=1.0):
 _SCHEMES = {"bf16x6": (torch.bfloat16, 6), "f16x3": (torch.float16, 3)}
 
 
+_forced_gemm_mode = None          # set by gemm_mode_forced(): overrides $LEMON_GEMM for the calls inside the context
+
+
+class gemm_mode_forced:
+    """with gemm_mode_forced("bf16x6"): ... -- the GEMM mode of the towers for the calls inside, whatever $LEMON_GEMM says
+    (pipeline.Embedder re-runs a micro-batch whose fp16 split operands overflowed with the range-free bf16 scheme)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        global _forced_gemm_mode
+        self.prev, _forced_gemm_mode = _forced_gemm_mode, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global _forced_gemm_mode
+        _forced_gemm_mode = self.prev
+        return False
+
+
+_attn_f16_state = None
+
+
+def select_attention_arithmetic(mode):
+    """The attention kernels' arithmetic follows the GEMM mode: split products on the fp16 matrix cores with 'f16x3' (inputs
+    must stay inside the fp16 range, like the GEMM operands of that mode), v_mfma_f32_32x32x2_f32 with 'bf16x6' (the mode whose
+    point is to have no range limit) and 'f32'.  $LEMON_ATTN_F16=0 keeps the fp32 form in every mode."""
+    global _attn_f16_state
+    import os
+    want = 1 if (mode == "f16x3" and os.environ.get("LEMON_ATTN_F16", "1") != "0") else 0
+    if want != _attn_f16_state:
+        _lib.load().lemon_attention_set_f16(want)
+        _attn_f16_state = want
+
+
 def gemm_mode():
     """How the four GEMMs of every transformer block run (LEMON_GEMM):
     'f16x3' (default): 2-way fp16 split operands, three cross products, one fp16 GEMM over 3k -- the fp32 GEMM's accuracy
@@ -162,7 +198,7 @@ def gemm_mode():
         fp32 accumulation bounds both --, no fp16 range limit on the operands, 1.4x faster than fp32);
     'f32': every GEMM on the fp32 matrix cores."""
     import os
-    v = os.environ.get("LEMON_GEMM", DEFAULT_GEMM_MODE).lower()
+    v = (_forced_gemm_mode or os.environ.get("LEMON_GEMM", DEFAULT_GEMM_MODE)).lower()
     if v in ("f32", "fp32", "0"):
         return "f32"
     if v in ("split", "bf16x6"):

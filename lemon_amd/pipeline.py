@@ -98,15 +98,24 @@ def all_gather_rows(t, n_total, group=None, log=None, name="rows", force=False):
 
 
 class Embedder:
-    """HOT LOOP 1/2 of run_lemon.py (:137-161, :202-233) without the D2H copies."""
+    """HOT LOOP 1/2 of run_lemon.py (:137-161, :202-233) without the D2H copies.
 
-    def __init__(self, model, device, batch_size=128, dtype=torch.float32, text_dedup=False, text_batch_size=None):
+    Range fallback.  The default GEMM mode (LEMON_GEMM=f16x3) carries the fp32 operands of the block GEMMs (and q, k, v of
+    the attention kernels) as fp16 pairs: a value beyond +-65 504 turns into inf / NaN there instead of being clamped.  Every
+    micro-batch leaves a device flag "not finite"; the flags of one embed_images / embed_texts call are read with ONE host
+    transfer after all its micro-batches are queued, and a flagged micro-batch is embedded again with the range-free scheme
+    (3-way bf16 split GEMMs, fp32 attention: the same fp32-equivalent contract) -- counted in `fallback_batches`, reported by
+    the CLI.  What is still not finite after that is not a range problem and raises in raise_if_nonfinite()."""
+
+    def __init__(self, model, device, batch_size=128, dtype=torch.float32, text_dedup=False, text_batch_size=None, range_fallback=True):
         self.model = model.eval().to(device=device, dtype=dtype)
         self.device, self.batch_size, self.dtype, self.text_dedup = device, batch_size, dtype, text_dedup
         # prompts are ~7x shorter than the image token sequence: a 4x larger text micro-batch keeps the
         # text tower's GEMMs at the image tower's row count (and efficiency)
         self.text_batch_size = text_batch_size or 4 * batch_size
         self._nonfinite = None        # device flag: some embedding so far was not finite (raise_if_nonfinite)
+        self.range_fallback = range_fallback
+        self.fallback_batches = 0     # micro-batches re-embedded with bf16x6 operands because fp16 overflowed
 
     def _note(self, e):
         if e.is_cuda and e.shape[0]:
@@ -115,13 +124,24 @@ class Embedder:
         return e
 
     def raise_if_nonfinite(self):
-        """One host read for everything embedded since the last call.  The default GEMM mode (LEMON_GEMM=f16x3) carries the fp32
-        operands of the block GEMMs as fp16 pairs: an activation beyond +-65 504 turns into inf / NaN there instead of being
-        clamped, and this is where it is reported."""
+        """One host read for everything embedded since the last call."""
         flag, self._nonfinite = self._nonfinite, None
         if flag is not None and bool(flag.item()):
-            raise FloatingPointError(f"non-finite embeddings (LEMON_GEMM={ops.gemm_mode()}): with f16x3 an activation left the fp16 "
-                                     "range of the split GEMM operands -- rerun with LEMON_GEMM=bf16x6 (no range limit) or f32")
+            how = ("the range fallback is off (range_fallback=False): an activation left the fp16 range of the split operands -- "
+                   "rerun with LEMON_GEMM=bf16x6 (no range limit) or f32" if (ops.gemm_mode() == "f16x3" and not self.range_fallback)
+                   else "also with range-free operands (bf16x6 GEMMs, fp32 attention): the weights or inputs themselves produce inf / NaN")
+            raise FloatingPointError(f"non-finite embeddings (LEMON_GEMM={ops.gemm_mode()}): {how}")
+
+    def _run_batches(self, spans, run_one):
+        """[run_one(lo, hi) for the spans], with the fp16-range fallback of the class docstring."""
+        outs = [run_one(lo, hi).float() for lo, hi in spans]
+        if outs and outs[0].is_cuda and self.range_fallback and ops.gemm_mode() == "f16x3":
+            bad = torch.stack([~torch.isfinite(e).all() for e in outs]).cpu()          # the call's one host read
+            for j in bad.nonzero().flatten().tolist():
+                with ops.gemm_mode_forced("bf16x6"):
+                    outs[j] = run_one(*spans[j]).float()
+                self.fallback_batches += 1
+        return outs
 
     @torch.no_grad()
     def embed_images(self, pixel_values):
@@ -130,12 +150,15 @@ class Embedder:
         raw = pixel_values.dtype == torch.uint8
         if raw:
             from .data import gpu_transform_batch
-        outs = []
-        for i in range(0, pixel_values.shape[0], self.batch_size):
-            px = pixel_values[i:i + self.batch_size].to(self.device, non_blocking=True)
+
+        def one(lo, hi):
+            px = pixel_values[lo:hi].to(self.device, non_blocking=True)
             if raw:
                 px = gpu_transform_batch(px, self.model.cfg.image_size, patch=self.model.cfg.patch_size)
-            outs.append(self.model.encode_image(px).float())
+            return self.model.encode_image(px)
+
+        n = pixel_values.shape[0]
+        outs = self._run_batches([(i, min(n, i + self.batch_size)) for i in range(0, n, self.batch_size)], one)
         e = torch.cat(outs) if outs else torch.empty((0, self.model.cfg.embed_dim), device=self.device)
         return ops.normalize_vectors(self._note(e)) if e.shape[0] else e              # :164 / :233
 
@@ -158,14 +181,15 @@ class Embedder:
         tower = getattr(self.model, "text", None)
         if eot is None and hasattr(tower, "seq_len_for"):
             eot = ids.argmax(dim=-1).cpu()
-        outs = []
-        for i in range(0, ids.shape[0], self.text_batch_size):
-            if eot is not None and hasattr(tower, "seq_len_for"):
-                L = tower.seq_len_for(int(eot[i:i + self.text_batch_size].max()))
-                outs.append(self.model.encode_text(ids[i:i + self.text_batch_size], seq_len=L).float())
-            else:
-                outs.append(self.model.encode_text(ids[i:i + self.text_batch_size]).float())
-        return torch.cat(outs)
+        bucketed = eot is not None and hasattr(tower, "seq_len_for")
+
+        def one(lo, hi):
+            if bucketed:
+                return self.model.encode_text(ids[lo:hi], seq_len=tower.seq_len_for(int(eot[lo:hi].max())))
+            return self.model.encode_text(ids[lo:hi])
+
+        n, tb = ids.shape[0], self.text_batch_size
+        return torch.cat(self._run_batches([(i, min(n, i + tb)) for i in range(0, n, tb)], one))
 
 
 def score_splits(db, splits, k, hparams=None, discrete=False):

@@ -198,3 +198,44 @@ def test_hand_issued_asm_is_left_alone_by_the_compiler(src, kernels):
         for n in hits:
             problems = _check_asm_discipline(n, bodies[n])
             assert not problems, "\n".join(problems[:10])
+
+
+# ---- k_attention_hd64_f16 (64 < L <= 288): built for four waves per SIMD (two workgroups of seven waves per CU) ----------------
+# hipcc keeps within 128 registers by spilling a few per-thread staging addresses AROUND the key-tile loops (written once before
+# the first loop, read back once at the second key block's staging): tolerated -- what is asserted is that no scratch access
+# sits inside a loop that issues MFMAs, and that the register count really allows the fourth wave.
+def _loops_with_mfma_and_scratch(lines):
+    header_of, kinds = {}, {}
+    cur = None
+    for raw in lines:
+        m = re.match(r"^(?:\.LBB\d+_\d+:|; %bb\.\d+:)\s*;\s*(?:=>This (?:Inner )?Loop Header: Depth=\d+|  in Loop: Header=(BB\d+_\d+) Depth=\d+)", raw)
+        lab = re.match(r"^(?:\.L(BB\d+_\d+):|; %bb\.\d+:)", raw)
+        if lab:
+            if "Loop Header" in raw and "in Loop" not in raw:
+                cur = lab.group(1)
+            elif m and m.group(1):
+                cur = m.group(1)
+            else:
+                cur = None
+            continue
+        if cur is None:
+            continue
+        ins = raw.split(";")[0].strip()
+        if ins.startswith("v_mfma"):
+            kinds.setdefault(cur, set()).add("mfma")
+        if ins.startswith("scratch_"):
+            kinds.setdefault(cur, set()).add("scratch")
+    return [h for h, k in kinds.items() if {"mfma", "scratch"} <= k]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_long_sequence_attention_kernel_fits_four_waves_and_keeps_scratch_out_of_its_loops():
+    meta = _kernel_meta("attention.hip")
+    bodies = _kernel_bodies(_kernel_asm("attention.hip"))
+    hits = [n for n in meta if "k_attention_hd64_f16ILi" in n]
+    assert len(hits) == 4, sorted(meta)
+    for n in hits:
+        assert meta[n]["vgpr_count"] <= 128, (n, meta[n])
+        assert meta[n]["vgpr_spill_count"] <= 20, (n, meta[n])
+        assert _loops_with_mfma_and_scratch(bodies[n]) == [], n
+        assert sum("v_mfma" in ln for ln in bodies[n]) >= 24, n

@@ -180,9 +180,10 @@ def test_tier_b_cpu_hf_embeddings_vs_gpu_pipeline(hip, oracle):
     assert round(a_ref, 3) == round(a_gpu, 3) and a_ref > 0.6 and oracle.auroc(y, s_ref) > 0.55
 
 
-def test_f16x3_reports_activations_beyond_the_fp16_range(hip, monkeypatch):
-    # LEMON_GEMM=f16x3 carries the block GEMMs' fp32 operands as fp16 pairs: an activation beyond +-65 504 must end in an
-    # error (Embedder.raise_if_nonfinite), never in a clamped, silently different embedding; bf16x6 / f32 have no such limit
+def test_f16x3_reembeds_micro_batches_beyond_the_fp16_range(hip, monkeypatch):
+    # LEMON_GEMM=f16x3 carries the block GEMMs' fp32 operands as fp16 pairs: an activation beyond +-65 504 is never clamped into a
+    # silently different embedding -- the micro-batch is embedded again with range-free operands (bf16x6 GEMMs, fp32 attention) and
+    # counted; with the fallback off it ends in an error.  bf16x6 / f32 have no such limit.
     from lemon_amd.clip import ClipConfig, LemonCLIP
     from lemon_amd.pipeline import Embedder
     dev = torch.device("cuda:0")
@@ -190,22 +191,66 @@ def test_f16x3_reports_activations_beyond_the_fp16_range(hip, monkeypatch):
     model = LemonCLIP(ClipConfig.named("tiny")).eval()
     px = torch.randn(8, 3, 32, 32).to(dev)
     outs = {}
-    for scale, modes in ((1.0, (("f32", True), ("bf16x6", True), ("f16x3", True))), (3.0e6, (("f32", True), ("bf16x6", True), ("f16x3", False)))):
+    for scale in (1.0, 3.0e6):
         with torch.no_grad():
             model.vision.blocks[0].ln1.weight.fill_(scale)           # LayerNorm output ~ scale: 3e6 is beyond fp16
-        for mode, fine in modes:
+        for mode in ("f32", "bf16x6", "f16x3"):
             monkeypatch.setenv("LEMON_GEMM", mode)
             emb = Embedder(model, dev, batch_size=4)
             e = emb.embed_images(px)
-            if fine:
-                emb.raise_if_nonfinite()
-                assert bool(torch.isfinite(e).all())
-                outs[(scale, mode)] = e
-            else:
-                with pytest.raises(FloatingPointError, match="fp16 range"):
-                    emb.raise_if_nonfinite()
+            emb.raise_if_nonfinite()
+            assert bool(torch.isfinite(e).all())
+            assert emb.fallback_batches == (2 if (mode == "f16x3" and scale > 1.0) else 0), (mode, scale, emb.fallback_batches)
+            outs[(scale, mode)] = e
         assert (outs[(scale, "bf16x6")] - outs[(scale, "f32")]).abs().max() < 5e-6      # (unit-norm embeddings)
-    assert (outs[(1.0, "f16x3")] - outs[(1.0, "f32")]).abs().max() < 5e-6
+        assert (outs[(scale, "f16x3")] - outs[(scale, "f32")]).abs().max() < 5e-6
+    assert torch.equal(outs[(3.0e6, "f16x3")], outs[(3.0e6, "bf16x6")])                 # the re-embedded batches ARE bf16x6 batches
+    monkeypatch.setenv("LEMON_GEMM", "f16x3")
+    emb = Embedder(model, dev, batch_size=4, range_fallback=False)
+    emb.embed_images(px)
+    with pytest.raises(FloatingPointError, match="fp16 range"):
+        emb.raise_if_nonfinite()
+
+
+@pytest.mark.parametrize("L,H,causal", [(50, 12, False), (24, 8, True), (197, 12, False)])
+def test_attention_range_and_small_magnitudes_on_head_dim_64(hip, L, H, causal):
+    # the three attention kernels (one / two key tiles: short kernel; L > 64: general kernel) at head_dim 64, both arithmetic
+    # forms, against float64: (a) O(1) inputs, (b) q, k of magnitude 1e-3 (the general kernel's UNscaled lo parts keep 2^-25
+    # absolute), (c) v of magnitude 1e4 .. 6e4 (inside fp16) and (d) beyond the fp16 range: the fp16 form must go non-finite (loud), the
+    # fp32 form (lemon_attention_set_f16(0), what the f32 / bf16x6 GEMM modes select) must stay exact
+    from lemon_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(L * 31 + H)
+    B, W = 3, 64 * H
+
+    def ref(qkv):
+        q, k, v = qkv.double().view(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+        s = q @ k.transpose(-1, -2) / 8.0
+        if causal:
+            s = s.masked_fill(torch.triu(torch.ones(L, L, dtype=torch.bool), 1), float("-inf"))
+        return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, L, W)
+
+    cases = {"unit": (1.0, 1.0), "small_qk": (1e-3, 1.0), "large_v": (1.0, 1.0e4), "beyond_fp16": (1.0, 2.0e5)}
+    prev = lib.lemon_attention_set_f16(1)
+    try:
+        for name, (sq, sv) in cases.items():
+            qkv = torch.randn(B, L, 3 * W, generator=g)
+            qkv.view(B, L, 3, W)[:, :, :2] *= sq
+            qkv.view(B, L, 3, W)[:, :, 2] *= sv
+            if name == "large_v":
+                qkv.clamp_(-6.0e4, 6.0e4)                      # every value inside the fp16 range (65 504)
+            want = ref(qkv)
+            tol = 3e-6 * float(want.abs().max()) + 1e-12
+            for f16 in (1, 0):
+                lib.lemon_attention_set_f16(f16)
+                got = ops.attention(qkv.cuda(), H, causal).cpu().double()
+                if name == "beyond_fp16" and f16:
+                    assert not bool(torch.isfinite(got).all()), "fp16 attention must not clamp out-of-range inputs"
+                else:
+                    assert bool(torch.isfinite(got).all()) and float((got - want).abs().max()) <= tol, (name, f16, float((got - want).abs().max()), tol)
+    finally:
+        lib.lemon_attention_set_f16(prev)
+        ops._attn_f16_state = None
 
 
 def test_fused_mlp_and_library_mlp_give_the_same_embeddings(hip, monkeypatch):

@@ -530,6 +530,33 @@ def test_fused_attention_matches_float64_reference(hip, B, L, H, causal):
     assert (got - ref).abs().max() < 2e-5, (got - ref).abs().max()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L,H,causal", [(2, 65, 3, False), (3, 77, 8, True), (2, 197, 12, False), (1, 257, 16, False), (2, 288, 2, True),
+                                           (1, 256, 4, True), (2, 96, 1, False)])
+def test_long_sequence_attention_kernels_agree_bit_for_bit(hip, B, L, H, causal):
+    # 64 < L <= 288, split-fp16 arithmetic: k_attention_hd64_f16 (K and V split once at staging, V read transposed by
+    # ds_read_b64_tr_b16, Q and the output through LDS) against the first general kernel (lemon_attention_set_f16(2)): same
+    # arithmetic in the same order, so every output form must hold the same bits
+    from lemon_amd import _lib
+    from lemon_amd.ops import attention, attention_split, attention_t
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    qkv = (torch.randn(B, L, 3 * H * 64, generator=g) * 1.5).cuda()
+    prev = lib.lemon_attention_set_f16(1)
+    try:
+        new = (attention(qkv, H, causal), attention_split(qkv, H, causal, "f16x3"), attention_split(qkv, H, causal, "bf16x6"), attention_t(qkv, H, causal))
+        lib.lemon_attention_set_f16(2)
+        old = (attention(qkv, H, causal), attention_split(qkv, H, causal, "f16x3"), attention_split(qkv, H, causal, "bf16x6"), attention_t(qkv, H, causal))
+    finally:
+        lib.lemon_attention_set_f16(prev)
+    rows = (B * L + 127) // 128 * 128
+    for i, (a, b) in enumerate(zip(new, old)):
+        if i == 3:      # tile-major operand: rows beyond B*L are uninitialised in both
+            from lemon_amd.ops import unpack_act_t
+            a, b = unpack_act_t(a, B * L, H * 64), unpack_act_t(b, B * L, H * 64)
+        assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
+
+
 @pytest.mark.parametrize("B,L,H,causal", [(3, 50, 12, False), (5, 8, 8, True), (2, 77, 8, True), (2, 197, 12, False)])
 def test_attention_split_output_equals_split_of_attention(hip, B, L, H, causal):
     # lemon_attention_split3 / _f16x3 store the split of exactly the values lemon_attention_f32 stores (all three kernels)
@@ -814,6 +841,67 @@ def test_fused_mlp_in_the_hand_written_gemm_matches_float64(hip, m, width, mlp):
                            residual=xc, alpha=1.0 / (s * s2)).cpu().double()
     e_lib = float((lib - ref).abs().max())
     assert e_fused <= 2.0 * e_lib + 2e-6, (e_fused, e_lib)
+
+
+def _heavy_tailed(shape, g, typical, big, frac):
+    """N(0, typical) with a fraction `frac` of the entries multiplied up to magnitude ~big."""
+    x = torch.randn(shape, generator=g) * typical
+    mask = torch.rand(shape, generator=g) < frac
+    return torch.where(mask, torch.randn(shape, generator=g) * big, x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,width,mlp", [(700, 768, 3072), (300, 512, 2048)])
+def test_split_gemms_on_real_checkpoint_statistics(hip, m, width, mlp):
+    # what real CLIP checkpoints do to the f16x3 operands and the N(0, sigma) tests do not: rows that hold 1e3 next to 1e-4,
+    # LayerNorm gains up to 30 in a few channels, weight tensors whose largest entries are 1e3 x the typical one (so that
+    # wscale leaves the typical weight at 2^4 and its lo part near the fp16 subnormals), activations far below 2^-14 (fp16
+    # subnormal hi AND lo parts).  Bar: the split GEMM's error against float64 is no worse than 1.5 x the fp32 GEMM's on the
+    # same operands (relative to the largest output) -- through the library kernel (lemon_linear_f16x3) and through the
+    # hand-written one (LayerNorm -> fc1 -> QuickGELU -> fc2 on tile-major operands, both MFMA shapes).
+    from lemon_amd import ops
+    g = torch.Generator().manual_seed(m + width)
+    # ---- library kernel on raw heavy-tailed operands ----
+    x = _heavy_tailed((m, width), g, 1e-4, 1e3, 0.01)                      # 1e-4 typical, 1 % of the entries ~1e3
+    x[:, 5] = 1e-7 * torch.randn(m, generator=g)                          # a channel of fp16-subnormal magnitudes
+    w = _heavy_tailed((mlp, width), g, 0.02, 20.0, 0.0005)                  # max / typical ~ 1e3
+    ref = x.double() @ w.double().T
+    ws = ops.weight_scale_f16x3(w)
+    got = ops.linear_split(ops.split_operand(x.cuda(), "f16x3"), ops.split_operand(w.cuda(), "f16x3", weight=True, wscale=ws),
+                           alpha=1.0 / ws).cpu().double()
+    f32 = ops.linear(x.cuda(), w.cuda()).cpu().double()
+    scale = float(ref.abs().max())
+    e_split, e_f32 = float((got - ref).abs().max()) / scale, float((f32 - ref).abs().max()) / scale
+    assert torch.isfinite(got).all() and e_split <= 1.5 * e_f32 + 1e-6, (e_split, e_f32)
+    # ---- hand-written kernel: LayerNorm with outlier gains -> fc1 (heavy-tailed W1) -> QuickGELU -> fc2 (+ residual) ----
+    x = _heavy_tailed((m, width), g, 1.0, 40.0, 0.003)                       # outlier channels in the residual stream
+    lw = 1.0 + 0.1 * torch.randn(width, generator=g)
+    lw[torch.randperm(width, generator=g)[:6]] = torch.tensor([30.0, -25.0, 18.0, 30.0, 0.001, 1e-5])
+    lb = 0.1 * torch.randn(width, generator=g)
+    w1, b1 = _heavy_tailed((mlp, width), g, 0.03, 1.5, 0.0005), 0.1 * torch.randn(mlp, generator=g)
+    w2, b2 = _heavy_tailed((width, mlp), g, 0.02, 1.0, 0.0005), 0.1 * torch.randn(width, generator=g)
+    s = ops.QUICK_GELU_SCALE
+    xd = x.double()
+    xn = torch.nn.functional.layer_norm(xd, (width,), lw.double(), lb.double(), 1e-5)
+    z = xn @ w1.double().T + b1.double()
+    ref = (z * torch.sigmoid(s * z)) @ w2.double().T + b2.double() + xd
+    xc, lwc, lbc = x.cuda(), lw.cuda(), lb.cuda()
+    # the fp32 chain on the same inputs (lemon_layernorm_f32 + two lemon_linear_f32)
+    h32 = ops.linear(ops.layer_norm(xc, lwc, lbc, 1e-5), w1.cuda(), (b1 * s).cuda(), act="silu", alpha=s)
+    f32 = ops.linear(h32, w2.cuda(), b2.cuda(), residual=xc, alpha=1.0 / s).cpu().double()
+    scale = float(ref.abs().max())
+    e_f32 = float((f32 - ref).abs().max()) / scale
+    s1, s2 = ops.weight_scale_f16x3(w1), ops.weight_scale_f16x3(w2)
+    from lemon_amd import _lib
+    lib_ = _lib.load()
+    for shape in (16, 32):
+        assert lib_.lemon_linear_f16x3t_set_mfma(shape) >= 0
+        at = ops.layer_norm_t(xc, lwc, lbc, 1e-5)
+        ht = ops.linear_t(at, ops.pack_weight_t(w1.cuda(), s1), m, mlp, width, (b1 * s).cuda(), act="silu", alpha=s / s1)
+        got = ops.linear_t(ht, ops.pack_weight_t(w2.cuda(), s2), m, width, mlp, b2.cuda(), residual=xc, alpha=1.0 / (s * s2)).cpu().double()
+        e_hand = float((got - ref).abs().max()) / scale
+        assert torch.isfinite(got).all() and e_hand <= 1.5 * e_f32 + 1e-6, (shape, e_hand, e_f32)
+    lib_.lemon_linear_f16x3t_set_mfma(0)
 
 
 @pytest.mark.gpu
