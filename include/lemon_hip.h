@@ -103,6 +103,14 @@ int lemon_preprocess_u8(const uint8_t *img_dev, int64_t batch, int in_h, int in_
                         const int32_t *bnd_h_dev, int ks_h, const int32_t *kk_v_dev, const int32_t *bnd_v_dev,
                         int ks_v, int out_size, int max_rows_per_block, int rows_per_block,
                         const float *mean3_host, const float *std3_host, int patch, float *out_dev, void *stream);
+/* The same transform with the patch rows written as the tile-major fp16 split operand of lemon_linear_f16x3t (rows = batch *
+ * (out_size / patch)^2 padded to 128, k = 3 patch^2; patch % 4 == 0, 3 patch^2 % 16 == 0): the patch embedding then runs in the
+ * hand-written GEMM straight from this kernel's output -- no fp32 pixel tensor, no split pass.  Values are exactly the fp16 split
+ * (split3.hpp) of what lemon_preprocess_u8 writes. */
+int lemon_preprocess_u8_f16x3t(const uint8_t *img_dev, int64_t batch, int in_h, int in_w, const int32_t *kk_h_dev,
+                               const int32_t *bnd_h_dev, int ks_h, const int32_t *kk_v_dev, const int32_t *bnd_v_dev,
+                               int ks_v, int out_size, int max_rows_per_block, int rows_per_block,
+                               const float *mean3_host, const float *std3_host, int patch, uint16_t *outt_dev, void *stream);
 
 /* Multi-head self-attention of the CLIP towers, fused to one pass: the attention inside
  * encode_image / encode_text (lib/models/downstream_models.py:37-41 -> HF CLIPAttention; in-tree twin

@@ -258,7 +258,21 @@ class VisionTower(nn.Module):
         self.proj = nn.Linear(v.width, cfg.embed_dim, bias=False)
 
     def forward(self, pixel_values):
-        if pixel_values.dim() == 3:
+        if hasattr(pixel_values, "at"):
+            # data.PatchOperand: the patch rows are already the tile-major fp16 operand (lemon_preprocess_u8_f16x3t) -- the patch
+            # embedding runs in the hand-written GEMM, no fp32 pixel tensor and no split pass exist
+            from . import ops
+            po = pixel_values
+            w = self.patch.weight.reshape(self.patch.weight.shape[0], -1)
+            cache = self.__dict__.setdefault("_split_cache", {})
+            hit = cache.get(("patch", "tiled"))
+            if hit is None or hit[0] != (w.data_ptr(), self.patch.weight._version):
+                wscale = ops.weight_scale_f16x3(w)
+                hit = ((w.data_ptr(), self.patch.weight._version), ops.pack_weight_t(w.detach().contiguous(), wscale), 1.0 / wscale)
+                cache[("patch", "tiled")] = hit
+            x = ops.linear_t(po.at, hit[1], po.batch * po.n_patches, w.shape[0], po.k, alpha=hit[2],
+                             out_shape=(po.batch, po.n_patches, w.shape[0]))
+        elif pixel_values.dim() == 3:
             # patch-major input [B, nP, 3*P*P] (lemon_preprocess_u8 with patch=P): the stride == kernel
             # convolution is a plain GEMM with the flattened filter bank, no im2col and no MIOpen
             from . import ops

@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "common.hpp"
+#include "split3.hpp"
 
 namespace {
 
@@ -29,6 +30,7 @@ struct PreParams {
     float *out;              // [B, 3, S, S]
     int H, W, S, ks_h, ks_v, R, blocks_per_img;
     int patch;               // 0: NCHW; P > 0: patch-major [B, (S/P)^2, 3*P*P] (what the patch-embedding GEMM reads)
+    unsigned short *out_t;   // non-null (with P > 0): the same patch rows as the TILE-MAJOR fp16 split operand of lemon_linear_f16x3t
     float mean[3], stdv[3];
 };
 
@@ -109,6 +111,23 @@ __global__ __launch_bounds__(256) void k_preprocess_u8(PreParams p) {
             for (int c = 0; c < 3; ++c) {
                 const float *lut = s_lut + 256 * c;
                 const float4 v = make_float4(lut[pil_clip8(acc[c])], lut[pil_clip8(acc[3 + c])], lut[pil_clip8(acc[6 + c])], lut[pil_clip8(acc[9 + c])]);
+                if (p.out_t) {
+                    // the patch-embedding GEMM's activation operand (split3.hpp: tiled_off): four consecutive k of one patch row = 8 bytes
+                    // of its hi plane and 8 of its lo plane; no fp32 pixel tensor, no split pass
+                    const float x4[4] = {v.x, v.y, v.z, v.w};
+                    lemon_split::us4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        unsigned short a_, b_, c_;
+                        lemon_split::split2h<false>(x4[e], a_, b_, c_);
+                        hi[e] = a_; lo[e] = c_;
+                    }
+                    const int64_t o = lemon_split::tiled_off(lemon_split::TILE_A_ROWS, b * nP * nP + (int64_t)(y / P) * nP + x / P,
+                                                             c * P * P + (y % P) * P + (x % P), 0, 3 * P * P);
+                    *reinterpret_cast<lemon_split::us4 *>(p.out_t + o) = hi;
+                    *reinterpret_cast<lemon_split::us4 *>(p.out_t + o + lemon_split::TILE_A_ROWS * 16) = lo;
+                    continue;
+                }
                 // NCHW row, or the row's place inside its patches: out[b][py*nP+px][c*P*P + (y%P)*P + (x%P)]
                 float *dst = P ? p.out + (b * nP * nP + (int64_t)(y / P) * nP + x / P) * (3 * P * P) + c * P * P + (y % P) * P + (x % P)
                                : p.out + ((b * 3 + c) * S + y) * (int64_t)S + x;
@@ -137,11 +156,11 @@ __global__ __launch_bounds__(256) void k_preprocess_u8(PreParams p) {
 
 }  // namespace
 
-extern "C" int lemon_preprocess_u8(const uint8_t *img_dev, int64_t batch, int in_h, int in_w, const int32_t *kk_h_dev,
-                                   const int32_t *bnd_h_dev, int ks_h, const int32_t *kk_v_dev, const int32_t *bnd_v_dev,
-                                   int ks_v, int out_size, int max_rows_per_block, int rows_per_block,
-                                   const float *mean3_host, const float *std3_host, int patch, float *out_dev,
-                                   void *stream) {
+static int preprocess_impl(const uint8_t *img_dev, int64_t batch, int in_h, int in_w, const int32_t *kk_h_dev,
+                           const int32_t *bnd_h_dev, int ks_h, const int32_t *kk_v_dev, const int32_t *bnd_v_dev,
+                           int ks_v, int out_size, int max_rows_per_block, int rows_per_block,
+                           const float *mean3_host, const float *std3_host, int patch, float *out_dev, unsigned short *out_t,
+                           void *stream) {
     LEMON_REQUIRE(batch >= 0 && in_h > 0 && in_w > 0 && out_size > 0, "batch >= 0, sizes > 0");
     LEMON_REQUIRE(ks_h > 0 && ks_v > 0 && rows_per_block > 0 && max_rows_per_block > 0, "table geometry");
     LEMON_REQUIRE(patch >= 0 && (patch == 0 || out_size % patch == 0), "patch must divide out_size");
@@ -153,7 +172,7 @@ extern "C" int lemon_preprocess_u8(const uint8_t *img_dev, int64_t batch, int in
     LEMON_REQUIRE((size_t)max_rows_per_block * out_size * 3 <= 56 * 1024, "rows_per_block too large: the horizontal tile must fit 56 KB of LDS");
     PreParams p;
     p.img = img_dev; p.kk_h = kk_h_dev; p.bnd_h = bnd_h_dev; p.kk_v = kk_v_dev; p.bnd_v = bnd_v_dev; p.out = out_dev;
-    p.patch = patch;
+    p.patch = patch; p.out_t = out_t;
     p.H = in_h; p.W = in_w; p.S = out_size; p.ks_h = ks_h; p.ks_v = ks_v; p.R = rows_per_block;
     p.blocks_per_img = (out_size + rows_per_block - 1) / rows_per_block;
     for (int c = 0; c < 3; ++c) { p.mean[c] = mean3_host[c]; p.stdv[c] = std3_host[c]; }
@@ -162,4 +181,27 @@ extern "C" int lemon_preprocess_u8(const uint8_t *img_dev, int64_t batch, int in
     hipLaunchKernelGGL(k_preprocess_u8, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, p);
     LEMON_HIP_CHECK(hipGetLastError());
     return LEMON_OK;
+}
+
+extern "C" int lemon_preprocess_u8(const uint8_t *img_dev, int64_t batch, int in_h, int in_w, const int32_t *kk_h_dev,
+                                   const int32_t *bnd_h_dev, int ks_h, const int32_t *kk_v_dev, const int32_t *bnd_v_dev,
+                                   int ks_v, int out_size, int max_rows_per_block, int rows_per_block,
+                                   const float *mean3_host, const float *std3_host, int patch, float *out_dev,
+                                   void *stream) {
+    return preprocess_impl(img_dev, batch, in_h, in_w, kk_h_dev, bnd_h_dev, ks_h, kk_v_dev, bnd_v_dev, ks_v, out_size, max_rows_per_block,
+                           rows_per_block, mean3_host, std3_host, patch, out_dev, nullptr, stream);
+}
+
+// ... with the patch rows written as the tile-major fp16 split operand of lemon_linear_f16x3t (rows = batch * (out_size / patch)^2,
+// k = 3 patch^2): the patch embedding then runs in the hand-written GEMM straight from this kernel's output
+extern "C" int lemon_preprocess_u8_f16x3t(const uint8_t *img_dev, int64_t batch, int in_h, int in_w, const int32_t *kk_h_dev,
+                                          const int32_t *bnd_h_dev, int ks_h, const int32_t *kk_v_dev, const int32_t *bnd_v_dev,
+                                          int ks_v, int out_size, int max_rows_per_block, int rows_per_block,
+                                          const float *mean3_host, const float *std3_host, int patch, uint16_t *outt_dev,
+                                          void *stream) {
+    LEMON_REQUIRE(patch > 0 && patch % 4 == 0 && out_size % 4 == 0 && (3 * patch * patch) % 16 == 0,
+                  "patch a positive multiple of 4 with 3 patch^2 a multiple of 16 (the operand's k16 steps)");
+    LEMON_REQUIRE(outt_dev != nullptr, "null pointer");
+    return preprocess_impl(img_dev, batch, in_h, in_w, kk_h_dev, bnd_h_dev, ks_h, kk_v_dev, bnd_v_dev, ks_v, out_size, max_rows_per_block,
+                           rows_per_block, mean3_host, std3_host, patch, reinterpret_cast<float *>(outt_dev), outt_dev, stream);
 }

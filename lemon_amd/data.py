@@ -119,10 +119,24 @@ def _gpu_transform_plan(h, w, size, device_index):
                 max_rows=max(spans), rows_per_block=rows_per_block)
 
 
-def gpu_transform_batch(images_u8, size=224, patch=0):
+class PatchOperand:
+    """The patch rows of a preprocessed image batch as the tile-major fp16 split operand of lemon_linear_f16x3t
+    (lemon_preprocess_u8_f16x3t): `at` flat fp16, rows = batch * n_patches (padded to 128), k = 3 * patch^2."""
+
+    def __init__(self, at, batch, n_patches, k):
+        self.at, self.batch, self.n_patches, self.k = at, batch, n_patches, k
+        self.is_cuda, self.device = True, at.device
+
+
+def patch_operand_supported(patch, size=224):
+    return patch > 0 and patch % 4 == 0 and size % 4 == 0 and (3 * patch * patch) % 32 == 0
+
+
+def gpu_transform_batch(images_u8, size=224, patch=0, operand=False):
     """generic_transform for a uint8 CUDA batch [B,H,W,3] in one HIP kernel (lemon_preprocess_u8):
     -> float32 [B,3,size,size], bit-identical to the PIL + torch pipeline; with patch=P the same values
-    in patch-major order [B, (size/P)^2, 3*P*P] (the ViT patch embedding then is one GEMM)."""
+    in patch-major order [B, (size/P)^2, 3*P*P] (the ViT patch embedding then is one GEMM); with operand=True (and
+    patch_operand_supported(P)) a PatchOperand: the same rows already split for the hand-written GEMM."""
     import ctypes
     from . import _lib
     from .ops import ptr, stream_ptr
@@ -130,11 +144,22 @@ def gpu_transform_batch(images_u8, size=224, patch=0):
     x = images_u8.contiguous()
     B, H, W, _ = x.shape
     plan = _gpu_transform_plan(H, W, size, x.device.index or 0)
-    out = torch.empty((B, 3, size, size) if not patch else (B, (size // patch) ** 2, 3 * patch * patch),
-                      dtype=torch.float32, device=x.device)
     mean = (ctypes.c_float * 3)(*[float(np.float32(v)) for v in ds.CLIP_MEAN])
     std = (ctypes.c_float * 3)(*[float(np.float32(v)) for v in ds.CLIP_STD])
     lib = _lib.load()
+    if operand:
+        assert patch_operand_supported(patch, size)
+        nP, K = (size // patch) ** 2, 3 * patch * patch
+        rows = (B * nP + 127) // 128 * 128
+        at = torch.empty((rows * K * 2,), dtype=torch.float16, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.lemon_preprocess_u8_f16x3t(ptr(x), B, H, W, ptr(plan["kk_h"]), ptr(plan["b_h"]), plan["ks_h"],
+                                                      ptr(plan["kk_v"]), ptr(plan["b_v"]), plan["ks_v"], size, plan["max_rows"],
+                                                      plan["rows_per_block"], mean, std, int(patch), ptr(at), stream_ptr(x.device)),
+                       "lemon_preprocess_u8_f16x3t")
+        return PatchOperand(at, B, nP, K)
+    out = torch.empty((B, 3, size, size) if not patch else (B, (size // patch) ** 2, 3 * patch * patch),
+                      dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(lib.lemon_preprocess_u8(ptr(x), B, H, W, ptr(plan["kk_h"]), ptr(plan["b_h"]), plan["ks_h"],
                                            ptr(plan["kk_v"]), ptr(plan["b_v"]), plan["ks_v"], size, plan["max_rows"],

@@ -149,12 +149,17 @@ class Embedder:
         generic_transform runs on the GPU per micro-batch (lemon_preprocess_u8, lib/datasets/utils.py:159-170)."""
         raw = pixel_values.dtype == torch.uint8
         if raw:
-            from .data import gpu_transform_batch
+            from .data import gpu_transform_batch, patch_operand_supported
 
         def one(lo, hi):
             px = pixel_values[lo:hi].to(self.device, non_blocking=True)
             if raw:
-                px = gpu_transform_batch(px, self.model.cfg.image_size, patch=self.model.cfg.patch_size)
+                # f16x3 with the hand-written GEMM: the transform writes the patch-embedding GEMM's operand itself
+                cfg = self.model.cfg
+                operand = (ops.gemm_mode() == "f16x3" and ops.mlp_mode() != "lib" and patch_operand_supported(cfg.patch_size, cfg.image_size)
+                           and cfg.vision.width % 256 == 0 and hasattr(self.model, "vision")
+                           and os.environ.get("LEMON_PATCH_OPERAND", "1") != "0")          # (=0: A/B knob, the fp32 patch rows + split pass)
+                px = gpu_transform_batch(px, cfg.image_size, patch=cfg.patch_size, operand=operand)
             return self.model.encode_image(px)
 
         n = pixel_values.shape[0]

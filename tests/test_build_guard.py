@@ -204,19 +204,21 @@ def test_hand_issued_asm_is_left_alone_by_the_compiler(src, kernels):
 # hipcc keeps within 128 registers by spilling a few per-thread staging addresses AROUND the key-tile loops (written once before
 # the first loop, read back once at the second key block's staging): tolerated -- what is asserted is that no scratch access
 # sits inside a loop that issues MFMAs, and that the register count really allows the fourth wave.
-def _loops_with_mfma_and_scratch(lines):
-    header_of, kinds = {}, {}
-    cur = None
+def _loops_with_mfma_and_scratch(lines, _probe=False):
+    """Loop headers (asm labels) whose loop body holds both an MFMA and a scratch access.  hipcc annotates every basic block of a
+    loop with `in Loop: Header=BBx_y` / `Loop Header`, on the label line or on a comment line right below it."""
+    kinds = {}
+    cur, last_label = None, None
     for raw in lines:
-        m = re.match(r"^(?:\.LBB\d+_\d+:|; %bb\.\d+:)\s*;\s*(?:=>This (?:Inner )?Loop Header: Depth=\d+|  in Loop: Header=(BB\d+_\d+) Depth=\d+)", raw)
         lab = re.match(r"^(?:\.L(BB\d+_\d+):|; %bb\.\d+:)", raw)
         if lab:
-            if "Loop Header" in raw and "in Loop" not in raw:
-                cur = lab.group(1)
-            elif m and m.group(1):
+            cur, last_label = None, lab.group(1)
+        if lab or raw.lstrip().startswith(";"):
+            m = re.search(r"in Loop: Header=(BB\d+_\d+)", raw)
+            if m:
                 cur = m.group(1)
-            else:
-                cur = None
+            elif "Loop Header" in raw and last_label:
+                cur = last_label
             continue
         if cur is None:
             continue
@@ -225,6 +227,8 @@ def _loops_with_mfma_and_scratch(lines):
             kinds.setdefault(cur, set()).add("mfma")
         if ins.startswith("scratch_"):
             kinds.setdefault(cur, set()).add("scratch")
+    if _probe:                                   # (self-check of the parser: loops that issue MFMAs were found at all)
+        return [h for h, k in kinds.items() if "mfma" in k]
     return [h for h, k in kinds.items() if {"mfma", "scratch"} <= k]
 
 
@@ -238,4 +242,4 @@ def test_long_sequence_attention_kernel_fits_four_waves_and_keeps_scratch_out_of
         assert meta[n]["vgpr_count"] <= 128, (n, meta[n])
         assert meta[n]["vgpr_spill_count"] <= 20, (n, meta[n])
         assert _loops_with_mfma_and_scratch(bodies[n]) == [], n
-        assert sum("v_mfma" in ln for ln in bodies[n]) >= 24, n
+        assert _loops_with_mfma_and_scratch(bodies[n], _probe=True), "the parser must see the MFMA loops"

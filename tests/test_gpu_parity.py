@@ -712,6 +712,28 @@ def test_patch_major_preprocess_feeds_patch_embedding_gemm(hip):
     assert a.shape == b.shape and (a - b).abs().max() < 1e-4
 
 
+@pytest.mark.parametrize("arch,B,hw", [("vit-b-32", 37, (32, 32)), ("vit-b-16", 9, (40, 56))])
+def test_preprocess_writes_the_patch_embedding_operand(hip, arch, B, hw):
+    # lemon_preprocess_u8_f16x3t: the tile-major operand holds exactly the fp16 split of lemon_preprocess_u8's patch rows, and the
+    # tower fed with it (patch embedding in the hand-written GEMM) gives the embeddings of the fp32 patch-major path
+    from lemon_amd.clip import ClipConfig, LemonCLIP
+    from lemon_amd.data import gpu_transform_batch
+    from lemon_amd.ops import normalize_vectors, split_operand, unpack_act_t
+    cfg = ClipConfig.named(arch)
+    imgs = torch.from_numpy(np.random.default_rng(B).integers(0, 256, (B,) + hw + (3,), dtype=np.uint8)).cuda()
+    patches = gpu_transform_batch(imgs, cfg.image_size, patch=cfg.patch_size)
+    po = gpu_transform_batch(imgs, cfg.image_size, patch=cfg.patch_size, operand=True)
+    m_rows, K = B * po.n_patches, po.k
+    assert patches.shape == (B, po.n_patches, K)
+    y3 = split_operand(patches.reshape(m_rows, K), "f16x3").view(m_rows, 3, K)
+    assert torch.equal(unpack_act_t(po.at, m_rows, K), y3[:, 0].float() + y3[:, 2].float() * (1.0 / 2048.0))
+    torch.manual_seed(3)
+    model = LemonCLIP(cfg).eval().cuda()
+    with torch.no_grad():
+        a, b = normalize_vectors(model.encode_image(patches).float()), normalize_vectors(model.encode_image(po).float())
+    assert bool(torch.isfinite(b).all()) and float((a - b).abs().max()) < 5e-6
+
+
 def test_fused_split_scoring_equals_per_split_calls(hip, oracle):
     # pipeline.score_splits sends train (k+1, self-exclusion) and val/test (k) through ONE neighbours call
     from lemon_amd.pipeline import score_splits

@@ -1,7 +1,7 @@
 """Copy the judged summaries of a tools/gpu_profile.sh run from gpurun_out/ into profiles/<tag>/.
 python tools/collect_profiles.py [tag]"""
 import csv, glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles", tag)
 os.makedirs(P, exist_ok=True)
@@ -46,13 +46,31 @@ def write_pmc(name, dirs):
         w = csv.DictWriter(f, fieldnames=list(out[0].keys())); w.writeheader(); w.writerows(out)
     print(name, len(out), "rows (from", len(rows), "launch records)")
 
-for src, dst in ((f"bench_{tag}.json", "bench_default.json"), (f"prof_knn_{tag}.json", "knn_1000000x768.json")):
+for src, dst in ((f"bench_{tag}.json", "bench_default.json"), (f"prof_knn_{tag}.json", "knn_1000000x768.json"),
+                 (f"bench_vit-b-16_{tag}.json", "bench_vit-b-16.json"), (f"bench_vit-l-14_{tag}.json", "bench_vit-l-14.json")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copyfile(os.path.join(G, src), os.path.join(P, dst)); print(dst)
-for d, dst in ((f"prof_bench_{tag}", "bench_default_kernel_stats.csv"), (f"prof_knn_{tag}", "knn_1000000x768_kernel_stats.csv")):
+for d, dst in ((f"prof_bench_{tag}", "bench_default_kernel_stats.csv"), (f"prof_knn_{tag}", "knn_1000000x768_kernel_stats.csv"),
+               (f"prof_vit-b-16_{tag}", "bench_vit-b-16_kernel_stats.csv"), (f"prof_vit-l-14_{tag}", "bench_vit-l-14_kernel_stats.csv")):
     f = one(f"{d}/**/*kernel_stats.csv")
     if f:
         shutil.copyfile(f, os.path.join(P, dst)); print(dst)
-write_pmc("bench_default_pmc.csv", [f"pmc_bench_fetch_{tag}", f"pmc_bench_write_{tag}", f"pmc_bench_mfma_{tag}"])
-write_pmc("knn_1000000x768_pmc.csv", [f"pmc_fetch_{tag}", f"pmc_write_{tag}", f"pmc_mfma_{tag}"])
-write_pmc("encoder_mfma_pmc.csv", [f"pmc_encoder_mfma_{tag}"])
+CS = ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES")
+write_pmc("knn_1000000x768_pmc.csv", [f"pmc_knn_{c}_{tag}" for c in CS])
+# the headline step's counters: everything in bench_default_pmc.csv; the hand-written GEMM's rows again in encoder_gemm_pmc.csv
+# (what bench.py's roofline object reads) and the MFMA rows of all encoder kernels in encoder_mfma_pmc.csv
+write_pmc("bench_default_pmc.csv", [f"pmc_bench_{c}_{tag}" for c in CS])
+import csv as _csv
+src = os.path.join(P, "bench_default_pmc.csv")
+if os.path.exists(src):
+    rows = list(_csv.DictReader(open(src)))
+    for name, keep in (("encoder_gemm_pmc.csv", lambda r: "k_gemm_f16x3t" in r["kernel"]),
+                       ("encoder_mfma_pmc.csv", lambda r: r["counter"] in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES")
+                                                          and not r["kernel"].startswith(("void (anonymous namespace)::k_scan", "void k_neighbors")))):
+        sel = [r for r in rows if keep(r)]
+        if sel:
+            with open(os.path.join(P, name), "w", newline="") as f:
+                w = _csv.DictWriter(f, fieldnames=list(sel[0].keys())); w.writeheader(); w.writerows(sel)
+            print(name, len(sel), "rows")
+for a in ("vit-b-16", "vit-l-14"):
+    write_pmc(f"bench_{a}_pmc.csv", [f"pmc_{a}_{c}_{tag}" for c in CS])

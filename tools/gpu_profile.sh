@@ -1,24 +1,43 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): headline bench, rocprofv3 kernel trace of the same command, and the PMC passes
-# (separate runs, kernel-trace only: never combined with --sys-trace etc.) the roofline `traffic` figures come from.
+# (separate runs, kernel-trace only: never combined with --sys-trace etc.) the roofline figures come from.
 # The program is put directly after `--` (no env / bash -c hop: the profiler preloads before the program starts).
+# Every profiled pass runs with --no_f32_gemm_check: the untimed all-fp32 cross-check step of the plain bench run must not
+# contaminate kernel statistics or counters (round-3 advisor finding).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
-TAG=${1:-r3}
+TAG=${1:-r4}
 cd /tmp && export TMPDIR=/tmp
 K1M="--workload knn --knn_n 1000000 --knn_d 768 --steps 1 --warmup 0 --no_cpu_baseline"
+P="--no_cpu_baseline --no_knn_1m --no_f32_gemm_check"
+SCAN="k_scan|k_bf16_final|k_neighbors|k_merge"
+ENC="Cijk|k_attention|k_gemm_f16x3t|k_layernorm|k_vision|k_preprocess"
 python3 $R/bench.py --steps 2 --warmup 1 > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench_$TAG -- python3 $R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_knn_1m > $OUT/prof_bench_$TAG.json 2> $OUT/prof_bench_$TAG.err || exit 2
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench_$TAG -- python3 $R/bench.py --steps 2 --warmup 1 $P > $OUT/prof_bench_$TAG.json 2> $OUT/prof_bench_$TAG.err || exit 2
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_knn_$TAG -- python3 $R/bench.py $K1M > $OUT/prof_knn_$TAG.json 2> $OUT/prof_knn_$TAG.err || exit 3
-rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_scan|k_bf16_final|k_neighbors|k_merge" --output-format csv -d $OUT/pmc_fetch_$TAG -- python3 $R/bench.py $K1M > $OUT/pmc_fetch_$TAG.json 2> $OUT/pmc_fetch_$TAG.err || exit 4
-rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_scan|k_bf16_final|k_neighbors|k_merge" --output-format csv -d $OUT/pmc_write_$TAG -- python3 $R/bench.py $K1M > $OUT/pmc_write_$TAG.json 2> $OUT/pmc_write_$TAG.err || exit 5
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "k_scan|k_bf16_final|k_neighbors|k_merge" --output-format csv -d $OUT/pmc_mfma_$TAG -- python3 $R/bench.py $K1M > $OUT/pmc_mfma_$TAG.json 2> $OUT/pmc_mfma_$TAG.err || exit 6
-rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_scan|k_bf16_final|k_neighbors|k_merge" --output-format csv -d $OUT/pmc_bench_fetch_$TAG -- python3 $R/bench.py --steps 1 --warmup 0 --no_cpu_baseline --no_knn_1m > /dev/null 2> $OUT/pmc_bench_fetch_$TAG.err || exit 7
-rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_scan|k_bf16_final|k_neighbors|k_merge" --output-format csv -d $OUT/pmc_bench_write_$TAG -- python3 $R/bench.py --steps 1 --warmup 0 --no_cpu_baseline --no_knn_1m > /dev/null 2> $OUT/pmc_bench_write_$TAG.err || exit 8
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "k_scan|k_bf16_final|k_neighbors|k_merge|k_attention|k_layernorm|k_vision" --output-format csv -d $OUT/pmc_bench_mfma_$TAG -- python3 $R/bench.py --steps 1 --warmup 0 --no_cpu_baseline --no_knn_1m > /dev/null 2> $OUT/pmc_bench_mfma_$TAG.err || exit 9
-# MFMA utilisation of the tower GEMMs (hipBLASLt `Cijk_...` kernels) and the attention kernels on the FULL headline shape
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "Cijk|k_attention|k_gemm_f16x3t" --output-format csv -d $OUT/pmc_encoder_mfma_$TAG -- python3 $R/bench.py --steps 1 --warmup 0 --no_cpu_baseline --no_knn_1m > /dev/null 2> $OUT/pmc_encoder_mfma_$TAG.err || exit 10
+n=3
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  n=$((n+1)); t=$(echo $c | cut -d' ' -f1)
+  rocprofv3 --pmc $c --kernel-include-regex "$SCAN" --output-format csv -d $OUT/pmc_knn_${t}_$TAG -- python3 $R/bench.py $K1M > /dev/null 2> $OUT/pmc_knn_${t}_$TAG.err || exit $n
+done
+# the headline step: scan kernels and the encoder kernels (hand-written GEMM, library GEMMs, attention, LayerNorm), one pass per counter set
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
+  n=$((n+1)); t=$(echo $c | cut -d' ' -f1)
+  rocprofv3 --pmc $c --kernel-include-regex "$SCAN|$ENC" --output-format csv -d $OUT/pmc_bench_${t}_$TAG -- python3 $R/bench.py --steps 1 --warmup 0 $P > /dev/null 2> $OUT/pmc_bench_${t}_$TAG.err || exit $n
+done
+# configs[2] / configs[4] encoders: ViT-B/16 (L = 197) and ViT-L/14 (L = 257) at 4 000 + 500 + 500 samples
+for a in vit-b-16 vit-l-14; do
+  eb=332; [ $a = vit-l-14 ] && eb=255
+  A="--arch $a --n_train 4000 --n_val 500 --n_test 500 --encoder_batch $eb $P"
+  n=$((n+1))
+  python3 $R/bench.py --steps 2 --warmup 1 $A > $OUT/bench_${a}_$TAG.json 2> $OUT/bench_${a}_$TAG.err || exit $n
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${a}_$TAG -- python3 $R/bench.py --steps 2 --warmup 1 $A > /dev/null 2> $OUT/prof_${a}_$TAG.err || exit $n
+  for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
+    t=$(echo $c | cut -d' ' -f1)
+    rocprofv3 --pmc $c --kernel-include-regex "$ENC" --output-format csv -d $OUT/pmc_${a}_${t}_$TAG -- python3 $R/bench.py --steps 1 --warmup 0 $A > /dev/null 2> $OUT/pmc_${a}_${t}_$TAG.err || exit $n
+  done
+done
 find $OUT -name "*_kernel_trace.csv" -size +20M -delete
-ls $OUT/prof_bench_$TAG/*/ | head -20
+ls $OUT | head -60
