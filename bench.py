@@ -33,7 +33,7 @@ PEAK_HBM_GBS = 8000.0          # HBM3E spec peak (6.3 TB/s achievable)
 def pmc_summary(kernel_substr, fname="bench_default_pmc.csv"):
     """{counter: row} of the longest-running launch group of a kernel in a COMMITTED PMC summary (profiles/rN/<fname>), + path."""
     import csv
-    path = next((p for p in (os.path.join(ROOT, "profiles", r, fname) for r in ("r3", "r2", "r1")) if os.path.exists(p)), None)
+    path = next((p for p in (os.path.join(ROOT, "profiles", r, fname) for r in ("r4", "r3", "r2", "r1")) if os.path.exists(p)), None)
     if path is None:
         return {}, None
     best = {}
@@ -53,7 +53,7 @@ def pmc_traffic(kernel_substr):
     from inside the timed process, so this is NOT a measurement of the current run: the file it came from is
     reported next to it as `traffic_source`.  (None, None) when no summary is committed."""
     import csv
-    path = next((p for p in (os.path.join(ROOT, "profiles", r, "bench_default_pmc.csv") for r in ("r3", "r2", "r1"))
+    path = next((p for p in (os.path.join(ROOT, "profiles", r, "bench_default_pmc.csv") for r in ("r4", "r3", "r2", "r1"))
                  if os.path.exists(p)), None)
     if path is None:
         return None, None

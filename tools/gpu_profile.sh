@@ -14,6 +14,8 @@ K1M="--workload knn --knn_n 1000000 --knn_d 768 --steps 1 --warmup 0 --no_cpu_ba
 P="--no_cpu_baseline --no_knn_1m --no_f32_gemm_check"
 SCAN="k_scan|k_bf16_final|k_neighbors|k_merge"
 ENC="Cijk|k_attention|k_gemm_f16x3t|k_layernorm|k_vision|k_preprocess"
+PART=${PART:-ab}      # a: headline + 1M kNN passes, b: the ViT-B/16 and ViT-L/14 passes (two gpurun calls: each stays inside the 20-minute limit)
+if [[ $PART == *a* ]]; then
 python3 $R/bench.py --steps 2 --warmup 1 > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench_$TAG -- python3 $R/bench.py --steps 2 --warmup 1 $P > $OUT/prof_bench_$TAG.json 2> $OUT/prof_bench_$TAG.err || exit 2
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_knn_$TAG -- python3 $R/bench.py $K1M > $OUT/prof_knn_$TAG.json 2> $OUT/prof_knn_$TAG.err || exit 3
@@ -27,8 +29,10 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT
   n=$((n+1)); t=$(echo $c | cut -d' ' -f1)
   rocprofv3 --pmc $c --kernel-include-regex "$SCAN|$ENC" --output-format csv -d $OUT/pmc_bench_${t}_$TAG -- python3 $R/bench.py --steps 1 --warmup 0 $P > /dev/null 2> $OUT/pmc_bench_${t}_$TAG.err || exit $n
 done
+fi
+n=20
 # configs[2] / configs[4] encoders: ViT-B/16 (L = 197) and ViT-L/14 (L = 257) at 4 000 + 500 + 500 samples
-for a in vit-b-16 vit-l-14; do
+[[ $PART == *b* ]] && for a in vit-b-16 vit-l-14; do
   eb=332; [ $a = vit-l-14 ] && eb=255
   A="--arch $a --n_train 4000 --n_val 500 --n_test 500 --encoder_batch $eb $P"
   n=$((n+1))
