@@ -137,7 +137,9 @@ def parse():
     ap.add_argument("--knn_k", type=int, default=50)
     ap.add_argument("--dist_type", default="cosine", choices=["cosine", "euclidean"])
     ap.add_argument("--encoder_batch", type=int, default=2620,
-                    help="images per encoder micro-batch (per-sample results do not depend on it); 2 620 x 50 tokens = 1 024 row tiles of the MLP GEMM: whole rounds of the 512 workgroup slots")
+                    help="images per encoder micro-batch (per-sample results are equal within fp32 rounding whatever it is: the hand-written GEMM is position-independent, "
+                         "a library GEMM may pick another solution -- another summation order -- for another row count); 2 620 x 50 tokens = 1 024 row tiles "
+                         "of the MLP GEMM: whole rounds of the 512 workgroup slots")
     ap.add_argument("--text_dedup", action="store_true",
                     help="embed each distinct prompt once (exact; off by default so every sample's prompt is encoded)")
     ap.add_argument("--algo", default="auto", choices=["auto", "f32", "bf16"])
