@@ -367,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
         __builtin_amdgcn_s_barrier();                       // B': every wave has read both slots
         if (t + 3 < KS) issue(t + 3, p0);
         if (t + 4 < KS) issue(t + 4, p1);
+        // (s_setprio 1 / 0 around this cluster: measured neutral, +-1 % by shape, tools/micro/gemm_ab.hip)
         MF_BLOCK(1); MF_BLOCK(2); MF_BLOCK(3); MF_BLOCK(4); MF_BLOCK(5); MF_BLOCK(6); MF_BLOCK(7);
         p0 = p0 == 0 ? 2 : p0 - 1;                          // (p + 2) mod 3
         p1 = p1 == 0 ? 2 : p1 - 1;
