@@ -56,14 +56,15 @@ struct GemmParams {
     int64_t m;
     int n, ks, m_tiles, n_tiles;
     int gm, gn;                // super-block of the tile walk: gm m-tiles x gn n-tiles per XCD at a time
+    int vblocks;               // virtual workgroup ids of the tile walk (>= tiles: ragged super-blocks leave holes)
     float alpha;
 };
 
 // Tile walk.  Consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2); an XCD works through
 // super-blocks of gm x gn tiles, m fastest: the workgroups it runs at a time (2 per CU = 64) then share gm activation tile
 // rows and gn weight tile columns instead of streaming one of the two operands once per tile.
-__device__ __forceinline__ bool tile_of_workgroup(const GemmParams &p, int &mt, int &nt) {
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+__device__ __forceinline__ bool tile_of_workgroup(const GemmParams &p, unsigned vb, int &mt, int &nt) {
+    const int xcd = vb & 7, q = vb >> 3;
     const int per = p.gm * p.gn;
     const int gm_n = (p.m_tiles + p.gm - 1) / p.gm, gn_n = (p.n_tiles + p.gn - 1) / p.gn;
     const int blk = (q / per) * 8 + xcd, pos = q % per;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     int mt, nt;
-    if (!tile_of_workgroup(p, mt, nt)) return;
+    if (!tile_of_workgroup(p, blockIdx.x, mt, nt)) return;
     const int KS = p.ks;
     const char *a_src = p.at + (size_t)mt * KS * 2 * BLKA;
     const char *w_src = p.wt + (size_t)nt * KS * 2 * BLKW;
@@ -284,7 +285,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     int mt, nt;
-    if (!tile_of_workgroup(p, mt, nt)) return;
+#ifdef LEMON_GEMM_PERSIST
+    for (unsigned vb = blockIdx.x; vb < (unsigned)p.vblocks; vb += gridDim.x) {
+    if (vb != blockIdx.x) __syncthreads();                  // the previous tile's epilogue is done with the LDS patch
+    if (!tile_of_workgroup(p, vb, mt, nt)) continue;
+#else
+    if (!tile_of_workgroup(p, blockIdx.x, mt, nt)) return;
+#endif
     const int KS = p.ks;                                    // k16 slots: even (the host checks k % 32 == 0)
     const char *a_src = p.at + (size_t)mt * KS * 2 * BLKA;
     const char *w_src = p.wt + (size_t)nt * KS * 2 * BLKW;
@@ -413,7 +420,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
                 }
             }
         }
+#ifdef LEMON_GEMM_PERSIST
+        continue;
+#else
         return;
+#endif
     }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -439,6 +450,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
             *reinterpret_cast<h16x4 *>(base + TM * 16) = lo;
         }
     }
+#ifdef LEMON_GEMM_PERSIST
+    }
+#endif
 }
 
 // fp32 [n, k] weight -> tile-major fp16 pairs of w * wscale (one thread per 8 consecutive k)
@@ -476,6 +490,7 @@ struct GemmProf {
 } g_prof;
 constexpr size_t PROF_POOL = 2 * 8192;
 int g_gm = 0, g_gn = 0;                // tile-walk override (tools/micro); 0: the defaults
+int g_persist = 0;                     // (experiment, -DLEMON_GEMM_PERSIST) workgroups of the persistent form; 0: one tile per workgroup
 int g_mfma_shape = 0;                  // 0: not decided yet ($LEMON_GEMM_MFMA, default 16); tools/micro sets it directly
 void walk_override() {
     static bool read = false;
@@ -543,8 +558,12 @@ extern "C" int lemon_linear_f16x3t(const uint16_t *at_dev, const uint16_t *wt_de
     }
     if (p.gn > p.n_tiles) p.gn = p.n_tiles;
     const int64_t blocks = (int64_t)((p.m_tiles + p.gm - 1) / p.gm) * ((p.n_tiles + p.gn - 1) / p.gn);
-    const int64_t grid = ((blocks + 7) / 8) * p.gm * p.gn * 8;
+    int64_t grid = ((blocks + 7) / 8) * p.gm * p.gn * 8;
     LEMON_REQUIRE(grid < ((int64_t)1 << 31), "grid size");
+    p.vblocks = (int)grid;
+#ifdef LEMON_GEMM_PERSIST
+    if (g_persist && grid > g_persist) grid = g_persist;     // experiment: g_persist workgroups (a multiple of 8) loop over the tiles
+#endif
     const size_t lds = (size_t)NB * STAGE;
     // the 72 KB of dynamic LDS need the attribute on every DEVICE this process launches on (it is per device, not per process)
     int dev = 0;
