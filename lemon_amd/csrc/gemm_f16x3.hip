@@ -285,13 +285,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     int mt, nt;
-#ifdef LEMON_GEMM_PERSIST
-    for (unsigned vb = blockIdx.x; vb < (unsigned)p.vblocks; vb += gridDim.x) {
-    if (vb != blockIdx.x) __syncthreads();                  // the previous tile's epilogue is done with the LDS patch
-    if (!tile_of_workgroup(p, vb, mt, nt)) continue;
-#else
+    // (one tile per workgroup, dispatched by the hardware as slots free up.  A persistent form -- 512 workgroups looping over
+    // their tiles in the same walk order -- measured 2-5 % SLOWER at the tower shapes: tools/micro/gemm_ab.hip, round 4)
     if (!tile_of_workgroup(p, blockIdx.x, mt, nt)) return;
-#endif
     const int KS = p.ks;                                    // k16 slots: even (the host checks k % 32 == 0)
     const char *a_src = p.at + (size_t)mt * KS * 2 * BLKA;
     const char *w_src = p.wt + (size_t)nt * KS * 2 * BLKW;
@@ -420,11 +416,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
                 }
             }
         }
-#ifdef LEMON_GEMM_PERSIST
-        continue;
-#else
         return;
-#endif
     }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -450,9 +442,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
             *reinterpret_cast<h16x4 *>(base + TM * 16) = lo;
         }
     }
-#ifdef LEMON_GEMM_PERSIST
-    }
-#endif
 }
 
 // fp32 [n, k] weight -> tile-major fp16 pairs of w * wscale (one thread per 8 consecutive k)
@@ -490,7 +479,6 @@ struct GemmProf {
 } g_prof;
 constexpr size_t PROF_POOL = 2 * 8192;
 int g_gm = 0, g_gn = 0;                // tile-walk override (tools/micro); 0: the defaults
-int g_persist = 0;                     // (experiment, -DLEMON_GEMM_PERSIST) workgroups of the persistent form; 0: one tile per workgroup
 int g_mfma_shape = 0;                  // 0: not decided yet ($LEMON_GEMM_MFMA, default 16); tools/micro sets it directly
 void walk_override() {
     static bool read = false;
@@ -561,9 +549,6 @@ extern "C" int lemon_linear_f16x3t(const uint16_t *at_dev, const uint16_t *wt_de
     int64_t grid = ((blocks + 7) / 8) * p.gm * p.gn * 8;
     LEMON_REQUIRE(grid < ((int64_t)1 << 31), "grid size");
     p.vblocks = (int)grid;
-#ifdef LEMON_GEMM_PERSIST
-    if (g_persist && grid > g_persist) grid = g_persist;     // experiment: g_persist workgroups (a multiple of 8) loop over the tiles
-#endif
     const size_t lds = (size_t)NB * STAGE;
     // the 72 KB of dynamic LDS need the attribute on every DEVICE this process launches on (it is per device, not per process)
     int dev = 0;

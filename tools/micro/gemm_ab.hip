@@ -88,7 +88,6 @@ int main(int argc, char **argv) {
     if (argc > 1 && !strcmp(argv[1], "debug")) { debug_run(32); debug_run(64); debug_run(128); return 0; }
     const bool walk = argc > 1 && !strcmp(argv[1], "walk");
     if (walk) { --argc; ++argv; }
-    if (getenv("GEMM_PERSIST")) g_persist = atoi(getenv("GEMM_PERSIST"));
     if (getenv("GEMM_GM")) { g_gm = atoi(getenv("GEMM_GM")); g_gn = atoi(getenv("GEMM_GN") ? getenv("GEMM_GN") : "1"); }
     const int rounds = argc > 1 ? atoi(argv[1]) : 7, reps = argc > 2 ? atoi(argv[2]) : 10;
     const int M = argc > 3 ? atoi(argv[3]) : 131000;
