@@ -381,42 +381,73 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
     const int N = p.n;
     if (EPI == 0) {
         // fp32 row-major (+ residual) in full 128-byte lines: 2 x 2 accumulator tiles (32 m x 32 n) per pass through the
-        // wave-private LDS patch (the ring is free: every wave's reads ended before the last B')
-        float *patch = reinterpret_cast<float *>(smem) + wave * (32 * 36);
+        // wave-private LDS patch (the ring is free: every wave's reads ended before the last B').  The residual of pass i + 1 is
+        // fetched while pass i makes its LDS round trip and stores: fetched inside the pass that uses it, every pass waited a
+        // global-load latency (eight per tile: +8.5 % on the output projection, +2.9 % on fc2, tools/micro/gemm_ab.hip).  Rows
+        // beyond m read the last valid row (never stored), so that the loads need no per-lane branches.
+        // Two patches per wave: pass i + 1's accumulator tiles are written before pass i is read back, so that a pass does not
+        // wait for its own LDS round trip; the four bias vectors of the wave's columns are fetched once, up front.
+        float *patch0 = reinterpret_cast<float *>(smem) + wave * (2 * 32 * 36);
         const int prow = lane >> 3, pcol = 4 * (lane & 7);
+        const bool has_res = p.residual != nullptr;
+        const int64_t m_last = p.m - 1;
+        float4 bias4[4];
 #pragma unroll
         for (int cp = 0; cp < 4; ++cp) {
+            bias4[cp] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias) bias4[cp] = *reinterpret_cast<const float4 *>(p.bias + nt * TN + wn * 128 + cp * 32 + pcol);
+        }
+        auto load_res = [&](int pass, float4 (&r)[4]) {
+            const int n = nt * TN + wn * 128 + (pass >> 1) * 32 + pcol;
+            const int64_t m0 = (int64_t)mt * TM + wm * (IB * 32) + (pass & 1) * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t m = m0 + 8 * q + prow;
+                r[q] = *reinterpret_cast<const float4 *>(p.residual + (m < m_last ? m : m_last) * N + n);
+            }
+        };
+        float4 rn[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rn[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_res) load_res(0, rn);
+#define PATCH_WRITE(pass_)                                                                                       \
+        do {                                                                                                     \
+            float *pw_ = patch0 + ((pass_) & 1) * (32 * 36);                                                     \
+            _Pragma("unroll") for (int ci = 0; ci < 2; ++ci) _Pragma("unroll") for (int bi = 0; bi < 2; ++bi) { \
+                const f32x4 a = acc[2 * ((pass_) >> 1) + ci][2 * ((pass_) & 1) + bi];                            \
+                *reinterpret_cast<float4 *>(pw_ + (bi * 16 + r16) * 36 + ci * 16 + 4 * kg) = make_float4(a[0], a[1], a[2], a[3]); \
+            }                                                                                                    \
+        } while (0)
+        PATCH_WRITE(0);
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int cp = pass >> 1, bp = pass & 1;
             const int n = nt * TN + wn * 128 + cp * 32 + pcol;
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias) bv = *reinterpret_cast<const float4 *>(p.bias + n);
+            const float4 bv = bias4[cp];
+            const int64_t m0 = (int64_t)mt * TM + wm * (IB * 32) + bp * 32;
+            float4 r[4];
 #pragma unroll
-            for (int bp = 0; bp < 2; ++bp) {
-                const int64_t m0 = (int64_t)mt * TM + wm * (IB * 32) + bp * 32;
+            for (int q = 0; q < 4; ++q) r[q] = rn[q];
+            if (has_res && pass + 1 < 8) load_res(pass + 1, rn);
+            if (pass + 1 < 8) PATCH_WRITE(pass + 1);
+            const float *pr = patch0 + (pass & 1) * (32 * 36);
 #pragma unroll
-                for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-                    for (int bi = 0; bi < 2; ++bi) {
-                        const f32x4 a = acc[2 * cp + ci][2 * bp + bi];
-                        *reinterpret_cast<float4 *>(patch + (bi * 16 + r16) * 36 + ci * 16 + 4 * kg) = make_float4(a[0], a[1], a[2], a[3]);
-                    }
-                float4 r[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const int64_t m = m0 + 8 * q + prow;
-                    if (p.residual && m < p.m) r[q] = *reinterpret_cast<const float4 *>(p.residual + m * N + n);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int64_t m = m0 + 8 * q + prow;
-                    const float4 v = *reinterpret_cast<const float4 *>(patch + (8 * q + prow) * 36 + pcol);
-                    if (m < p.m)
-                        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + m * N + n) =
-                            make_float4(p.alpha * v.x + bv.x + r[q].x, p.alpha * v.y + bv.y + r[q].y, p.alpha * v.z + bv.z + r[q].z, p.alpha * v.w + bv.w + r[q].w);
-                }
+            for (int q = 0; q < 4; ++q) {
+                const int64_t m = m0 + 8 * q + prow;
+                const float4 v = *reinterpret_cast<const float4 *>(pr + (8 * q + prow) * 36 + pcol);
+                if (m < p.m)
+                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + m * N + n) =
+                        make_float4(p.alpha * v.x + bv.x + r[q].x, p.alpha * v.y + bv.y + r[q].y, p.alpha * v.z + bv.z + r[q].z, p.alpha * v.w + bv.w + r[q].w);
             }
         }
+#undef PATCH_WRITE
         return;
+    }
+    float4 bias8[8];                                        // (fetched once: behind the operand stores below hipcc must reload them)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        bias8[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bias8[c] = *reinterpret_cast<const float4 *>(p.bias + nt * TN + wn * 128 + c * 16 + 4 * kg);
     }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -424,8 +455,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int n = nt * TN + wn * 128 + c * 16 + 4 * kg;
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias) bv = *reinterpret_cast<const float4 *>(p.bias + n);
+            const float4 bv = bias8[c];
             const float o[4] = {p.alpha * acc[c][b][0] + bv.x, p.alpha * acc[c][b][1] + bv.y, p.alpha * acc[c][b][2] + bv.z, p.alpha * acc[c][b][3] + bv.w};
             // the next GEMM's activation operand (its k = this n): the lane's four values are half a 16-byte slot, a wave's
             // store instruction covers two runs of 256 contiguous bytes

@@ -119,7 +119,7 @@ int main(int argc, char **argv) {
         const float alpha = 1.0f / wscale;
         auto run = [&](int v) {
             g_mfma_shape = v ? 16 : 32;
-            LCHECK(lemon_linear_f16x3t(at, wt, bias, s.epi ? nullptr : res, s.m, s.n, s.k, alpha, s.epi ? LEMON_ACT_SILU : LEMON_ACT_NONE,
+            LCHECK(lemon_linear_f16x3t(at, wt, bias, (s.epi || getenv("GEMM_NO_RESIDUAL")) ? nullptr : res, s.m, s.n, s.k, alpha, s.epi ? LEMON_ACT_SILU : LEMON_ACT_NONE,
                                        s.epi, out[v], nullptr));
         };
         if (walk) {
