@@ -58,6 +58,9 @@ struct GemmParams {
     int gm, gn;                // super-block of the tile walk: gm m-tiles x gn n-tiles per XCD at a time
     int vblocks;               // virtual workgroup ids of the tile walk (>= tiles: ragged super-blocks leave holes)
     float alpha;
+#ifdef LEMON_GEMM_PHASES
+    unsigned long long *dbg;   // diagnostic build: summed shader cycles of [start -> first barrier passed, main loop, epilogue] + workgroups
+#endif
 };
 
 // Tile walk.  Consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2); an XCD works through
@@ -288,6 +291,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
     // (one tile per workgroup, dispatched by the hardware as slots free up.  A persistent form -- 512 workgroups looping over
     // their tiles in the same walk order -- measured 2-5 % SLOWER at the tower shapes: tools/micro/gemm_ab.hip, round 4)
     if (!tile_of_workgroup(p, blockIdx.x, mt, nt)) return;
+#ifdef LEMON_GEMM_PHASES
+    const unsigned long long ph0 = __builtin_amdgcn_s_memtime();
+    unsigned long long ph1 = 0;
+#endif
     const int KS = p.ks;                                    // k16 slots: even (the host checks k % 32 == 0)
     const char *a_src = p.at + (size_t)mt * KS * 2 * BLKA;
     const char *w_src = p.wt + (size_t)nt * KS * 2 * BLKW;
@@ -339,6 +346,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
         // slots t and t+1 have landed (this wave's share; the barrier makes it everyone's): the only younger DMAs are slot t+2's
         if (t + 2 < KS) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#ifdef LEMON_GEMM_PHASES
+        if (t == 0) ph1 = __builtin_amdgcn_s_memtime();
+#endif
         const unsigned sb = (unsigned)((upper ? p1 : p0) * STAGE);
         const unsigned pa = fa + sb, pw = fw + sb;
         // LGKM_CNT is a 4-bit counter: never more than 15 LDS reads in flight, or the counted waits below read a wrapped count
@@ -368,10 +378,27 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
                      : "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(wf[2][0]), "+v"(wf[2][1]), "+v"(wf[3][0]), "+v"(wf[3][1]), "+v"(wf[4][0]),
                        "+v"(wf[4][1]), "+v"(wf[5][0]), "+v"(wf[5][1]), "+v"(wf[6][0]), "+v"(wf[6][1]), "+v"(wf[7][0]), "+v"(wf[7][1]) : : "memory");
         __builtin_amdgcn_s_barrier();                       // B': every wave has read both slots
+#ifdef LEMON_GEMM_DMA_BURST
         if (t + 3 < KS) issue(t + 3, p0);
         if (t + 4 < KS) issue(t + 4, p1);
-        // (s_setprio 1 / 0 around this cluster: measured neutral, +-1 % by shape, tools/micro/gemm_ab.hip)
         MF_BLOCK(1); MF_BLOCK(2); MF_BLOCK(3); MF_BLOCK(4); MF_BLOCK(5); MF_BLOCK(6); MF_BLOCK(7);
+#else
+        // the twelve 1-KB DMA pieces of slots t+3, t+4 go out two at a time between the weight blocks' MFMAs (same order, same
+        // counts for the waits above): issued in one burst behind B' they kept the wave from its MFMAs for their whole issue time
+        const bool d3 = t + 3 < KS, d4 = t + 4 < KS;
+        const char *as3 = a_src + (size_t)(t + 3) * 2 * BLKA, *ws3 = w_src + (size_t)(t + 3) * 2 * BLKW;
+        const char *as4 = a_src + (size_t)(t + 4) * 2 * BLKA, *ws4 = w_src + (size_t)(t + 4) * 2 * BLKW;
+        const unsigned la3 = lds0 + p0 * STAGE + wave * (BLKA / 2), lw3 = lds0 + p0 * STAGE + 2 * BLKA + wave * (BLKW / 2);
+        const unsigned la4 = lds0 + p1 * STAGE + wave * (BLKA / 2), lw4 = lds0 + p1 * STAGE + 2 * BLKA + wave * (BLKW / 2);
+        static_assert(BLKA / 2048 == 2, "two activation pieces per wave and slot");
+        MF_BLOCK(1); if (d3) { dma1k(as3, va, la3); dma1k(as3, va + 1024, la3 + 1024); }
+        MF_BLOCK(2); if (d3) { dma1k(ws3, vw, lw3); dma1k(ws3, vw + 1024, lw3 + 1024); }
+        MF_BLOCK(3); if (d3) { dma1k(ws3, vw + 2048, lw3 + 2048); dma1k(ws3, vw + 3072, lw3 + 3072); }
+        MF_BLOCK(4); if (d4) { dma1k(as4, va, la4); dma1k(as4, va + 1024, la4 + 1024); }
+        MF_BLOCK(5); if (d4) { dma1k(ws4, vw, lw4); dma1k(ws4, vw + 1024, lw4 + 1024); }
+        MF_BLOCK(6); if (d4) { dma1k(ws4, vw + 2048, lw4 + 2048); dma1k(ws4, vw + 3072, lw4 + 3072); }
+        MF_BLOCK(7);
+#endif
         p0 = p0 == 0 ? 2 : p0 - 1;                          // (p + 2) mod 3
         p1 = p1 == 0 ? 2 : p1 - 1;
     }
@@ -379,6 +406,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
 #undef PIN_ACC16
     // ---- epilogue: the lane holds row m = r16 of activation block b and columns n = 4 kg + e of weight block c ----
     const int N = p.n;
+#ifdef LEMON_GEMM_PHASES
+    const unsigned long long ph2 = __builtin_amdgcn_s_memtime();
+    struct PhaseEnd {
+        unsigned long long *dbg, a, b, c; int tid;
+        __device__ ~PhaseEnd() {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long d = __builtin_amdgcn_s_memtime();
+            if (dbg && tid == 0) { atomicAdd(dbg, b - a); atomicAdd(dbg + 1, c - b); atomicAdd(dbg + 2, d - c); atomicAdd(dbg + 3, 1ull); }
+        }
+    } phase_end{p.dbg, ph0, ph1, ph2, tid};
+#endif
     if (EPI == 0) {
         // fp32 row-major (+ residual) in full 128-byte lines: 2 x 2 accumulator tiles (32 m x 32 n) per pass through the
         // wave-private LDS patch (the ring is free: every wave's reads ended before the last B').  The residual of pass i + 1 is
@@ -418,28 +456,33 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
                 *reinterpret_cast<float4 *>(pw_ + (bi * 16 + r16) * 36 + ci * 16 + 4 * kg) = make_float4(a[0], a[1], a[2], a[3]); \
             }                                                                                                    \
         } while (0)
-        PATCH_WRITE(0);
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int cp = pass >> 1, bp = pass & 1;
-            const int n = nt * TN + wn * 128 + cp * 32 + pcol;
-            const float4 bv = bias4[cp];
-            const int64_t m0 = (int64_t)mt * TM + wm * (IB * 32) + bp * 32;
-            float4 r[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) r[q] = rn[q];
-            if (has_res && pass + 1 < 8) load_res(pass + 1, rn);
-            if (pass + 1 < 8) PATCH_WRITE(pass + 1);
-            const float *pr = patch0 + (pass & 1) * (32 * 36);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int64_t m = m0 + 8 * q + prow;
-                const float4 v = *reinterpret_cast<const float4 *>(pr + (8 * q + prow) * 36 + pcol);
-                if (m < p.m)
-                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + m * N + n) =
-                        make_float4(p.alpha * v.x + bv.x + r[q].x, p.alpha * v.y + bv.y + r[q].y, p.alpha * v.z + bv.z + r[q].z, p.alpha * v.w + bv.w + r[q].w);
-            }
+        // The eight passes, in two forms: tiles that lie wholly inside the m rows (all but the last tile row) store without
+        // per-lane conditions -- behind `if (m < p.m)` hipcc wraps every load / store in its own exec-masked branch and waits
+        // vmcnt(0) / lgkmcnt(0) at each of them (four serialised LDS reads and a full drain of the previous pass's stores per
+        // pass: the fp32 epilogue was 20 % of a k = 768 tile's cycles) --, the ragged tile row keeps the conditions.
+#define EPI0_PASSES(MASKED)                                                                                      \
+        _Pragma("unroll") for (int pass = 0; pass < 8; ++pass) {                                                 \
+            const int cp = pass >> 1, bp = pass & 1;                                                             \
+            const int n = nt * TN + wn * 128 + cp * 32 + pcol;                                                   \
+            const float4 bv = bias4[cp];                                                                         \
+            const int64_t m0 = (int64_t)mt * TM + wm * (IB * 32) + bp * 32;                                      \
+            float4 r[4];                                                                                         \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) r[q] = rn[q];                                          \
+            if (has_res && pass + 1 < 8) load_res(pass + 1, rn);                                                 \
+            if (pass + 1 < 8) PATCH_WRITE(pass + 1);                                                             \
+            const float *pr = patch0 + (pass & 1) * (32 * 36);                                                   \
+            float4 v[4];                                                                                         \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4 *>(pr + (8 * q + prow) * 36 + pcol); \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
+                const int64_t m = m0 + 8 * q + prow;                                                             \
+                if (!(MASKED) || m < p.m)                                                                        \
+                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + m * N + n) =                  \
+                        make_float4(p.alpha * v[q].x + bv.x + r[q].x, p.alpha * v[q].y + bv.y + r[q].y, p.alpha * v[q].z + bv.z + r[q].z, p.alpha * v[q].w + bv.w + r[q].w); \
+            }                                                                                                    \
         }
+        PATCH_WRITE(0);
+        if ((int64_t)(mt + 1) * TM <= p.m) { EPI0_PASSES(false) } else { EPI0_PASSES(true) }
+#undef EPI0_PASSES
 #undef PATCH_WRITE
         return;
     }
@@ -509,6 +552,9 @@ struct GemmProf {
 } g_prof;
 constexpr size_t PROF_POOL = 2 * 8192;
 int g_gm = 0, g_gn = 0;                // tile-walk override (tools/micro); 0: the defaults
+#ifdef LEMON_GEMM_PHASES
+unsigned long long *g_phase_dbg = nullptr;
+#endif
 int g_mfma_shape = 0;                  // 0: not decided yet ($LEMON_GEMM_MFMA, default 16); tools/micro sets it directly
 void walk_override() {
     static bool read = false;
@@ -579,6 +625,9 @@ extern "C" int lemon_linear_f16x3t(const uint16_t *at_dev, const uint16_t *wt_de
     int64_t grid = ((blocks + 7) / 8) * p.gm * p.gn * 8;
     LEMON_REQUIRE(grid < ((int64_t)1 << 31), "grid size");
     p.vblocks = (int)grid;
+#ifdef LEMON_GEMM_PHASES
+    p.dbg = g_phase_dbg;
+#endif
     const size_t lds = (size_t)NB * STAGE;
     // the 72 KB of dynamic LDS need the attribute on every DEVICE this process launches on (it is per device, not per process)
     int dev = 0;

@@ -191,6 +191,19 @@ int main(int argc, char **argv) {
                 float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
                 t[v].push_back(ms / reps * 1e3f);
             }
+#ifdef LEMON_GEMM_PHASES
+        {   // diagnostic build: where a workgroup of the 16x16x32 kernel spends its shader cycles
+            if (!g_phase_dbg) CHECK(hipMalloc(&g_phase_dbg, 32));
+            CHECK(hipMemset(g_phase_dbg, 0, 32));
+            for (int i = 0; i < 5; ++i) run(1);
+            CHECK(hipDeviceSynchronize());
+            unsigned long long h[4];
+            CHECK(hipMemcpy(h, g_phase_dbg, 32, hipMemcpyDeviceToHost));
+            const double wg = (double)h[3], tot = (double)(h[0] + h[1] + h[2]);
+            printf("  [phases] %-22s cycles per workgroup: prologue (to the first barrier) %.0f (%.1f %%), main loop %.0f (%.1f %%), epilogue incl. store drain %.0f (%.1f %%)\n",
+                   s.name, h[0] / wg, 100.0 * h[0] / tot, h[1] / wg, 100.0 * h[1] / tot, h[2] / wg, 100.0 * h[2] / tot);
+        }
+#endif
         const double flop = 2.0 * s.m * (double)s.n * 3.0 * s.k;
         for (int v = 0; v < 2; ++v) {
             std::sort(t[v].begin(), t[v].end());
