@@ -59,7 +59,8 @@ struct GemmParams {
     int vblocks;               // virtual workgroup ids of the tile walk (>= tiles: ragged super-blocks leave holes)
     float alpha;
 #ifdef LEMON_GEMM_PHASES
-    unsigned long long *dbg;   // diagnostic build: summed shader cycles of [start -> first barrier passed, main loop, epilogue] + workgroups
+    unsigned long long *dbg;   // diagnostic build: summed shader cycles of [start -> first barrier passed, main loop, epilogue], workgroups,
+                               // 100-MHz ticks resident, in-loop cycles of [DMA wait + B, reads + block 0 + B', blocks 1-7]
 #endif
 };
 
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
     // their tiles in the same walk order -- measured 2-5 % SLOWER at the tower shapes: tools/micro/gemm_ab.hip, round 4)
     if (!tile_of_workgroup(p, blockIdx.x, mt, nt)) return;
 #ifdef LEMON_GEMM_PHASES
-    const unsigned long long ph0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long ph0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long ph1 = 0;
 #endif
     const int KS = p.ks;                                    // k16 slots: even (the host checks k % 32 == 0)
@@ -326,6 +327,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
     h16x8 af[4][2], wf[8][2];
     static_assert(NB == 3 && DMA_PER_STAGE == 6, "the slot arithmetic and the counted waits below");
 #define PIN_ACC16() do { _Pragma("unroll") for (int c_ = 0; c_ < 8; ++c_) _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) asm volatile("" : "+a"(acc[c_][b_])); } while (0)
+#if defined(LEMON_GEMM_ABLATE) && (LEMON_GEMM_ABLATE & 4)
+    constexpr bool MF_ALL = false;      // (diagnostic: the hi x hi product only)
+#else
+    constexpr bool MF_ALL = true;
+#endif
 #define MF_BLOCK(c)                                                                                              \
     do {                                                                                                         \
         _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) mfma16(acc[c][b_], wf[c][0], af[b_][0]);               \
@@ -336,21 +342,35 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
            block, seen on the GPU; tests/test_build_guard.py now checks the distance on the generated ISA) */        \
         h16x8 ws_ = wf[c][0] * (_Float16)0.00048828125f;                                                         \
         asm volatile("" : "+v"(ws_));                                                                            \
-        _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) mfma16(acc[c][b_], wf[c][1], af[b_][0]);               \
-        _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) mfma16(acc[c][b_], ws_, af[b_][1]);                    \
+        if (MF_ALL) { _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) mfma16(acc[c][b_], wf[c][1], af[b_][0]); }  \
+        if (MF_ALL) { _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) mfma16(acc[c][b_], ws_, af[b_][1]); }       \
     } while (0)
     int p0 = 0, p1 = 1;                                     // ring positions of slots t, t+1
     PIN_ACC16();
+#ifdef LEMON_GEMM_PHASES
+    // inside the loop: (a) the DMA wait + barrier B, (b) fragment reads + weight block 0 + barrier B', (c) the other seven
+    // weight blocks with the DMA issue.  (s_memtime returns through LGKM_CNT: stamped only where no LDS read is in flight.)
+    unsigned long long lp_a = 0, lp_b = 0, lp_c = 0, lt = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lt));
+#define LSTAMP(acc) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(now_)); acc += now_ - lt; lt = now_; } while (0)
+#else
+#define LSTAMP(acc) do { } while (0)
+#endif
     for (int t = 0; t < KS; t += 2) {
         PIN_ACC16();
+        LSTAMP(lp_c);
         // slots t and t+1 have landed (this wave's share; the barrier makes it everyone's): the only younger DMAs are slot t+2's
         if (t + 2 < KS) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #ifdef LEMON_GEMM_PHASES
         if (t == 0) ph1 = __builtin_amdgcn_s_memtime();
 #endif
+        LSTAMP(lp_a);
         const unsigned sb = (unsigned)((upper ? p1 : p0) * STAGE);
         const unsigned pa = fa + sb, pw = fw + sb;
+#if defined(LEMON_GEMM_ABLATE) && (LEMON_GEMM_ABLATE & 2)
+        if (t == 0) {   // (diagnostic: fragments read once, every later step reuses them)
+#endif
         // LGKM_CNT is a 4-bit counter: never more than 15 LDS reads in flight, or the counted waits below read a wrapped count
         // (seen: 24 reads issued at once -> `lgkmcnt(14)` fell through with the fragments still on their way).  Two batches:
         // 14 reads (activations + weight blocks 0-2), wait for the first ten, then the other ten behind at most four.
@@ -373,11 +393,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
             wf[c][0] = lds128(pw, (c >> 1) * 1024 + (c & 1) * 256);
             wf[c][1] = lds128(pw, BLKW + (c >> 1) * 1024 + (c & 1) * 256);
         }
+#if defined(LEMON_GEMM_ABLATE) && (LEMON_GEMM_ABLATE & 2)
+        }
+#endif
         MF_BLOCK(0);
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(wf[2][0]), "+v"(wf[2][1]), "+v"(wf[3][0]), "+v"(wf[3][1]), "+v"(wf[4][0]),
                        "+v"(wf[4][1]), "+v"(wf[5][0]), "+v"(wf[5][1]), "+v"(wf[6][0]), "+v"(wf[6][1]), "+v"(wf[7][0]), "+v"(wf[7][1]) : : "memory");
         __builtin_amdgcn_s_barrier();                       // B': every wave has read both slots
+        LSTAMP(lp_b);
 #ifdef LEMON_GEMM_DMA_BURST
         if (t + 3 < KS) issue(t + 3, p0);
         if (t + 4 < KS) issue(t + 4, p1);
@@ -385,7 +409,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
 #else
         // the twelve 1-KB DMA pieces of slots t+3, t+4 go out two at a time between the weight blocks' MFMAs (same order, same
         // counts for the waits above): issued in one burst behind B' they kept the wave from its MFMAs for their whole issue time
+#if defined(LEMON_GEMM_ABLATE) && (LEMON_GEMM_ABLATE & 1)
+        const bool d3 = false, d4 = false;     // (diagnostic: no operand traffic inside the loop)
+#else
         const bool d3 = t + 3 < KS, d4 = t + 4 < KS;
+#endif
         const char *as3 = a_src + (size_t)(t + 3) * 2 * BLKA, *ws3 = w_src + (size_t)(t + 3) * 2 * BLKW;
         const char *as4 = a_src + (size_t)(t + 4) * 2 * BLKA, *ws4 = w_src + (size_t)(t + 4) * 2 * BLKW;
         const unsigned la3 = lds0 + p0 * STAGE + wave * (BLKA / 2), lw3 = lds0 + p0 * STAGE + 2 * BLKA + wave * (BLKW / 2);
@@ -404,18 +432,23 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
     }
 #undef MF_BLOCK
 #undef PIN_ACC16
+    LSTAMP(lp_c);
+#undef LSTAMP
     // ---- epilogue: the lane holds row m = r16 of activation block b and columns n = 4 kg + e of weight block c ----
     const int N = p.n;
 #ifdef LEMON_GEMM_PHASES
     const unsigned long long ph2 = __builtin_amdgcn_s_memtime();
     struct PhaseEnd {
-        unsigned long long *dbg, a, b, c; int tid;
+        unsigned long long *dbg, a, b, c, r, la, lb, lc; int tid;
         __device__ ~PhaseEnd() {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned long long d = __builtin_amdgcn_s_memtime();
-            if (dbg && tid == 0) { atomicAdd(dbg, b - a); atomicAdd(dbg + 1, c - b); atomicAdd(dbg + 2, d - c); atomicAdd(dbg + 3, 1ull); }
+            const unsigned long long d = __builtin_amdgcn_s_memtime(), rd = __builtin_amdgcn_s_memrealtime();
+            if (dbg && tid == 0) {
+                atomicAdd(dbg, b - a); atomicAdd(dbg + 1, c - b); atomicAdd(dbg + 2, d - c); atomicAdd(dbg + 3, 1ull);
+                atomicAdd(dbg + 4, rd - r); atomicAdd(dbg + 5, la); atomicAdd(dbg + 6, lb); atomicAdd(dbg + 7, lc);
+            }
         }
-    } phase_end{p.dbg, ph0, ph1, ph2, tid};
+    } phase_end{p.dbg, ph0, ph1, ph2, rt0, lp_a, lp_b, lp_c, tid};
 #endif
     if (EPI == 0) {
         // fp32 row-major (+ residual) in full 128-byte lines: 2 x 2 accumulator tiles (32 m x 32 n) per pass through the

@@ -105,8 +105,8 @@ int main(int argc, char **argv) {
         const size_t out_bytes = s.epi ? (size_t)mp * s.n * 4 : (size_t)s.m * s.n * 4;
         CHECK(hipMalloc(&out[0], out_bytes)); CHECK(hipMalloc(&out[1], out_bytes));
         CHECK(hipMemset(at, 0, (size_t)mp * s.k * 4));
-        hipLaunchKernelGGL(k_fill_normal, dim3(4096), dim3(256), 0, 0, x, (size_t)s.m * s.k, 1.0f, 1u);
-        hipLaunchKernelGGL(k_fill_normal, dim3(4096), dim3(256), 0, 0, w, (size_t)s.n * s.k, 0.02f, 77u);
+        hipLaunchKernelGGL(k_fill_normal, dim3(4096), dim3(256), 0, 0, x, (size_t)s.m * s.k, getenv("GEMM_ZERO") ? 0.0f : 1.0f, 1u);
+        hipLaunchKernelGGL(k_fill_normal, dim3(4096), dim3(256), 0, 0, w, (size_t)s.n * s.k, getenv("GEMM_ZERO") ? 0.0f : 0.02f, 77u);
         hipLaunchKernelGGL(k_fill_normal, dim3(64), dim3(256), 0, 0, bias, (size_t)s.n, 0.1f, 5u);
         hipLaunchKernelGGL(k_fill_normal, dim3(4096), dim3(256), 0, 0, res, (size_t)s.m * s.n, 1.0f, 9u);
         const float wscale = 8192.0f * 16.0f;     // max |w| ~ 0.04 -> ~2^12..2^13 (a power of two, as weight_scale_f16x3 picks)
@@ -193,15 +193,20 @@ int main(int argc, char **argv) {
             }
 #ifdef LEMON_GEMM_PHASES
         {   // diagnostic build: where a workgroup of the 16x16x32 kernel spends its shader cycles
-            if (!g_phase_dbg) CHECK(hipMalloc(&g_phase_dbg, 32));
-            CHECK(hipMemset(g_phase_dbg, 0, 32));
+            if (!g_phase_dbg) CHECK(hipMalloc(&g_phase_dbg, 64));
+            CHECK(hipMemset(g_phase_dbg, 0, 64));
             for (int i = 0; i < 5; ++i) run(1);
             CHECK(hipDeviceSynchronize());
-            unsigned long long h[4];
-            CHECK(hipMemcpy(h, g_phase_dbg, 32, hipMemcpyDeviceToHost));
+            unsigned long long h[8];
+            CHECK(hipMemcpy(h, g_phase_dbg, 64, hipMemcpyDeviceToHost));
             const double wg = (double)h[3], tot = (double)(h[0] + h[1] + h[2]);
             printf("  [phases] %-22s cycles per workgroup: prologue (to the first barrier) %.0f (%.1f %%), main loop %.0f (%.1f %%), epilogue incl. store drain %.0f (%.1f %%)\n",
                    s.name, h[0] / wg, 100.0 * h[0] / tot, h[1] / wg, 100.0 * h[1] / tot, h[2] / wg, 100.0 * h[2] / tot);
+            // s_memtime counts shader cycles, s_memrealtime the constant 100 MHz reference: their ratio is the clock the workgroups ran at
+            printf("  [phases] %-22s mean shader clock while resident: %.0f MHz (%.0f shader cycles, %.2f us per workgroup)\n", s.name, tot / (double)h[4] * 100.0, tot / wg, h[4] / wg / 100.0);
+            const double lp = (double)(h[5] + h[6] + h[7]);
+            printf("  [phases] %-22s inside the loop: DMA wait + barrier B %.1f %%, fragment reads + weight block 0 + barrier B' %.1f %%, weight blocks 1-7 + DMA issue %.1f %% (%.0f cycles per k32 step; 96 MFMAs = 1536)\n",
+                   s.name, 100.0 * h[5] / lp, 100.0 * h[6] / lp, 100.0 * h[7] / lp, lp / wg / (s.k / 32));
         }
 #endif
         const double flop = 2.0 * s.m * (double)s.n * 3.0 * s.k;
