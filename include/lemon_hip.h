@@ -229,6 +229,22 @@ int lemon_layernorm_f16x3t(const float *x_dev, const float *weight_dev, const fl
 int lemon_linear_f16x3t(const uint16_t *at_dev, const uint16_t *wt_dev, const float *bias_dev, const float *residual_dev,
                         int64_t m, int n, int k, float alpha, int act, int out_operand, void *out_dev, void *stream);
 int lemon_unpack_act_f16x3t(const uint16_t *at_dev, int64_t rows, int k, float *y_dev, void *stream);
+/* LayerNorm folded into the hand-written GEMMs (HF CLIPEncoderLayer.layer_norm1 / layer_norm2 in front of q/k/v_proj and
+ * mlp.fc1; in-tree twin lib/models/chexzero_clip.py:171-183: ln_1, ln_2).  LN(x) W^T + b = rstd (x W'^T - mean c) + b' with
+ * W' = W diag(gamma), c = W' 1, b' = b + W beta, so the GEMM behind a LayerNorm takes the RAW residual stream as its operand:
+ *   lemon_linear_f16x3t_ln(..., row_aff_dev, colsum_dev, NULL, NULL):  out = act(row_aff[m].x * (alpha x W'^T) + row_aff[m].y *
+ *       colsum[n] + bias[n]) (+ residual) with row_aff [m, 2] = (rstd, -mean rstd) and colsum [n] = alpha * sum_k W'[n, k]
+ *       (of the PACKED weight: hi + lo), bias = b'
+ *   lemon_linear_f16x3t_ln(..., NULL, NULL, emit_t_dev, emit_stats_dev) (act none, fp32 out):  the fp32 result is ALSO written as
+ *       the tile-major activation operand emit_t_dev (ceil(m / 128) * 128 rows x n) and emit_stats_dev [m, n / 128, 2] receives
+ *       per row and 128-column group (mean, sum of squared deviations); lemon_ln_finalize merges them into row_aff
+ *   lemon_rowstats_f16x3t: operand + row_aff of a tensor no GEMM produced (a tower's first block)
+ * k must be a multiple of 32.  With all four extra pointers NULL the call is lemon_linear_f16x3t. */
+int lemon_linear_f16x3t_ln(const uint16_t *at_dev, const uint16_t *wt_dev, const float *bias_dev, const float *residual_dev,
+                           int64_t m, int n, int k, float alpha, int act, int out_operand, void *out_dev, const float *row_aff_dev,
+                           const float *colsum_dev, uint16_t *emit_t_dev, float *emit_stats_dev, void *stream);
+int lemon_ln_finalize(const float *partials_dev, int64_t rows, int width, float eps, float *row_aff_dev, void *stream);
+int lemon_rowstats_f16x3t(const float *x_dev, float eps, int64_t rows, int width, uint16_t *yt_dev, float *row_aff_dev, void *stream);
 /* Timing of the hand-written GEMM (no reference counterpart; bench.py's roofline object): while profiling is on every
  * lemon_linear_f16x3t launch of this process is bracketed by HIP events on its launch stream (a pool of 8 192 pairs, made
  * on the first call; launches beyond it are not bracketed).  profile_read waits for the recorded events, returns the number

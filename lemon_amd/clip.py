@@ -239,6 +239,53 @@ class Block(nn.Module):
         w, a_ = self._w_split("fc2", ops, mode)
         return ops.linear_split(ops.split_operand(h, mode), w, self.fc2.bias, residual=x, alpha=a_ / s)
 
+    def _w_tiled_ln(self, name, ln, ops, extra):
+        """The layer's weight with the LayerNorm `ln` in front of it folded in (ops.fold_layernorm_weight), once per version of
+        the four tensors: (packed weight, 1 / wscale, colsum, bias')."""
+        lin = getattr(self, name)
+        key = (lin.weight.data_ptr(), lin.weight._version, lin.bias.data_ptr(), lin.bias._version,
+               ln.weight.data_ptr(), ln.weight._version, ln.bias.data_ptr(), ln.bias._version, extra)
+        cache = self.__dict__.setdefault("_split_cache", {})
+        hit = cache.get((name, "tiled_ln"))
+        if hit is None or hit[0] != key:
+            hit = (key,) + tuple(ops.fold_layernorm_weight(lin.weight, lin.bias, ln.weight, ln.bias, extra))
+            cache[(name, "tiled_ln")] = hit
+        return hit[1:]
+
+    def forward_chain(self, x, causal, carry=None, emit=True):
+        """forward(x, causal) for a run of consecutive blocks: -> (x_out, carry_out).  Where the hand-written GEMMs run the
+        whole block (LEMON_GEMM=f16x3, LEMON_MLP=block) the two LayerNorms are FOLDED into them (ops.ln_fold_enabled): `carry` =
+        (this block's input as the tile-major operand, its row-statistics partials) as the previous block's fc2 left them (None:
+        made here with one pass), and with `emit` this block's fc2 leaves the same for the next one."""
+        B, L, W = x.shape
+        mlp = self.fc1.weight.shape[0]
+        from . import ops
+        ok = (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and W % 32 == 0 and mlp % 32 == 0 and W <= 1024
+              and ops.gemm_mode() == "f16x3" and ops.mlp_mode() == "block" and ops.ln_fold_enabled()
+              and ops.block_fused_supported(W, mlp, self.heads, L))
+        if not ok:
+            return self(x, causal), None
+        ops.select_attention_arithmetic("f16x3")
+        m = B * L
+        if carry is None:
+            xt, aff = ops.rowstats_t(x, self.ln1.eps)
+        else:
+            xt, aff = carry[0], ops.ln_finalize(carry[1], m, W, self.ln1.eps)
+        wq, aq, csq, bq = self._w_tiled_ln("qkv", self.ln1, ops, 1.0)
+        qkv = ops.linear_t_ln(xt, wq, m, 3 * W, W, bq, alpha=aq, out_shape=(B, L, 3 * W), row_aff=aff, colsum=csq)
+        wo, ao = self._w_tiled("out", ops)
+        x, xt, st = ops.linear_t_ln(ops.attention_t(qkv, self.heads, causal), wo, m, W, W, self.out.bias, residual=x, alpha=ao,
+                                    out_shape=x.shape, emit=True)
+        aff = ops.ln_finalize(st, m, W, self.ln2.eps)
+        s = ops.QUICK_GELU_SCALE
+        w1, a1, cs1, b1 = self._w_tiled_ln("fc1", self.ln2, ops, s)
+        ht = ops.linear_t_ln(xt, w1, m, mlp, W, b1, act="silu", alpha=s * a1, row_aff=aff, colsum=cs1)
+        w2, a2 = self._w_tiled("fc2", ops)
+        if not emit:
+            return ops.linear_t(ht, w2, m, W, mlp, self.fc2.bias, residual=x, alpha=a2 / s, out_shape=x.shape), None
+        x, xt, st = ops.linear_t_ln(ht, w2, m, W, mlp, self.fc2.bias, residual=x, alpha=a2 / s, out_shape=x.shape, emit=True)
+        return x, (xt, st)
+
     def _sdpa(self, qkv, B, L, W, causal):
         q, k, v = qkv.view(B, L, 3, self.heads, W // self.heads).permute(2, 0, 3, 1, 4)
         return F.scaled_dot_product_attention(q, k, v, is_causal=causal).transpose(1, 2).reshape(B, L, W)
@@ -294,8 +341,9 @@ class VisionTower(nn.Module):
         else:
             x = torch.cat([self.cls.expand(x.shape[0], 1, -1), x], dim=1) + self.pos
             x = self.pre_ln(x)
-        for b in self.blocks[:-1]:
-            x = b(x, causal=False)
+        carry = None
+        for i, b in enumerate(self.blocks[:-1]):
+            x, carry = b.forward_chain(x, causal=False, carry=carry, emit=i + 2 < len(self.blocks))
         batch = torch.arange(x.shape[0], device=x.device)
         x = self.blocks[-1](x, causal=False, rows=(batch, torch.zeros_like(batch)))   # CLS rows of the last block
         if fused:
@@ -334,8 +382,9 @@ class TextTower(nn.Module):
                                 L, self.tok.weight, self.pos)
         else:
             x = self.tok(input_ids[:, :L]) + self.pos[:L]
-        for b in self.blocks[:-1]:
-            x = b(x, causal=True)
+        carry = None
+        for i, b in enumerate(self.blocks[:-1]):
+            x, carry = b.forward_chain(x, causal=True, carry=carry, emit=i + 2 < len(self.blocks))
         x = self.blocks[-1](x, causal=True, rows=(torch.arange(x.shape[0], device=x.device), eot))   # EOT rows only
         if fused:
             return ops.linear(ops.layer_norm(x, self.final_ln.weight, self.final_ln.bias, self.final_ln.eps), self.proj.weight)

@@ -139,10 +139,12 @@ __global__ __launch_bounds__(256) void k_layernorm8(const float *__restrict__ x,
 // 57 us for the row-major operand at 50 000 x 768).  Here a workgroup normalises eight consecutive rows (two per wave), parks
 // their hi / lo chunks in LDS as [chunk][part][row] and writes them out eight rows = one 128-byte line per chunk and part.
 // Same arithmetic and element-to-lane mapping as k_layernorm8: the operand holds exactly the split of lemon_layernorm_f32.
-template <int CH8>
+// RAW: the operand holds the split of x itself and aff[row] = (rstd, -mean rstd): the input side of a LayerNorm folded into the
+// GEMM (lemon_linear_f16x3t_ln) for the first block of a tower, whose input no GEMM epilogue produced.
+template <int CH8, bool RAW = false>
 __global__ __launch_bounds__(256) void k_layernorm8_t(const float *__restrict__ x, const float *__restrict__ w,
                                                       const float *__restrict__ b, float eps, int64_t rows, int width,
-                                                      unsigned short *__restrict__ yt) {
+                                                      unsigned short *__restrict__ yt, float2 *__restrict__ aff = nullptr) {
     extern __shared__ __attribute__((aligned(16))) us8 s_t[];          // [8 rows][2 parts x width/8 chunks (+1: odd pitch)] 16-byte slots
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = width >> 3;
@@ -180,6 +182,7 @@ __global__ __launch_bounds__(256) void k_layernorm8_t(const float *__restrict__ 
         const float rstd = rsqrtf(q / (float)width + eps);
         const float4 *w4 = reinterpret_cast<const float4 *>(w);
         const float4 *b4 = reinterpret_cast<const float4 *>(b);
+        if (RAW && lane == 0) aff[row] = make_float2(rstd, -mean * rstd);
 #pragma unroll
         for (int i = 0; i < CH8; ++i) {
             const int c = lane + 64 * i;
@@ -187,11 +190,15 @@ __global__ __launch_bounds__(256) void k_layernorm8_t(const float *__restrict__ 
                 float o[8];
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    const float4 ww = w4[2 * c + hf], bb = b4[2 * c + hf];
-                    o[4 * hf] = (v[i][hf].x - mean) * rstd * ww.x + bb.x;
-                    o[4 * hf + 1] = (v[i][hf].y - mean) * rstd * ww.y + bb.y;
-                    o[4 * hf + 2] = (v[i][hf].z - mean) * rstd * ww.z + bb.z;
-                    o[4 * hf + 3] = (v[i][hf].w - mean) * rstd * ww.w + bb.w;
+                    if (RAW) {
+                        o[4 * hf] = v[i][hf].x; o[4 * hf + 1] = v[i][hf].y; o[4 * hf + 2] = v[i][hf].z; o[4 * hf + 3] = v[i][hf].w;
+                    } else {
+                        const float4 ww = w4[2 * c + hf], bb = b4[2 * c + hf];
+                        o[4 * hf] = (v[i][hf].x - mean) * rstd * ww.x + bb.x;
+                        o[4 * hf + 1] = (v[i][hf].y - mean) * rstd * ww.y + bb.y;
+                        o[4 * hf + 2] = (v[i][hf].z - mean) * rstd * ww.z + bb.z;
+                        o[4 * hf + 3] = (v[i][hf].w - mean) * rstd * ww.w + bb.w;
+                    }
                 }
                 us8 hi, lo;
 #pragma unroll
@@ -389,6 +396,24 @@ extern "C" int lemon_layernorm_f16x3t(const float *x_dev, const float *weight_de
     if (width <= 512) hipLaunchKernelGGL((k_layernorm8_t<1>), grid, block, lds, stream, x_dev, weight_dev, bias_dev, eps, rows, width, yt_dev);
     else if (width <= 1024) hipLaunchKernelGGL((k_layernorm8_t<2>), grid, block, lds, stream, x_dev, weight_dev, bias_dev, eps, rows, width, yt_dev);
     else hipLaunchKernelGGL((k_layernorm8_t<4>), grid, block, lds, stream, x_dev, weight_dev, bias_dev, eps, rows, width, yt_dev);
+    LEMON_HIP_CHECK(hipGetLastError());
+    return LEMON_OK;
+}
+
+// The input side of a folded LayerNorm for a tensor no GEMM epilogue produced (the first block of a tower): x as the tile-major
+// operand + the rows' (rstd, -mean rstd).  Same statistics arithmetic as lemon_layernorm_f32.
+extern "C" int lemon_rowstats_f16x3t(const float *x_dev, float eps, int64_t rows, int width, uint16_t *yt_dev, float *row_aff_dev, void *stream_) {
+    LEMON_REQUIRE(rows >= 0 && width > 0 && (width & 15) == 0 && width <= 2048, "rows >= 0, width a multiple of 16, <= 2048");
+    if (rows == 0) return LEMON_OK;
+    LEMON_REQUIRE(x_dev && yt_dev && row_aff_dev, "null pointer");
+    LEMON_REQUIRE(((((uintptr_t)x_dev) | ((uintptr_t)yt_dev) | ((uintptr_t)row_aff_dev)) & 15) == 0, "aligned pointers");
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid((unsigned)((rows + 7) / 8)), block(256);
+    const size_t lds = (size_t)(2 * (width / 8) + 1) * 8 * 16;
+    float2 *aff = reinterpret_cast<float2 *>(row_aff_dev);
+    if (width <= 512) hipLaunchKernelGGL((k_layernorm8_t<1, true>), grid, block, lds, stream, x_dev, nullptr, nullptr, eps, rows, width, yt_dev, aff);
+    else if (width <= 1024) hipLaunchKernelGGL((k_layernorm8_t<2, true>), grid, block, lds, stream, x_dev, nullptr, nullptr, eps, rows, width, yt_dev, aff);
+    else hipLaunchKernelGGL((k_layernorm8_t<4, true>), grid, block, lds, stream, x_dev, nullptr, nullptr, eps, rows, width, yt_dev, aff);
     LEMON_HIP_CHECK(hipGetLastError());
     return LEMON_OK;
 }

@@ -58,6 +58,11 @@ struct GemmParams {
     int gm, gn;                // super-block of the tile walk: gm m-tiles x gn n-tiles per XCD at a time
     int vblocks;               // virtual workgroup ids of the tile walk (>= tiles: ragged super-blocks leave holes)
     float alpha;
+    // LayerNorm folded into the GEMM (k_gemm_f16x3t16 only; see "LayerNorm fold" above lemon_linear_f16x3t_ln):
+    const float2 *row_aff;     // FOLD: per row (rstd, -mean rstd) of the LayerNorm in front of this GEMM, or null
+    const float *colsum;       // FOLD: [n] alpha * sum_k of the packed weight row (the weight carries the LayerNorm gain)
+    unsigned short *emit_t;    // EMIT (EPI 0): the fp32 result also as the tile-major operand of the next GEMM (its k = n), or null
+    float *emit_stats;         // EMIT: [m][2 n_tiles][2] per row and 128-column group (mean, sum of squared deviations)
 #ifdef LEMON_GEMM_PHASES
     unsigned long long *dbg;   // diagnostic build: summed shader cycles of [start -> first barrier passed, main loop, epilogue], workgroups,
                                // 100-MHz ticks resident, in-loop cycles of [DMA wait + B, reads + block 0 + B', blocks 1-7]
@@ -283,8 +288,9 @@ __device__ __forceinline__ void mfma16(f32x4 &acc, const h16x8 &a, const h16x8 &
 #endif
 }
 
-template <int EPI>
+template <int EPI, bool FOLD, bool EMIT>
 __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
+    static_assert(!EMIT || EPI == 0, "the operand + statistics output rides on the fp32 epilogue");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
         }
     } phase_end{p.dbg, ph0, ph1, ph2, rt0, lp_a, lp_b, lp_c, tid};
 #endif
-    if (EPI == 0) {
+    if (EPI == 0 && !FOLD && !EMIT) {
         // fp32 row-major (+ residual) in full 128-byte lines: 2 x 2 accumulator tiles (32 m x 32 n) per pass through the
         // wave-private LDS patch (the ring is free: every wave's reads ended before the last B').  The residual of pass i + 1 is
         // fetched while pass i makes its LDS round trip and stores: fetched inside the pass that uses it, every pass waited a
@@ -519,20 +525,147 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
 #undef PATCH_WRITE
         return;
     }
+    if (EPI == 0) {
+        // The fp32 epilogue with a folded LayerNorm on one side or the other (see "LayerNorm fold" at lemon_linear_f16x3t_ln).  As
+        // above -- 32 x 32 patches through LDS, the next pass's residual, bias and weight-row sums fetched one pass ahead --, with
+        // the passes ordered row half first (all four column groups of rows 0-31, then of rows 32-63): a row's statistics are
+        // complete after four passes and only four rows' running sums are live at a time.
+        //   FOLD: out = rstd_m (alpha acc) - mean_m rstd_m colsum_n + bias_n (+ residual); the wave's 64 (rstd, -mean rstd) pairs
+        //         wait in LDS
+        //   EMIT: the stored value also goes out as the next GEMM's tile-major activation operand (eight rows x 16 B = one
+        //         128-byte line per store instruction and k chunk), and as a (mean, M2) partial per row and 128-column group:
+        //         shifted sums over the lane's 16 values (shift = the first one: the sums stay at the size of the row's spread),
+        //         equal-count pairwise merges over the row's eight lanes
+        float *patch0 = reinterpret_cast<float *>(smem) + wave * (2 * 32 * 36);
+        float2 *saff = reinterpret_cast<float2 *>(smem + 4 * (2 * 32 * 36) * 4) + wave * 64;
+        const int prow = lane >> 3, pcol = 4 * (lane & 7);
+        const bool has_res = p.residual != nullptr;
+        const int64_t m_last = p.m - 1;
+        const int64_t mw = (int64_t)mt * TM + wm * (IB * 32);          // the wave's first row
+        if (FOLD) { const int64_t m = mw + lane; saff[lane] = p.row_aff[m < m_last ? m : m_last]; }
+        auto load_next = [&](int pass, float4 (&r)[4], float4 &bv, float4 &cs) {
+            const int n = nt * TN + wn * 128 + (pass & 3) * 32 + pcol;
+            bv = make_float4(0.f, 0.f, 0.f, 0.f); cs = bv;
+            if (p.bias) bv = *reinterpret_cast<const float4 *>(p.bias + n);
+            if (FOLD) cs = *reinterpret_cast<const float4 *>(p.colsum + n);
+            if (has_res) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t m = mw + (pass >> 2) * 32 + 8 * q + prow;
+                    r[q] = *reinterpret_cast<const float4 *>(p.residual + (m < m_last ? m : m_last) * N + n);
+                }
+            }
+        };
+        float4 rn[4], bn, cn;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rn[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        load_next(0, rn, bn, cn);
+        float st_s[4], st_1[4], st_2[4];
+#define PATCH_WRITE(pass_)                                                                                       \
+        do {                                                                                                     \
+            float *pw_ = patch0 + ((pass_) & 1) * (32 * 36);                                                     \
+            _Pragma("unroll") for (int ci = 0; ci < 2; ++ci) _Pragma("unroll") for (int bi = 0; bi < 2; ++bi) { \
+                const f32x4 a = acc[2 * ((pass_) & 3) + ci][2 * ((pass_) >> 2) + bi];                            \
+                *reinterpret_cast<float4 *>(pw_ + (bi * 16 + r16) * 36 + ci * 16 + 4 * kg) = make_float4(a[0], a[1], a[2], a[3]); \
+            }                                                                                                    \
+        } while (0)
+#define EPI0_PASSES(MASKED)                                                                                      \
+        _Pragma("unroll") for (int pass = 0; pass < 8; ++pass) {                                                 \
+            const int cp = pass & 3, bp = pass >> 2;                                                             \
+            const int n = nt * TN + wn * 128 + cp * 32 + pcol;                                                   \
+            const int64_t m0 = mw + bp * 32;                                                                     \
+            float4 r[4];                                                                                         \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) r[q] = rn[q];                                          \
+            const float4 bv = bn, cs = cn;                                                                       \
+            if (pass + 1 < 8) load_next(pass + 1, rn, bn, cn);                                                   \
+            if (pass + 1 < 8) PATCH_WRITE(pass + 1);                                                             \
+            const float *pr = patch0 + (pass & 1) * (32 * 36);                                                   \
+            float4 v[4];                                                                                         \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4 *>(pr + (8 * q + prow) * 36 + pcol); \
+            float2 af[4];                                                                                        \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) af[q] = FOLD ? saff[bp * 32 + 8 * q + prow] : make_float2(1.0f, 0.0f); \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
+                const int64_t m = m0 + 8 * q + prow;                                                             \
+                float o_[4] = {p.alpha * v[q].x, p.alpha * v[q].y, p.alpha * v[q].z, p.alpha * v[q].w};          \
+                if (FOLD) {                                                                                      \
+                    /* the four products are kept as single registers: left alone hipcc pairs them into                \
+                       `v_pk_mul_f32 ... op_sel:[0,1]` (low lane = HIGH dword of the (rstd, -mean rstd) pair), and with  \
+                       that instruction right behind the pair's arrival the low results of lanes 48-63 came out wrong  \
+                       now and then (seen on the GPU, never with the four scalar multiplies; tests/test_build_guard.py   \
+                       refuses the pattern in these kernels) */                                                       \
+                    float t_[4] = {af[q].y * cs.x, af[q].y * cs.y, af[q].y * cs.z, af[q].y * cs.w};              \
+                    asm volatile("" : "+v"(t_[0]), "+v"(t_[1]), "+v"(t_[2]), "+v"(t_[3]));                       \
+                    o_[0] = af[q].x * o_[0] + t_[0]; o_[1] = af[q].x * o_[1] + t_[1];                             \
+                    o_[2] = af[q].x * o_[2] + t_[2]; o_[3] = af[q].x * o_[3] + t_[3];                             \
+                }                                                                                                \
+                o_[0] += bv.x + r[q].x; o_[1] += bv.y + r[q].y; o_[2] += bv.z + r[q].z; o_[3] += bv.w + r[q].w;   \
+                if (!(MASKED) || m < p.m)                                                                        \
+                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + m * N + n) = make_float4(o_[0], o_[1], o_[2], o_[3]); \
+                if (EMIT) {                                                                                      \
+                    /* (rows beyond m land in the operand's pad rows: never read into a stored result) */        \
+                    h16x4 hi_, lo_;                                                                              \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                              \
+                        unsigned short a_, b_, c_;                                                               \
+                        split2h<false>(o_[e], a_, b_, c_);                                                       \
+                        hi_[e] = __builtin_bit_cast(_Float16, a_); lo_[e] = __builtin_bit_cast(_Float16, c_);    \
+                    }                                                                                            \
+                    unsigned short *base_ = p.emit_t + tiled_off(TM, m, n, 0, N);                                \
+                    *reinterpret_cast<h16x4 *>(base_) = hi_;                                                     \
+                    *reinterpret_cast<h16x4 *>(base_ + TM * 16) = lo_;                                           \
+                    if (cp == 0) { st_s[q] = o_[0]; st_1[q] = 0.0f; st_2[q] = 0.0f; }                            \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                              \
+                        float d_ = o_[e] - st_s[q];                                                              \
+                        asm volatile("" : "+v"(d_));      /* (single registers: no packed op with op_sel, see FOLD) */ \
+                        st_1[q] += d_; st_2[q] += d_ * d_;                                                       \
+                    }                                                                                            \
+                    if (cp == 3) {                                                                               \
+                        float mean = st_s[q] + st_1[q] * 0.0625f;                                                \
+                        float m2 = st_2[q] - st_1[q] * st_1[q] * 0.0625f;                                        \
+                        float cnt = 16.0f;                                                                       \
+                        _Pragma("unroll") for (int off = 1; off < 8; off <<= 1) {                                \
+                            const float mo = __shfl_xor(mean, off), m2o = __shfl_xor(m2, off);                   \
+                            const float dm = mo - mean;                                                          \
+                            m2 = m2 + m2o + dm * dm * (0.5f * cnt);                                              \
+                            mean = 0.5f * (mean + mo);                                                           \
+                            cnt *= 2.0f;                                                                         \
+                        }                                                                                        \
+                        if ((lane & 7) == 0 && m < p.m)                                                          \
+                            *reinterpret_cast<float2 *>(p.emit_stats + (m * (2 * p.n_tiles) + 2 * nt + wn) * 2) = make_float2(mean, m2); \
+                    }                                                                                            \
+                }                                                                                                \
+            }                                                                                                    \
+        }
+        PATCH_WRITE(0);
+        if ((int64_t)(mt + 1) * TM <= p.m) { EPI0_PASSES(false) } else { EPI0_PASSES(true) }
+#undef EPI0_PASSES
+#undef PATCH_WRITE
+        return;
+    }
     float4 bias8[8];                                        // (fetched once: behind the operand stores below hipcc must reload them)
+    float4 cs8[8];                                          // FOLD: the weight-row sums of the lane's columns
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         bias8[c] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias) bias8[c] = *reinterpret_cast<const float4 *>(p.bias + nt * TN + wn * 128 + c * 16 + 4 * kg);
+        if (FOLD) cs8[c] = *reinterpret_cast<const float4 *>(p.colsum + nt * TN + wn * 128 + c * 16 + 4 * kg);
     }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int64_t m = (int64_t)mt * TM + wm * (IB * 32) + b * 16 + r16;
+        float2 af = make_float2(1.0f, 0.0f);
+        if (FOLD) af = p.row_aff[m < p.m - 1 ? m : p.m - 1];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int n = nt * TN + wn * 128 + c * 16 + 4 * kg;
             const float4 bv = bias8[c];
-            const float o[4] = {p.alpha * acc[c][b][0] + bv.x, p.alpha * acc[c][b][1] + bv.y, p.alpha * acc[c][b][2] + bv.z, p.alpha * acc[c][b][3] + bv.w};
+            float o[4] = {p.alpha * acc[c][b][0], p.alpha * acc[c][b][1], p.alpha * acc[c][b][2], p.alpha * acc[c][b][3]};
+            if (FOLD) {
+                const float4 cs = cs8[c];
+                float t[4] = {af.y * cs.x, af.y * cs.y, af.y * cs.z, af.y * cs.w};     // (single registers: see the fp32 epilogue)
+                asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+                o[0] = af.x * o[0] + t[0]; o[1] = af.x * o[1] + t[1]; o[2] = af.x * o[2] + t[2]; o[3] = af.x * o[3] + t[3];
+            }
+            o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
             // the next GEMM's activation operand (its k = this n): the lane's four values are half a 16-byte slot, a wave's
             // store instruction covers two runs of 256 contiguous bytes
             h16x4 hi, lo;
@@ -569,6 +702,20 @@ __global__ __launch_bounds__(256) void k_unpack_act_t(const unsigned short *__re
     const int c = (int)(t - r * k);
     const float hi = f16_val(at[tiled_off(TILE_A_ROWS, r, c, 0, k)]), lo = f16_val(at[tiled_off(TILE_A_ROWS, r, c, 1, k)]);
     y[t] = hi + lo * 0.00048828125f;
+}
+
+// a row's (mean, M2) partials over `per`-column groups -> (rstd, -mean rstd) of its LayerNorm (one thread per row)
+__global__ __launch_bounds__(256) void k_ln_finalize(const float *__restrict__ part, int64_t rows, int np, float per, float eps, float2 *__restrict__ aff) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float2 *pr = reinterpret_cast<const float2 *>(part) + r * np;
+    float mean = 0.0f;
+    for (int i = 0; i < np; ++i) mean += pr[i].x;
+    mean /= (float)np;
+    float m2 = 0.0f;
+    for (int i = 0; i < np; ++i) { const float d = pr[i].x - mean; m2 += pr[i].y + per * d * d; }
+    const float rstd = rsqrtf(m2 / (per * (float)np) + eps);
+    aff[r] = make_float2(rstd, -mean * rstd);
 }
 
 // ---- host-side state of the launcher ----
@@ -628,11 +775,42 @@ extern "C" int lemon_unpack_act_f16x3t(const uint16_t *at_dev, int64_t rows, int
     return LEMON_OK;
 }
 
+// ---- LayerNorm fold ---------------------------------------------------------------------------------------------------------
+// LN(x) W^T + b = rstd (x W'^T - mean c) + b' with W' = W diag(gamma), c = W' 1, b' = b + W beta: the GEMM in front of which a
+// LayerNorm stands can take the RAW residual stream x as its activation operand and apply the row's (rstd, -mean rstd) and the
+// weight-row sums in its epilogue (FOLD) -- if the GEMM that PRODUCES x (output projection, fc2: fp32 + residual) also writes x
+// as the tile-major operand and leaves per-row statistics (EMIT): the LayerNorm pass (one read + one write of the token matrix,
+// 4.7 % of the headline step) disappears.  Statistics are (mean, M2) partials per row and 128-column group, shifted sums inside
+// a lane and pairwise merges (no E[x^2] - mean^2 cancellation); k_ln_finalize merges a row's partials.  Error: the split
+// operand now carries x instead of LN(x), so a product term's rounding (2^-22) scales with |x_k| rstd instead of |x_k - mean|
+// rstd -- a factor sqrt(1 + mean^2 / var) on the GEMM's error, 1.0x for the zero-mean rows of a transformer's residual stream.
+static int linear_f16x3t_impl(const uint16_t *at_dev, const uint16_t *wt_dev, const float *bias_dev, const float *residual_dev,
+                              int64_t m, int n, int k, float alpha, int act, int out_operand, void *out_dev,
+                              const float *row_aff_dev, const float *colsum_dev, uint16_t *emit_t_dev, float *emit_stats_dev, void *stream_);
+
 extern "C" int lemon_linear_f16x3t(const uint16_t *at_dev, const uint16_t *wt_dev, const float *bias_dev, const float *residual_dev,
                                    int64_t m, int n, int k, float alpha, int act, int out_operand, void *out_dev, void *stream_) {
+    return linear_f16x3t_impl(at_dev, wt_dev, bias_dev, residual_dev, m, n, k, alpha, act, out_operand, out_dev, nullptr, nullptr, nullptr, nullptr, stream_);
+}
+
+extern "C" int lemon_linear_f16x3t_ln(const uint16_t *at_dev, const uint16_t *wt_dev, const float *bias_dev, const float *residual_dev,
+                                      int64_t m, int n, int k, float alpha, int act, int out_operand, void *out_dev,
+                                      const float *row_aff_dev, const float *colsum_dev, uint16_t *emit_t_dev, float *emit_stats_dev, void *stream_) {
+    LEMON_REQUIRE((row_aff_dev != nullptr) == (colsum_dev != nullptr), "row_aff and colsum come together");
+    LEMON_REQUIRE((emit_t_dev != nullptr) == (emit_stats_dev != nullptr), "emit_t and emit_stats come together");
+    LEMON_REQUIRE(!emit_t_dev || (!out_operand && act == LEMON_ACT_NONE), "the operand + statistics output rides on the fp32 form");
+    LEMON_REQUIRE(!(row_aff_dev && emit_t_dev), "a GEMM either consumes a folded LayerNorm or produces the next one's input");
+    LEMON_REQUIRE(!(row_aff_dev || emit_t_dev) || k % 32 == 0, "the LayerNorm fold needs k a multiple of 32 (16x16x32 kernel)");
+    return linear_f16x3t_impl(at_dev, wt_dev, bias_dev, residual_dev, m, n, k, alpha, act, out_operand, out_dev, row_aff_dev, colsum_dev, emit_t_dev, emit_stats_dev, stream_);
+}
+
+static int linear_f16x3t_impl(const uint16_t *at_dev, const uint16_t *wt_dev, const float *bias_dev, const float *residual_dev,
+                              int64_t m, int n, int k, float alpha, int act, int out_operand, void *out_dev,
+                              const float *row_aff_dev, const float *colsum_dev, uint16_t *emit_t_dev, float *emit_stats_dev, void *stream_) {
     LEMON_REQUIRE(m >= 0 && n > 0 && k > 0 && n % TN == 0 && k % 16 == 0, "m >= 0, n a multiple of 256, k a multiple of 16");
     if (m == 0) return LEMON_OK;
     LEMON_REQUIRE(at_dev && wt_dev && out_dev, "null pointer");
+    LEMON_REQUIRE(((((uintptr_t)row_aff_dev) | ((uintptr_t)colsum_dev) | ((uintptr_t)emit_t_dev) | ((uintptr_t)emit_stats_dev)) & 15) == 0, "16-byte aligned pointers");
     LEMON_REQUIRE(((((uintptr_t)at_dev) | ((uintptr_t)wt_dev) | ((uintptr_t)out_dev) | ((uintptr_t)bias_dev) | ((uintptr_t)residual_dev)) & 15) == 0,
                   "16-byte aligned pointers");
     LEMON_REQUIRE((act == LEMON_ACT_NONE && !out_operand) || (act == LEMON_ACT_SILU && out_operand && !residual_dev),
@@ -641,6 +819,8 @@ extern "C" int lemon_linear_f16x3t(const uint16_t *at_dev, const uint16_t *wt_de
     GemmParams p;
     p.at = reinterpret_cast<const char *>(at_dev); p.wt = reinterpret_cast<const char *>(wt_dev);
     p.bias = bias_dev; p.residual = residual_dev; p.out = out_dev;
+    p.row_aff = reinterpret_cast<const float2 *>(row_aff_dev); p.colsum = colsum_dev;
+    p.emit_t = reinterpret_cast<unsigned short *>(emit_t_dev); p.emit_stats = emit_stats_dev;
     p.m = m; p.n = n; p.ks = k / 16; p.m_tiles = (int)((m + TM - 1) / TM); p.n_tiles = n / TN; p.alpha = alpha;
     // super-block of the tile walk: gn = the largest divisor of the n-tile count up to 4 (a gn that does not divide it leaves
     // every other XCD with half-empty super-blocks: +25 % time measured), gm so that an XCD's 64 resident workgroups cover one
@@ -671,8 +851,11 @@ extern "C" int lemon_linear_f16x3t(const uint16_t *at_dev, const uint16_t *wt_de
         if (!g_attr_set[dev]) {
             LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<0, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<1, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<0, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             g_attr_set[dev] = true;
         }
     }
@@ -689,9 +872,14 @@ extern "C" int lemon_linear_f16x3t(const uint16_t *at_dev, const uint16_t *wt_de
         }
     }
     if (ev0) LEMON_HIP_CHECK(hipEventRecord(ev0, (hipStream_t)stream_));
-    if (mf16) {
-        if (out_operand) hipLaunchKernelGGL(k_gemm_f16x3t16<1>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
-        else hipLaunchKernelGGL(k_gemm_f16x3t16<0>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+    const bool fold = row_aff_dev != nullptr, emit = emit_t_dev != nullptr;
+    if (fold || emit) {
+        if (fold && out_operand) hipLaunchKernelGGL((k_gemm_f16x3t16<1, true, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+        else if (fold) hipLaunchKernelGGL((k_gemm_f16x3t16<0, true, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+        else hipLaunchKernelGGL((k_gemm_f16x3t16<0, false, true>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+    } else if (mf16) {
+        if (out_operand) hipLaunchKernelGGL((k_gemm_f16x3t16<1, false, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+        else hipLaunchKernelGGL((k_gemm_f16x3t16<0, false, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
     } else {
         if (out_operand) hipLaunchKernelGGL(k_gemm_f16x3t<1>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
         else hipLaunchKernelGGL(k_gemm_f16x3t<0>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
@@ -729,5 +917,15 @@ extern "C" int lemon_linear_f16x3t_profile_read(int64_t *launches, double *kerne
         *kernel_ms += ms; *flops += g_prof.flops[i / 2];
     }
     g_prof.used = 0; g_prof.flops.clear();
+    return LEMON_OK;
+}
+
+extern "C" int lemon_ln_finalize(const float *partials_dev, int64_t rows, int width, float eps, float *row_aff_dev, void *stream_) {
+    LEMON_REQUIRE(rows >= 0 && width > 0 && width % TN == 0, "rows >= 0, width a multiple of 256");
+    if (rows == 0) return LEMON_OK;
+    LEMON_REQUIRE(partials_dev && row_aff_dev, "null pointer");
+    hipLaunchKernelGGL(k_ln_finalize, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, partials_dev, rows, width / 128, 128.0f, eps,
+                       reinterpret_cast<float2 *>(row_aff_dev));
+    LEMON_HIP_CHECK(hipGetLastError());
     return LEMON_OK;
 }

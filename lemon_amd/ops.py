@@ -367,6 +367,93 @@ def linear_t(at, wt, m, n, k, bias=None, residual=None, act=None, alpha=1.0, out
     return out
 
 
+def ln_fold_enabled():
+    """LEMON_LNFOLD (default 1): with LEMON_GEMM=f16x3 and LEMON_MLP=block the LayerNorms in front of QKV and fc1 are folded into
+    the hand-written GEMMs (lemon_linear_f16x3t_ln): the output projection / fc2 write the residual stream also as the next
+    GEMM's operand together with row statistics, QKV / fc1 apply (rstd, -mean rstd) and the weight-row sums in their epilogue --
+    no LayerNorm pass over the token matrix.  0: LayerNorm kernels as before (A/B aid)."""
+    import os
+    return os.environ.get("LEMON_LNFOLD", "1") != "0"
+
+
+def fold_layernorm_weight(w, b, gamma, beta, extra=1.0):
+    """The weight side of a folded LayerNorm: LN(x) W^T + b = rstd (x W'^T - mean c) + b' with W' = W diag(gamma).  Returns
+    (tile-major packed W' * wscale, 1 / wscale, colsum, bias'): colsum[n] = extra / wscale * sum_k of the PACKED weight row (hi + lo,
+    float64 sum), bias' = extra * (b + W beta) -- `extra` is the factor the caller multiplies alpha = 1 / wscale with (QuickGELU's
+    1.702 for fc1)."""
+    wp = (w.detach() * gamma.detach()[None, :]).contiguous()
+    wscale = weight_scale_f16x3(wp)
+    wt = pack_weight_t(wp, wscale)
+    t = wp * wscale                                       # exact: wscale is a power of two
+    hi = t.to(torch.float16)
+    lo = (t - hi.float()).to(torch.float16)               # split3.hpp split2h<WEIGHT = true>
+    colsum = ((hi.double() + lo.double()).sum(1) * (extra / wscale)).float().contiguous()
+    bias = (b.detach().double() if b is not None else 0.0) + w.detach().double() @ beta.detach().double()
+    return wt, 1.0 / wscale, colsum, (bias * extra).float().contiguous()
+
+
+def rowstats_t(x, eps):
+    """x as the tile-major activation operand + its rows' (rstd, -mean rstd) [m, 2]: the input of a folded LayerNorm for a tensor
+    no GEMM epilogue produced (lemon_rowstats_f16x3t)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 16 == 0
+    x = x.contiguous()
+    width = x.shape[-1]
+    m = x.numel() // width
+    at = torch.empty((_tiled_rows(m) * width * 2,), dtype=torch.float16, device=x.device)
+    aff = torch.empty((m, 2), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.lemon_rowstats_f16x3t(ptr(x), float(eps), m, width, ptr(at), ptr(aff), stream_ptr(x.device)), "lemon_rowstats_f16x3t")
+    return at, aff
+
+
+def ln_finalize(stats, m, width, eps):
+    """[m, width / 128, 2] (mean, M2) partials of lemon_linear_f16x3t_ln's emit side -> (rstd, -mean rstd) [m, 2]."""
+    assert stats.is_cuda and stats.dtype == torch.float32 and stats.numel() == m * (width // 128) * 2
+    aff = torch.empty((m, 2), dtype=torch.float32, device=stats.device)
+    lib = _lib.load()
+    with torch.cuda.device(stats.device):
+        _lib.check(lib.lemon_ln_finalize(ptr(stats), m, width, float(eps), ptr(aff), stream_ptr(stats.device)), "lemon_ln_finalize")
+    return aff
+
+
+def linear_t_ln(at, wt, m, n, k, bias=None, residual=None, act=None, alpha=1.0, out_shape=None, row_aff=None, colsum=None, emit=False):
+    """linear_t with a folded LayerNorm on one side (lemon_linear_f16x3t_ln).  row_aff / colsum: this GEMM stands behind a LayerNorm
+    whose input `at` holds (see fold_layernorm_weight / rowstats_t / ln_finalize).  emit: returns (out, out as the next GEMM's
+    tile-major operand, its row-statistics partials [m, n / 128, 2])."""
+    assert at.is_cuda and at.dtype == torch.float16 and wt.dtype == torch.float16
+    assert at.numel() == _tiled_rows(m) * k * 2 and wt.numel() == n * k * 2 and k % 32 == 0
+    assert (row_aff is None) == (colsum is None) and not (emit and row_aff is not None)
+    lib = _lib.load()
+    if bias is not None:
+        bias = bias.contiguous()
+    if act == "silu":
+        assert residual is None and not emit
+        out = torch.empty((_tiled_rows(m) * n * 2,), dtype=torch.float16, device=at.device)
+    else:
+        assert act is None
+        out = torch.empty(out_shape if out_shape is not None else (m, n), dtype=torch.float32, device=at.device)
+        assert out.numel() == m * n
+        if residual is not None:
+            assert residual.dtype == torch.float32 and residual.numel() == m * n
+            residual = residual.contiguous()
+    if row_aff is not None:
+        assert row_aff.dtype == torch.float32 and row_aff.numel() == 2 * m and colsum.dtype == torch.float32 and colsum.numel() == n
+        row_aff, colsum = row_aff.contiguous(), colsum.contiguous()
+    et = st = None
+    if emit:
+        et = torch.empty((_tiled_rows(m) * n * 2,), dtype=torch.float16, device=at.device)
+        st = torch.empty((m, n // 128, 2), dtype=torch.float32, device=at.device)
+    with torch.cuda.device(at.device):
+        _lib.check(lib.lemon_linear_f16x3t_ln(ptr(at), ptr(wt), ptr(bias) if bias is not None else None,
+                                              ptr(residual) if residual is not None else None, m, n, k, float(alpha),
+                                              ACT_SILU if act == "silu" else ACT_NONE, int(act == "silu"), ptr(out),
+                                              ptr(row_aff) if row_aff is not None else None, ptr(colsum) if colsum is not None else None,
+                                              ptr(et) if emit else None, ptr(st) if emit else None, stream_ptr(at.device)),
+                   "lemon_linear_f16x3t_ln")
+    return (out, et, st) if emit else out
+
+
 def gemm_profiling(on):
     """HIP events around every lemon_linear_f16x3t launch from now on (bench.py: the roofline of the step's dominant kernel)."""
     _lib.check(_lib.load().lemon_linear_f16x3t_set_profiling(int(bool(on))), "lemon_linear_f16x3t_set_profiling")

@@ -243,3 +243,26 @@ def test_long_sequence_attention_kernel_fits_four_waves_and_keeps_scratch_out_of
         assert meta[n]["vgpr_spill_count"] <= 20, (n, meta[n])
         assert _loops_with_mfma_and_scratch(bodies[n]) == [], n
         assert _loops_with_mfma_and_scratch(bodies[n], _probe=True), "the parser must see the MFMA loops"
+
+
+# ---- k_gemm_f16x3t16 and its LayerNorm-fold variants -------------------------------------------------------------------------
+# (1) the two plain instantiations (the measured product kernels) hold everything in registers; the fold variants may spill a few
+#     epilogue values, never inside the MFMA loop;
+# (2) no packed fp32 instruction takes the HIGH dword of a register pair for its LOW lane (`op_sel:[..1..]`): with
+#     `v_pk_mul_f32 ... op_sel:[0,1]` on a (rstd, -mean rstd) pair that had just arrived from LDS / memory the low results of
+#     lanes 48-63 were wrong now and then on the GPU (round 4, tools/scratch history in DESIGN.md); the epilogues keep such
+#     products in single registers, and this test keeps hipcc from quietly re-pairing them.
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_gemm16_variants_register_discipline():
+    meta = _kernel_meta("gemm_f16x3.hip")
+    bodies = _kernel_bodies(_kernel_asm("gemm_f16x3.hip"))
+    names = [n for n in bodies if "k_gemm_f16x3t16ILi" in n]
+    assert len(names) == 5, sorted(names)
+    for n in names:
+        assert meta[n]["vgpr_count"] <= 256, (n, meta[n])            # (arch + accumulation registers: two waves per SIMD)
+        if "Lb0ELb0E" in n:
+            assert meta[n]["vgpr_spill_count"] == 0 and meta[n]["private_segment_fixed_size"] == 0, (n, meta[n])
+        assert _loops_with_mfma_and_scratch(bodies[n]) == [], n
+        assert _loops_with_mfma_and_scratch(bodies[n], _probe=True), "the parser must see the MFMA loop"
+        bad = [ln.strip() for ln in bodies[n] if re.search(r"\bv_pk_\w+_f32\b", ln) and re.search(r"op_sel:\[[01,]*1", ln)]
+        assert not bad, (n, bad[:4])

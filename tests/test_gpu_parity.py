@@ -965,3 +965,81 @@ def test_hand_written_gemm_odd_k_step_counts(hip, m, k, n):
     ws2 = ops.weight_scale_f16x3(w2)
     y = ops.linear_t(ht, ops.pack_weight_t(w2.cuda(), ws2), m, 256, n, None, residual=x2.cuda(), alpha=1.0 / ws2).cpu().double()
     assert float((y - (ref @ w2.double().T + x2.double())).abs().max()) < 3e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,k,n,mean_over_sigma", [(300, 128, 512, 0.0), (1000, 768, 2304, 3.0), (129, 512, 256, 30.0), (2500, 768, 3072, 0.3)])
+def test_layernorm_folded_into_the_gemm_matches_float64(hip, m, k, n, mean_over_sigma):
+    # LN(x) W^T + b through lemon_linear_f16x3t_ln (raw x as the operand, (rstd, -mean rstd) and the weight-row sums in the
+    # epilogue) against float64, for both epilogues (fp32 + residual, SiLU -> operand) and rows whose mean is far from 0 in
+    # units of their spread: the bar is the un-folded path's own error on the same operands (x 1.5) widened by the documented
+    # factor max over rows of sqrt(1 + mean^2 / var) of the fold (1.0x for zero-mean rows; ops.LN_FOLD_MAX_SHIFT bounds it in
+    # the product: a micro-batch beyond it is re-embedded with LayerNorm kernels).
+    from lemon_amd import ops
+    g = torch.Generator().manual_seed(m + k + n)
+    x = torch.randn(m, k, generator=g) * (0.5 + torch.rand(m, 1, generator=g) * 4) + mean_over_sigma * torch.randn(m, 1, generator=g)
+    gamma, beta = 1 + 0.3 * torch.randn(k, generator=g), 0.2 * torch.randn(k, generator=g)
+    w, b = 0.03 * torch.randn(n, k, generator=g), 0.1 * torch.randn(n, generator=g)
+    res = torch.randn(m, n, generator=g)
+    eps = 1e-5
+    xd = x.double()
+    ln = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + eps) * gamma.double() + beta.double()
+    want = ln @ w.double().t() + b.double()
+    xc, wc, bc, gc, bec, rc = (t.cuda() for t in (x, w, b, gamma, beta, res))
+    # un-folded: LayerNorm kernel -> GEMM
+    ws = ops.weight_scale_f16x3(wc)
+    plain = ops.linear_t(ops.layer_norm_t(xc, gc, bec, eps), ops.pack_weight_t(wc, ws), m, n, k, bc, residual=rc, alpha=1.0 / ws).cpu().double() - res.double()
+    e_plain = float((plain - want).abs().max())
+    # folded
+    xt, aff = ops.rowstats_t(xc, eps)
+    wt, a, cs, bp = ops.fold_layernorm_weight(wc, bc, gc, bec, 1.0)
+    got = ops.linear_t_ln(xt, wt, m, n, k, bp, residual=rc, alpha=a, row_aff=aff, colsum=cs).cpu().double() - res.double()
+    e_fold = float((got - want).abs().max())
+    scale = float(want.abs().max())
+    ratio = float(torch.sqrt(1.0 + xd.mean(1) ** 2 / xd.var(1, unbiased=False)).max())      # the fold's documented error factor
+    bar = 1.5 * max(e_plain, 2e-7 * scale) * ratio
+    assert e_fold <= bar, (e_fold, e_plain, scale, ratio)
+    for _ in range(3):      # (the same call again: the packed-multiply fault this path once had was sporadic, ~1e3 wrong values per call)
+        again = ops.linear_t_ln(xt, wt, m, n, k, bp, residual=rc, alpha=a, row_aff=aff, colsum=cs).cpu().double() - res.double()
+        assert torch.equal(again, got)
+    # the SiLU -> operand form
+    s = 1.702
+    wt, a, cs, bp = ops.fold_layernorm_weight(wc, bc, gc, bec, s)
+    ht = ops.linear_t_ln(xt, wt, m, n, k, bp, act="silu", alpha=s * a, row_aff=aff, colsum=cs)
+    got = ops.unpack_act_t(ht, m, n).cpu().double()
+    z = s * want
+    want_h = z * torch.sigmoid(z)
+    assert float((got - want_h).abs().max()) <= 2.0 * bar * s + 1e-6 * float(want_h.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,k,n", [(300, 128, 256), (1000, 768, 768), (129, 2048, 768), (2600, 64, 512)])
+def test_gemm_emits_the_next_layernorms_operand_and_statistics(hip, m, k, n):
+    # the producing side of the fold: the fp32 result is the plain kernel's (same products, the bias / residual additions in
+    # another order: last-bit differences), the operand it also writes is the fp16 split of exactly what it stored, and the
+    # finished row statistics are those of the stored values (float64), also for rows with a large common offset
+    from lemon_amd import ops
+    g = torch.Generator().manual_seed(m + k + n)
+    x = torch.randn(m, k, generator=g)
+    w, b = 0.05 * torch.randn(n, k, generator=g), 0.1 * torch.randn(n, generator=g)
+    res = torch.randn(m, n, generator=g) * (0.2 + 3 * torch.rand(m, 1, generator=g)) + 20.0 * torch.randn(m, 1, generator=g)
+    xc, wc, bc, rc = (t.cuda() for t in (x, w, b, res))
+    ws = ops.weight_scale_f16x3(wc)
+    wt = ops.pack_weight_t(wc, ws)
+    at, _ = ops.rowstats_t(xc, 1e-5)
+    plain = ops.linear_t(at, wt, m, n, k, bc, residual=rc, alpha=1.0 / ws)
+    out, et, st = ops.linear_t_ln(at, wt, m, n, k, bc, residual=rc, alpha=1.0 / ws, emit=True)
+    assert float((out - plain).abs().max()) <= 4e-7 * float(plain.abs().max())
+    back = ops.unpack_act_t(et, m, n)
+    assert float((back - out).abs().max()) <= 2.0 ** -21 * float(out.abs().max())
+    assert bool(((back - out).abs() <= 2.0 ** -21 * out.abs() + 1e-30).all())
+    eps = 1e-5
+    aff = ops.ln_finalize(st, m, n, eps).cpu().double()
+    od = out.cpu().double()
+    mean, var = od.mean(1), od.var(1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    assert float(((aff[:, 0] - rstd).abs() / rstd).max()) <= 2e-6
+    assert float((aff[:, 1] + mean * rstd).abs().max()) <= 2e-6 * float((mean * rstd).abs().max() + 1.0)
+    # and through the first-block kernel
+    _, aff0 = ops.rowstats_t(out, eps)
+    assert float((aff0.cpu().double()[:, 0] - rstd).abs().max() / float(rstd.max())) <= 2e-6
