@@ -474,13 +474,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
             bias4[cp] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.bias) bias4[cp] = *reinterpret_cast<const float4 *>(p.bias + nt * TN + wn * 128 + cp * 32 + pcol);
         }
+        // Addresses.  A full tile (all but the last tile row) needs no row clamp: a wave-uniform 64-bit base (the wave's first
+        // row and column) + a 32-bit lane offset + compile-time multiples of N -- hipcc then issues `global_load/store ... s[base]`
+        // with one v_add per access; with the clamp every access cost a 64-bit compare-select-multiply chain.
+        const bool full = (int64_t)(mt + 1) * TM <= p.m;
+        const int64_t wave_off = ((int64_t)mt * TM + wm * (IB * 32)) * N + nt * TN + wn * 128;      // (wave-uniform)
+        const char *res_w = reinterpret_cast<const char *>(p.residual + wave_off);
+        char *out_w = reinterpret_cast<char *>(reinterpret_cast<float *>(p.out) + wave_off);
+        const unsigned lane_off = (unsigned)(prow * N + pcol) * 4u;                                  // (bytes)
         auto load_res = [&](int pass, float4 (&r)[4]) {
             const int n = nt * TN + wn * 128 + (pass >> 1) * 32 + pcol;
             const int64_t m0 = (int64_t)mt * TM + wm * (IB * 32) + (pass & 1) * 32;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int64_t m = m0 + 8 * q + prow;
-                r[q] = *reinterpret_cast<const float4 *>(p.residual + (m < m_last ? m : m_last) * N + n);
+                if (full) r[q] = *reinterpret_cast<const float4 *>(res_w + (lane_off + 4u * (unsigned)(((pass & 1) * 32 + 8 * q) * N + (pass >> 1) * 32)));
+                else r[q] = *reinterpret_cast<const float4 *>(p.residual + (m < m_last ? m : m_last) * N + n);
             }
         };
         float4 rn[4];
@@ -514,13 +523,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
             _Pragma("unroll") for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4 *>(pr + (8 * q + prow) * 36 + pcol); \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
                 const int64_t m = m0 + 8 * q + prow;                                                             \
-                if (!(MASKED) || m < p.m)                                                                        \
-                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + m * N + n) =                  \
-                        make_float4(p.alpha * v[q].x + bv.x + r[q].x, p.alpha * v[q].y + bv.y + r[q].y, p.alpha * v[q].z + bv.z + r[q].z, p.alpha * v[q].w + bv.w + r[q].w); \
+                const float4 o4_ = make_float4(p.alpha * v[q].x + bv.x + r[q].x, p.alpha * v[q].y + bv.y + r[q].y, p.alpha * v[q].z + bv.z + r[q].z, p.alpha * v[q].w + bv.w + r[q].w); \
+                if (!(MASKED)) *reinterpret_cast<float4 *>(out_w + (lane_off + 4u * (unsigned)((bp * 32 + 8 * q) * N + cp * 32))) = o4_; \
+                else if (m < p.m) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + m * N + n) = o4_; \
             }                                                                                                    \
         }
         PATCH_WRITE(0);
-        if ((int64_t)(mt + 1) * TM <= p.m) { EPI0_PASSES(false) } else { EPI0_PASSES(true) }
+        if (full) { EPI0_PASSES(false) } else { EPI0_PASSES(true) }
 #undef EPI0_PASSES
 #undef PATCH_WRITE
         return;
@@ -536,23 +545,36 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
         //         128-byte line per store instruction and k chunk), and as a (mean, M2) partial per row and 128-column group:
         //         shifted sums over the lane's 16 values (shift = the first one: the sums stay at the size of the row's spread),
         //         equal-count pairwise merges over the row's eight lanes
+        // Addresses as in the plain epilogue: full tiles use a wave-uniform base + 32-bit lane offset + compile-time terms (for the
+        // tile-major operand too: split3.hpp tiled_off taken apart into its wave, lane and (pass, q) parts).
         float *patch0 = reinterpret_cast<float *>(smem) + wave * (2 * 32 * 36);
         float2 *saff = reinterpret_cast<float2 *>(smem + 4 * (2 * 32 * 36) * 4) + wave * 64;
         const int prow = lane >> 3, pcol = 4 * (lane & 7);
         const bool has_res = p.residual != nullptr;
         const int64_t m_last = p.m - 1;
         const int64_t mw = (int64_t)mt * TM + wm * (IB * 32);          // the wave's first row
+        const bool full = (int64_t)(mt + 1) * TM <= p.m;
+        const int n_w = nt * TN + wn * 128;                            // the wave's first column
+        const int64_t wave_off = mw * N + n_w;
+        const char *res_w = reinterpret_cast<const char *>(p.residual + wave_off);
+        char *out_w = reinterpret_cast<char *>(reinterpret_cast<float *>(p.out) + wave_off);
+        const unsigned lane_off = (unsigned)(prow * N + pcol) * 4u;
+        // tile-major operand (halves): ((mt (N / 16) + n / 16) 2 + part) (TM 16) + (r / 32) 512 + ((n / 8) & 1) 256 + (r % 32) 8 + n % 8
+        char *emit_w = reinterpret_cast<char *>(p.emit_t) + 2 * ((((int64_t)mt * (N >> 4) + (n_w >> 4)) * 2) * (TM * 16) + wm * 2 * 512);
+        const unsigned emit_lane = 2u * (unsigned)(((lane & 7) >> 2) * 2 * (TM * 16) + (((lane & 7) >> 1) & 1) * 256 + prow * 8 + 4 * (lane & 1));
         if (FOLD) { const int64_t m = mw + lane; saff[lane] = p.row_aff[m < m_last ? m : m_last]; }
         auto load_next = [&](int pass, float4 (&r)[4], float4 &bv, float4 &cs) {
-            const int n = nt * TN + wn * 128 + (pass & 3) * 32 + pcol;
+            const int cpn = pass & 3, bpn = pass >> 2;
+            const int n = n_w + cpn * 32 + pcol;
             bv = make_float4(0.f, 0.f, 0.f, 0.f); cs = bv;
             if (p.bias) bv = *reinterpret_cast<const float4 *>(p.bias + n);
             if (FOLD) cs = *reinterpret_cast<const float4 *>(p.colsum + n);
             if (has_res) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int64_t m = mw + (pass >> 2) * 32 + 8 * q + prow;
-                    r[q] = *reinterpret_cast<const float4 *>(p.residual + (m < m_last ? m : m_last) * N + n);
+                    const int64_t m = mw + bpn * 32 + 8 * q + prow;
+                    if (full) r[q] = *reinterpret_cast<const float4 *>(res_w + (lane_off + 4u * (unsigned)((bpn * 32 + 8 * q) * N + cpn * 32)));
+                    else r[q] = *reinterpret_cast<const float4 *>(p.residual + (m < m_last ? m : m_last) * N + n);
                 }
             }
         };
@@ -572,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
 #define EPI0_PASSES(MASKED)                                                                                      \
         _Pragma("unroll") for (int pass = 0; pass < 8; ++pass) {                                                 \
             const int cp = pass & 3, bp = pass >> 2;                                                             \
-            const int n = nt * TN + wn * 128 + cp * 32 + pcol;                                                   \
+            const int n = n_w + cp * 32 + pcol;                                                                  \
             const int64_t m0 = mw + bp * 32;                                                                     \
             float4 r[4];                                                                                         \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) r[q] = rn[q];                                          \
@@ -599,23 +621,27 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
                     o_[2] = af[q].x * o_[2] + t_[2]; o_[3] = af[q].x * o_[3] + t_[3];                             \
                 }                                                                                                \
                 o_[0] += bv.x + r[q].x; o_[1] += bv.y + r[q].y; o_[2] += bv.z + r[q].z; o_[3] += bv.w + r[q].w;   \
-                if (!(MASKED) || m < p.m)                                                                        \
-                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + m * N + n) = make_float4(o_[0], o_[1], o_[2], o_[3]); \
+                const float4 o4_ = make_float4(o_[0], o_[1], o_[2], o_[3]);                                      \
+                if (!(MASKED)) *reinterpret_cast<float4 *>(out_w + (lane_off + 4u * (unsigned)((bp * 32 + 8 * q) * N + cp * 32))) = o4_; \
+                else if (m < p.m) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + m * N + n) = o4_; \
                 if (EMIT) {                                                                                      \
-                    /* (rows beyond m land in the operand's pad rows: never read into a stored result) */        \
+                    /* (rows beyond m land in the operand's pad rows: never read into a stored result)                \
+                       lo 2^11 = o 2^11 - hi 2^11 exactly, in one fused step from the fp16 value (v_fma_mix_f32) */    \
                     h16x4 hi_, lo_;                                                                              \
                     _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                              \
-                        unsigned short a_, b_, c_;                                                               \
-                        split2h<false>(o_[e], a_, b_, c_);                                                       \
-                        hi_[e] = __builtin_bit_cast(_Float16, a_); lo_[e] = __builtin_bit_cast(_Float16, c_);    \
+                        const _Float16 hh_ = (_Float16)o_[e];                                                    \
+                        hi_[e] = hh_; lo_[e] = (_Float16)__builtin_fmaf((float)hh_, -2048.0f, o_[e] * 2048.0f);  \
                     }                                                                                            \
-                    unsigned short *base_ = p.emit_t + tiled_off(TM, m, n, 0, N);                                \
+                    char *base_ = emit_w + (emit_lane + (unsigned)(cp * 16384 + bp * 1024 + q * 128));           \
                     *reinterpret_cast<h16x4 *>(base_) = hi_;                                                     \
-                    *reinterpret_cast<h16x4 *>(base_ + TM * 16) = lo_;                                           \
-                    if (cp == 0) { st_s[q] = o_[0]; st_1[q] = 0.0f; st_2[q] = 0.0f; }                            \
+                    *reinterpret_cast<h16x4 *>(base_ + TM * 16 * 2) = lo_;                                       \
+                    if (cp == 0) {                                                                               \
+                        float s0_ = o_[0];                /* (its own register: the shift is never the odd half of a pair */ \
+                        asm volatile("" : "+v"(s0_));     /*  a packed op would have to reach with op_sel, see FOLD) */  \
+                        st_s[q] = s0_; st_1[q] = 0.0f; st_2[q] = 0.0f;                                           \
+                    }                                                                                            \
                     _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                              \
-                        float d_ = o_[e] - st_s[q];                                                              \
-                        asm volatile("" : "+v"(d_));      /* (single registers: no packed op with op_sel, see FOLD) */ \
+                        const float d_ = o_[e] - st_s[q];                                                        \
                         st_1[q] += d_; st_2[q] += d_ * d_;                                                       \
                     }                                                                                            \
                     if (cp == 3) {                                                                               \
@@ -636,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
             }                                                                                                    \
         }
         PATCH_WRITE(0);
-        if ((int64_t)(mt + 1) * TM <= p.m) { EPI0_PASSES(false) } else { EPI0_PASSES(true) }
+        if (full) { EPI0_PASSES(false) } else { EPI0_PASSES(true) }
 #undef EPI0_PASSES
 #undef PATCH_WRITE
         return;

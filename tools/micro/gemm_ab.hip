@@ -18,7 +18,7 @@ void lemon_set_error(const char *fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
 }
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
-#define LCHECK(x) do { int r_ = (x); if (r_ != 0) { fprintf(stderr, "%s -> %d: %s\n", #x, r_, g_err); exit(1); } } while (0)
+#define LCHECK(x) do { int rc__ = (x); if (rc__ != 0) { fprintf(stderr, "%s -> %d: %s\n", #x, rc__, g_err); exit(1); } } while (0)
 
 __global__ void k_fill_normal(float *g, size_t n, float scale, unsigned seed) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -117,10 +117,25 @@ int main(int argc, char **argv) {
         }
         CHECK(hipDeviceSynchronize());
         const float alpha = 1.0f / wscale;
+        // GEMM_LN=fold | emit: variant 1 is the LayerNorm-fold form of the 16x16x32 kernel (identity row affine / scratch emit
+        // buffers: the same result), variant 0 the plain 16x16x32 kernel -- the cost of the fold's epilogues
+        const char *ln = getenv("GEMM_LN");
+        const bool ln_fold = ln && !strcmp(ln, "fold"), ln_emit = ln && !strcmp(ln, "emit") && !s.epi;
+        static float *aff = nullptr, *csum = nullptr, *stats = nullptr; static uint16_t *emit_t = nullptr;
+        if (ln && !aff) {
+            CHECK(hipMalloc(&aff, (size_t)131072 * 8)); CHECK(hipMalloc(&csum, 4096 * 4)); CHECK(hipMalloc(&stats, (size_t)131072 * 32 * 8));
+            CHECK(hipMalloc(&emit_t, (size_t)131072 * 3072 * 4));
+            std::vector<float> h(131072 * 2);
+            for (size_t i = 0; i < h.size(); i += 2) { h[i] = 1.0f; h[i + 1] = 0.0f; }
+            CHECK(hipMemcpy(aff, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+            CHECK(hipMemset(csum, 0, 4096 * 4));
+        }
         auto run = [&](int v) {
-            g_mfma_shape = v ? 16 : 32;
-            LCHECK(lemon_linear_f16x3t(at, wt, bias, (s.epi || getenv("GEMM_NO_RESIDUAL")) ? nullptr : res, s.m, s.n, s.k, alpha, s.epi ? LEMON_ACT_SILU : LEMON_ACT_NONE,
-                                       s.epi, out[v], nullptr));
+            g_mfma_shape = (v || ln) ? 16 : 32;
+            const float *resid_p = (s.epi || getenv("GEMM_NO_RESIDUAL")) ? nullptr : res;
+            if (v && ln_fold) LCHECK(lemon_linear_f16x3t_ln(at, wt, bias, resid_p, s.m, s.n, s.k, alpha, s.epi ? LEMON_ACT_SILU : LEMON_ACT_NONE, s.epi, out[v], aff, csum, nullptr, nullptr, nullptr));
+            else if (v && ln_emit) LCHECK(lemon_linear_f16x3t_ln(at, wt, bias, resid_p, s.m, s.n, s.k, alpha, LEMON_ACT_NONE, 0, out[v], nullptr, nullptr, emit_t, stats, nullptr));
+            else LCHECK(lemon_linear_f16x3t(at, wt, bias, resid_p, s.m, s.n, s.k, alpha, s.epi ? LEMON_ACT_SILU : LEMON_ACT_NONE, s.epi, out[v], nullptr));
         };
         if (walk) {
             // tile-walk sweep of the 16x16x32 kernel: interleaved rounds over the (gm, gn) super-block shapes
@@ -214,7 +229,7 @@ int main(int argc, char **argv) {
             std::sort(t[v].begin(), t[v].end());
             const float med = t[v][t[v].size() / 2], mn = t[v][0];
             printf("%-24s m=%d n=%d k=%d  mfma %s: median %.1f us (%.0f TFLOP/s fp16) min %.1f us  max|err| %.3g of %.3g\n", s.name, s.m, s.n, s.k,
-                   v ? "16x16x32" : "32x32x16", med, flop / (med * 1e-6) / 1e12, mn, worst[v], scale);
+                   ln ? (v ? (ln_fold ? "16 LN-fold" : ln_emit ? "16 LN-emit" : "16 plain'") : "16 plain") : v ? "16x16x32" : "32x32x16", med, flop / (med * 1e-6) / 1e12, mn, worst[v], scale);
             if (!(worst[v] <= 2e-5 * scale + 2e-5)) { printf("  ^^^ WRONG\n"); bad = 1; }
         }
         fflush(stdout);
