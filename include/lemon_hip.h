@@ -239,7 +239,11 @@ int lemon_unpack_act_f16x3t(const uint16_t *at_dev, int64_t rows, int k, float *
  *       the tile-major activation operand emit_t_dev (ceil(m / 128) * 128 rows x n) and emit_stats_dev [m, n / 128, 2] receives
  *       per row and 128-column group (mean, sum of squared deviations); lemon_ln_finalize merges them into row_aff
  *   lemon_rowstats_f16x3t: operand + row_aff of a tensor no GEMM produced (a tower's first block)
- * k must be a multiple of 32.  With all four extra pointers NULL the call is lemon_linear_f16x3t. */
+ * k must be a multiple of 32.  With all four extra pointers NULL the call is lemon_linear_f16x3t.
+ * Accuracy contract: the fold's rounding error is the un-folded GEMM's times sqrt(1 + mean^2 / var) of the row, so rows with
+ * |mean| rstd > 8 (LEMON_LN_FOLD_MAX_SHIFT) get row_aff = (NaN, NaN) from lemon_ln_finalize / lemon_rowstats_f16x3t: their
+ * output rows come out non-finite and the caller must redo them without the fold (lemon_amd.pipeline.Embedder re-embeds the
+ * micro-batch with LayerNorm kernels). */
 int lemon_linear_f16x3t_ln(const uint16_t *at_dev, const uint16_t *wt_dev, const float *bias_dev, const float *residual_dev,
                            int64_t m, int n, int k, float alpha, int act, int out_operand, void *out_dev, const float *row_aff_dev,
                            const float *colsum_dev, uint16_t *emit_t_dev, float *emit_stats_dev, void *stream);

@@ -138,6 +138,10 @@ __host__ __device__ inline float lemon_key_score(u64 key) { return lemon_ord2f((
 __host__ __device__ inline u32 lemon_key_index(u64 key) { return 0xffffffffu - (u32)(key & 0xffffffffu); }
 
 #define LEMON_CAND_CAP 256 // candidate slots per query in the scan workspace
+// LayerNorm fold (lemon_linear_f16x3t_ln): the folded GEMM's rounding error grows with sqrt(1 + mean^2 / var) of a row; rows
+// beyond |mean| rstd = this get a NaN row affine -> a non-finite output row -> the caller's range fallback re-embeds the
+// micro-batch with LayerNorm kernels (pipeline.Embedder), so the fold never silently loses accuracy
+#define LEMON_LN_FOLD_MAX_SHIFT 8.0f
 #define LEMON_DEDUP_MIN_NQ 1024 // query de-duplication is attempted from this many queries on
 
 // internal entry points shared between translation units

@@ -182,7 +182,10 @@ __global__ __launch_bounds__(256) void k_layernorm8_t(const float *__restrict__ 
         const float rstd = rsqrtf(q / (float)width + eps);
         const float4 *w4 = reinterpret_cast<const float4 *>(w);
         const float4 *b4 = reinterpret_cast<const float4 *>(b);
-        if (RAW && lane == 0) aff[row] = make_float2(rstd, -mean * rstd);
+        if (RAW && lane == 0) {
+            const bool far = fabsf(mean) * rstd > LEMON_LN_FOLD_MAX_SHIFT;   // (see common.hpp: the caller falls back)
+            aff[row] = far ? make_float2(__builtin_nanf(""), __builtin_nanf("")) : make_float2(rstd, -mean * rstd);
+        }
 #pragma unroll
         for (int i = 0; i < CH8; ++i) {
             const int c = lane + 64 * i;

@@ -741,7 +741,8 @@ __global__ __launch_bounds__(256) void k_ln_finalize(const float *__restrict__ p
     float m2 = 0.0f;
     for (int i = 0; i < np; ++i) { const float d = pr[i].x - mean; m2 += pr[i].y + per * d * d; }
     const float rstd = rsqrtf(m2 / (per * (float)np) + eps);
-    aff[r] = make_float2(rstd, -mean * rstd);
+    const bool far = fabsf(mean) * rstd > LEMON_LN_FOLD_MAX_SHIFT;           // (see common.hpp: the caller falls back)
+    aff[r] = far ? make_float2(__builtin_nanf(""), __builtin_nanf("")) : make_float2(rstd, -mean * rstd);
 }
 
 // ---- host-side state of the launcher ----

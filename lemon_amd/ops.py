@@ -367,6 +367,9 @@ def linear_t(at, wt, m, n, k, bias=None, residual=None, act=None, alpha=1.0, out
     return out
 
 
+LN_FOLD_MAX_SHIFT = 8.0     # csrc/common.hpp LEMON_LN_FOLD_MAX_SHIFT: rows with |mean| rstd beyond it get a NaN row affine (-> fallback)
+
+
 def ln_fold_enabled():
     """LEMON_LNFOLD (default 1): with LEMON_GEMM=f16x3 and LEMON_MLP=block the LayerNorms in front of QKV and fc1 are folded into
     the hand-written GEMMs (lemon_linear_f16x3t_ln): the output projection / fc2 write the residual stream also as the next

@@ -105,7 +105,9 @@ class Embedder:
     micro-batch leaves a device flag "not finite"; the flags of one embed_images / embed_texts call are read with ONE host
     transfer after all its micro-batches are queued, and a flagged micro-batch is embedded again with the range-free scheme
     (3-way bf16 split GEMMs, fp32 attention: the same fp32-equivalent contract) -- counted in `fallback_batches`, reported by
-    the CLI.  What is still not finite after that is not a range problem and raises in raise_if_nonfinite()."""
+    the CLI.  The same path catches the folded LayerNorm's bound (ops.ln_fold_enabled): a row whose mean lies more than
+    ops.LN_FOLD_MAX_SHIFT standard deviations from 0 is given a NaN row affine by the kernels, so its micro-batch is flagged
+    and re-embedded here with LayerNorm kernels.  What is still not finite after that is not a range problem and raises in raise_if_nonfinite()."""
 
     def __init__(self, model, device, batch_size=128, dtype=torch.float32, text_dedup=False, text_batch_size=None, range_fallback=True):
         self.model = model.eval().to(device=device, dtype=dtype)
@@ -127,7 +129,8 @@ class Embedder:
         """One host read for everything embedded since the last call."""
         flag, self._nonfinite = self._nonfinite, None
         if flag is not None and bool(flag.item()):
-            how = ("the range fallback is off (range_fallback=False): an activation left the fp16 range of the split operands -- "
+            how = ("the range fallback is off (range_fallback=False): an activation left the fp16 range of the split operands (or a row's "
+                   "mean left the folded LayerNorm's bound, ops.LN_FOLD_MAX_SHIFT standard deviations) -- "
                    "rerun with LEMON_GEMM=bf16x6 (no range limit) or f32" if (ops.gemm_mode() == "f16x3" and not self.range_fallback)
                    else "also with range-free operands (bf16x6 GEMMs, fp32 attention): the weights or inputs themselves produce inf / NaN")
             raise FloatingPointError(f"non-finite embeddings (LEMON_GEMM={ops.gemm_mode()}): {how}")
