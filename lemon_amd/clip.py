@@ -125,11 +125,12 @@ class Block(nn.Module):
         self.fc1 = nn.Linear(cfg.width, cfg.mlp)
         self.fc2 = nn.Linear(cfg.mlp, cfg.width)
 
-    def forward(self, x, causal, rows=None):
+    def forward(self, x, causal, rows=None, carry=None):
         """x [B,L,W] -> [B,L,W]; with rows = (batch_index, token_index) the block's output for those tokens
         only, [len(rows), W].  The towers read ONE token of the last block (CLS / EOT pooling): attention
         still sees every token's keys and values, but the output projection and the MLP -- 3/4 of the block's
-        FLOPs, all row-wise -- are then evaluated for the pooled rows only.  Same function of the input."""
+        FLOPs, all row-wise -- are then evaluated for the pooled rows only.  Same function of the input.
+        carry: what forward_chain of the block in front left behind (x as the hand-written GEMM's operand + row statistics), or None."""
         B, L, W = x.shape
         fused = x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
         if fused:
@@ -139,7 +140,7 @@ class Block(nn.Module):
             mode = ops.gemm_mode()
             ops.select_attention_arithmetic(mode)
             if W % 4 == 0 and W <= 1024 and mode != "f32":
-                return self._forward_split(x, causal, rows, ops, mode)
+                return self._forward_split(x, causal, rows, ops, mode, carry)
             ln = lambda m, t: ops.layer_norm(t, m.weight, m.bias, m.eps) if t.shape[-1] % 4 == 0 else m(t)
             qkv = ops.linear(ln(self.ln1, x), self.qkv.weight, self.qkv.bias)
             if W == 64 * self.heads and L <= ops.ATTENTION_MAX_SEQ:
@@ -196,7 +197,7 @@ class Block(nn.Module):
             cache[(name, "tiled")] = hit
         return hit[1], hit[2]
 
-    def _forward_split(self, x, causal, rows, ops, mode):
+    def _forward_split(self, x, causal, rows, ops, mode, carry=None):
         """The fused inference path with the four GEMMs of the block (QKV, output projection, fc1, fc2) on the 16-bit matrix
         cores at fp32-equivalent accuracy (ops.linear_split: exact splits of both operands -- 3-way bf16, six cross products, or
         2-way fp16, three --, fp32 accumulate); LayerNorm and attention write the split operand directly, the MLP activations
@@ -214,8 +215,21 @@ class Block(nn.Module):
                                alpha=aq, out_shape=(B, L, 3 * W))
             x = ops.linear_t(ops.attention_t(qkv, self.heads, causal), wo, m, W, W, self.out.bias, residual=x, alpha=ao, out_shape=x.shape)
             return self._mlp_hand(x, ops, W, mlp)
-        w, a_ = self._w_split("qkv", ops, mode)
-        qkv = ops.linear_split(ops.layer_norm_split(x, self.ln1.weight, self.ln1.bias, self.ln1.eps, mode), w, self.qkv.bias, alpha=a_)
+        if rows is not None and mode == "f16x3" and ops.mlp_mode() == "block" and ops.block_fused_supported(W, mlp, self.heads, L):
+            # the pooled-row block still needs every token's keys and values: its QKV GEMM (all rows) in the hand-written kernel
+            # too, with the LayerNorm folded in when the block in front left its operand and statistics
+            m = B * L
+            if carry is not None and ops.ln_fold_enabled() and W % 32 == 0:
+                wq, aq, csq, bq = self._w_tiled_ln("qkv", self.ln1, ops, 1.0)
+                qkv = ops.linear_t_ln(carry[0], wq, m, 3 * W, W, bq, alpha=aq, out_shape=(B, L, 3 * W),
+                                      row_aff=ops.ln_finalize(carry[1], m, W, self.ln1.eps), colsum=csq)
+            else:
+                wq, aq = self._w_tiled("qkv", ops)
+                qkv = ops.linear_t(ops.layer_norm_t(x, self.ln1.weight, self.ln1.bias, self.ln1.eps), wq, m, 3 * W, W, self.qkv.bias,
+                                   alpha=aq, out_shape=(B, L, 3 * W))
+        else:
+            w, a_ = self._w_split("qkv", ops, mode)
+            qkv = ops.linear_split(ops.layer_norm_split(x, self.ln1.weight, self.ln1.bias, self.ln1.eps, mode), w, self.qkv.bias, alpha=a_)
         hip_attn = W == 64 * self.heads and L <= ops.ATTENTION_MAX_SEQ
         if hip_attn and rows is None:
             a6 = ops.attention_split(qkv, self.heads, causal, mode)      # the attention kernel stores the split operand itself
@@ -342,10 +356,10 @@ class VisionTower(nn.Module):
             x = torch.cat([self.cls.expand(x.shape[0], 1, -1), x], dim=1) + self.pos
             x = self.pre_ln(x)
         carry = None
-        for i, b in enumerate(self.blocks[:-1]):
-            x, carry = b.forward_chain(x, causal=False, carry=carry, emit=i + 2 < len(self.blocks))
+        for b in self.blocks[:-1]:
+            x, carry = b.forward_chain(x, causal=False, carry=carry)
         batch = torch.arange(x.shape[0], device=x.device)
-        x = self.blocks[-1](x, causal=False, rows=(batch, torch.zeros_like(batch)))   # CLS rows of the last block
+        x = self.blocks[-1](x, causal=False, rows=(batch, torch.zeros_like(batch)), carry=carry)   # CLS rows of the last block
         if fused:
             return ops.linear(ops.layer_norm(x, self.post_ln.weight, self.post_ln.bias, self.post_ln.eps), self.proj.weight)
         return self.proj(self.post_ln(x))
@@ -383,9 +397,9 @@ class TextTower(nn.Module):
         else:
             x = self.tok(input_ids[:, :L]) + self.pos[:L]
         carry = None
-        for i, b in enumerate(self.blocks[:-1]):
-            x, carry = b.forward_chain(x, causal=True, carry=carry, emit=i + 2 < len(self.blocks))
-        x = self.blocks[-1](x, causal=True, rows=(torch.arange(x.shape[0], device=x.device), eot))   # EOT rows only
+        for b in self.blocks[:-1]:
+            x, carry = b.forward_chain(x, causal=True, carry=carry)
+        x = self.blocks[-1](x, causal=True, rows=(torch.arange(x.shape[0], device=x.device), eot), carry=carry)   # EOT rows only
         if fused:
             return ops.linear(ops.layer_norm(x, self.final_ln.weight, self.final_ln.bias, self.final_ln.eps), self.proj.weight)
         return self.proj(self.final_ln(x))
