@@ -411,8 +411,10 @@ def bench_cifar(args, world, rank, dev):
                   "accumulation (delivered error vs float64 at the fp32 GEMM's level, tests/test_gpu_parity.py); patch embedding / projections: lemon_linear_f32; "
                   "recorded solution per shape, bias / SiLU / residual epilogues; LEMON_GEMM = f32 | bf16x6 | f16x3 selects the mode",
         "f16x3": f"LEMON_MLP={_ops.mlp_mode()} (block = default: QKV, output projection, fc1, fc2 of every block; fused: fc1, fc2): hand-written split-fp16 GEMM "
-                 "gemm_f16x3.hip (v_mfma_f32_16x16x32_f16, tile-major operands written by LayerNorm / attention / fc1's epilogue, LDS-DMA ring); "
-                 "patch embedding, the pooled-row last block (and what the mode leaves out): lemon_linear_f16x3 on hipBLASLt -- both fp32 operands "
+                 "gemm_f16x3.hip (v_mfma_f32_16x16x32_f16, tile-major operands written by the preprocess kernel / attention / the GEMM epilogues, "
+                 f"LDS-DMA ring; LEMON_LNFOLD={int(_ops.ln_fold_enabled())}: the two LayerNorms of a block folded into QKV / fc1, whose operands and row statistics "
+                 "the output projection / fc2 epilogues write); also the patch embedding and the last block's all-token QKV; the pooled rows of the "
+                 "last block (and what the mode leaves out): lemon_linear_f16x3 on hipBLASLt -- both fp32 operands "
                  "split into two fp16 parts (hi = f16(v), lo = the exact remainder kept to 11 bits: 22 bits + sign), weights pre-scaled by a "
                  "power of two, hi.hi + hi.lo + lo.hi summed by one fp16 GEMM with fp32 accumulation (error vs float64 at the "
                  "fp32 GEMM's level, tests/test_gpu_parity.py); final projections: lemon_linear_f32; recorded solution per "
