@@ -1,3 +1,6 @@
+# Probe of the folded-LayerNorm fp32 epilogue (round 4): which operand of out = aff.x * (alpha acc) + aff.y * colsum + bias + residual
+# goes wrong?  Row affines of five kinds against the plain kernel + host arithmetic; see DESIGN.md "hardware facts" (the
+# v_pk_mul_f32 op_sel fault) and profiles/r4/ln_fold_opsel_fault.txt.  DBG_SO=<path> loads another build of the library.
 import torch, sys, os
 sys.path.insert(0, ".")
 import lemon_amd._lib as L
