@@ -266,3 +266,19 @@ def test_gemm16_variants_register_discipline():
         assert _loops_with_mfma_and_scratch(bodies[n], _probe=True), "the parser must see the MFMA loop"
         bad = [ln.strip() for ln in bodies[n] if re.search(r"\bv_pk_\w+_f32\b", ln) and re.search(r"op_sel:\[[01,]*1", ln)]
         assert not bad, (n, bad[:4])
+
+
+# ---- every kernel of the library: no packed fp32 instruction whose LOW lane takes the HIGH dword of a pair -------------------
+# tools/micro/pk_opsel_war.hip (variants 10-12, nothing hand-issued): with MFMA waves of the same workgroup on the SIMD, hipcc's own
+# `v_pk_mul_f32 d, a, b op_sel:[0,1]` + `v_pk_fma_f32` give wrong LOW results in lanes 48-63 a few thousand times per 6.5e8; with
+# the multiplier broadcast into its own pair first (no op_sel; op_sel_hi forms allowed) never.  Any kernel here can share a SIMD
+# with matrix instructions, so the pattern is refused everywhere.
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_no_kernel_uses_a_packed_fp32_op_with_op_sel():
+    from lemon_amd import build
+    for src in build.SOURCES:
+        if not os.path.exists(os.path.join(CSRC, src)):
+            continue
+        for name, lines in _kernel_bodies(_kernel_asm(src)).items():
+            bad = [ln.strip() for ln in lines if re.search(r"\bv_pk_\w+_f32\b", ln) and re.search(r"op_sel:\[[01,]*1", ln)]
+            assert not bad, (src, name, bad[:3])

@@ -52,7 +52,14 @@ __global__ __launch_bounds__(512, 1) void k_probe(const float *__restrict__ in, 
 #define TAIL "v_pk_add_f32 %3, %3, %3\n\tv_pk_fma_f32 %2, %8, %4, %0 op_sel_hi:[1,0,1]"
 #define OUTS : "=&v"(t), "=&v"(oxy), "=&v"(ozw), "+v"(filler)
 #define INS  : "v"(aff), "v"(cxy), "v"(czw), "v"(vxy), "v"(vzw), "v"(yy)
-        if (VARIANT == 0 || VARIANT == 1 || VARIANT >= 7) asm volatile(HEAD "v_pk_mul_f32 %0, %6, %4 op_sel:[0,1]\n\t" TAIL OUTS INS);
+        if (VARIANT >= 10) {      // no asm at all: hipcc's own packed arithmetic (vector types) against its scalar arithmetic (pinned)
+            f32x2 ax = {aff[0], aff[0]}, ay2 = {aff[1], aff[1]};
+            if (VARIANT == 11) asm volatile("" : "+v"(ax), "+v"(ay2));      // broadcast pairs in their own registers: no op_sel / op_sel_hi at all
+            if (VARIANT == 12) asm volatile("" : "+v"(ay2));                // only the multiply's operand broadcast: op_sel_hi forms remain
+            t = cxy * ay2; oxy = __builtin_elementwise_fma(vxy, ax, t);
+            t2 = czw * ay2; ozw = __builtin_elementwise_fma(vzw, ax, t2);
+        }
+        else if (VARIANT == 0 || VARIANT == 1 || (VARIANT >= 7 && VARIANT <= 9)) asm volatile(HEAD "v_pk_mul_f32 %0, %6, %4 op_sel:[0,1]\n\t" TAIL OUTS INS);
         else if (VARIANT == 2) asm volatile(HEAD "s_nop 0\n\tv_pk_mul_f32 %0, %6, %4 op_sel:[0,1]\n\t" TAIL OUTS INS);
         else if (VARIANT == 3) asm volatile("v_pk_mul_f32 %0, %6, %5 op_sel:[0,1]\n\tv_pk_add_f32 %3, %3, %3\n\tv_pk_fma_f32 %1, %8, %5, %0 op_sel_hi:[1,0,1]\n\t"
                                             "v_pk_mul_f32 %4, %7, %5 op_sel:[0,1]\n\tv_pk_add_f32 %3, %3, %3\n\tv_pk_fma_f32 %2, %9, %5, %4 op_sel_hi:[1,0,1]"
@@ -75,8 +82,18 @@ __global__ __launch_bounds__(512, 1) void k_probe(const float *__restrict__ in, 
 #undef INS
         float2 a2 = s_aff[wave * 64 + ((lane + i) & 63)];
         if (VARIANT == 8) a2 = make_float2(p[8] + (float)(i & 1), p[9]);
-        const float ex = __builtin_fmaf(vxy[0], a2.x, cxy[0] * a2.y), ey = __builtin_fmaf(vxy[1], a2.x, cxy[1] * a2.y);
-        const float ez = __builtin_fmaf(vzw[0], a2.x, czw[0] * a2.y), ew = __builtin_fmaf(vzw[1], a2.x, czw[1] * a2.y);
+        float ex, ey, ez, ew;
+        if (VARIANT >= 10) {      // scalar on purpose: every product and fma pinned into a single register
+            float t0 = cxy[0] * a2.y, t1 = cxy[1] * a2.y, t2_ = czw[0] * a2.y, t3 = czw[1] * a2.y;
+            asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2_), "+v"(t3));
+            ex = __builtin_fmaf(vxy[0], a2.x, t0); asm volatile("" : "+v"(ex));
+            ey = __builtin_fmaf(vxy[1], a2.x, t1); asm volatile("" : "+v"(ey));
+            ez = __builtin_fmaf(vzw[0], a2.x, t2_); asm volatile("" : "+v"(ez));
+            ew = __builtin_fmaf(vzw[1], a2.x, t3); asm volatile("" : "+v"(ew));
+        } else {
+            ex = __builtin_fmaf(vxy[0], a2.x, cxy[0] * a2.y); ey = __builtin_fmaf(vxy[1], a2.x, cxy[1] * a2.y);
+            ez = __builtin_fmaf(vzw[0], a2.x, czw[0] * a2.y); ew = __builtin_fmaf(vzw[1], a2.x, czw[1] * a2.y);
+        }
         nb[0] += oxy[0] != ex; nb[1] += oxy[1] != ey; nb[2] += ozw[0] != ez; nb[3] += ozw[1] != ew;
         if (filler[0] == 12345.678f) nb[0] += 1000000;
     }
@@ -95,8 +112,9 @@ int main(int argc, char **argv) {
     const char *names[] = {"0 fma reads T, next packed multiply writes T", "1 the same, no MFMA waves next to it", "2 s_nop 0 in between",
                            "3 second multiply into another pair", "4 second product by two scalar multiplies", "5 an independent packed add in between",
                            "6 as 0 without op_sel on the multiplies", "7 as 0, the pair read by compiler-generated LDS code", "8 as 0, the pair from registers (no LDS)",
-                           "9 as 0, s_nop 7 x 2 behind the LDS wait"};
-    for (int v = 0; v < 10; ++v) {
+                           "9 as 0, s_nop 7 x 2 behind the LDS wait", "10 NO asm: hipcc's packed code vs its scalar code", "11 NO asm, broadcast pairs made first (no op_sel, no op_sel_hi)",
+                           "12 NO asm, multiplier pair made first (op_sel_hi only)"};
+    for (int v = 0; v < 13; ++v) {
         CHECK(hipMemset(bad, 0, 128));
         switch (v) {
         case 0: hipLaunchKernelGGL(k_probe<0>, dim3(grid), dim3(512), 0, 0, in, bad, iters); break;
@@ -108,7 +126,10 @@ int main(int argc, char **argv) {
         case 6: hipLaunchKernelGGL(k_probe<6>, dim3(grid), dim3(512), 0, 0, in, bad, iters); break;
         case 7: hipLaunchKernelGGL(k_probe<7>, dim3(grid), dim3(512), 0, 0, in, bad, iters); break;
         case 8: hipLaunchKernelGGL(k_probe<8>, dim3(grid), dim3(512), 0, 0, in, bad, iters); break;
-        default: hipLaunchKernelGGL(k_probe<9>, dim3(grid), dim3(512), 0, 0, in, bad, iters); break;
+        case 9: hipLaunchKernelGGL(k_probe<9>, dim3(grid), dim3(512), 0, 0, in, bad, iters); break;
+        case 10: hipLaunchKernelGGL(k_probe<10>, dim3(grid), dim3(512), 0, 0, in, bad, iters); break;
+        case 11: hipLaunchKernelGGL(k_probe<11>, dim3(grid), dim3(512), 0, 0, in, bad, iters); break;
+        default: hipLaunchKernelGGL(k_probe<12>, dim3(grid), dim3(512), 0, 0, in, bad, iters); break;
         }
         CHECK(hipDeviceSynchronize());
         unsigned hb[32];
