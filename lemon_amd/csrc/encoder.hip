@@ -389,7 +389,7 @@ extern "C" int lemon_layernorm_f16x3(const float *x_dev, const float *weight_dev
 // `rows` are not written; the GEMM never stores what it computes from them)
 extern "C" int lemon_layernorm_f16x3t(const float *x_dev, const float *weight_dev, const float *bias_dev, float eps,
                                       int64_t rows, int width, uint16_t *yt_dev, void *stream_) {
-    LEMON_REQUIRE(rows >= 0 && width > 0 && (width & 15) == 0 && width <= 2048, "rows >= 0, width a multiple of 16, <= 2048");
+    LEMON_REQUIRE(rows >= 0 && width > 0 && (width & 15) == 0 && width <= 2032, "rows >= 0, width a multiple of 16, <= 2032 (the eight-row staging image must fit 64 KB of LDS)");
     if (rows == 0) return LEMON_OK;
     LEMON_REQUIRE(x_dev && weight_dev && bias_dev && yt_dev, "null pointer");
     LEMON_REQUIRE(((((uintptr_t)x_dev) | ((uintptr_t)weight_dev) | ((uintptr_t)bias_dev) | ((uintptr_t)yt_dev)) & 15) == 0, "aligned pointers");
@@ -406,7 +406,7 @@ extern "C" int lemon_layernorm_f16x3t(const float *x_dev, const float *weight_de
 // The input side of a folded LayerNorm for a tensor no GEMM epilogue produced (the first block of a tower): x as the tile-major
 // operand + the rows' (rstd, -mean rstd).  Same statistics arithmetic as lemon_layernorm_f32.
 extern "C" int lemon_rowstats_f16x3t(const float *x_dev, float eps, int64_t rows, int width, uint16_t *yt_dev, float *row_aff_dev, void *stream_) {
-    LEMON_REQUIRE(rows >= 0 && width > 0 && (width & 15) == 0 && width <= 2048, "rows >= 0, width a multiple of 16, <= 2048");
+    LEMON_REQUIRE(rows >= 0 && width > 0 && (width & 15) == 0 && width <= 2032, "rows >= 0, width a multiple of 16, <= 2032 (the eight-row staging image must fit 64 KB of LDS)");
     if (rows == 0) return LEMON_OK;
     LEMON_REQUIRE(x_dev && yt_dev && row_aff_dev, "null pointer");
     LEMON_REQUIRE(((((uintptr_t)x_dev) | ((uintptr_t)yt_dev) | ((uintptr_t)row_aff_dev)) & 15) == 0, "aligned pointers");
