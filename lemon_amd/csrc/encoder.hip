@@ -389,13 +389,15 @@ extern "C" int lemon_layernorm_f16x3(const float *x_dev, const float *weight_dev
 // `rows` are not written; the GEMM never stores what it computes from them)
 extern "C" int lemon_layernorm_f16x3t(const float *x_dev, const float *weight_dev, const float *bias_dev, float eps,
                                       int64_t rows, int width, uint16_t *yt_dev, void *stream_) {
-    LEMON_REQUIRE(rows >= 0 && width > 0 && (width & 15) == 0 && width <= 2032, "rows >= 0, width a multiple of 16, <= 2032 (the eight-row staging image must fit 64 KB of LDS)");
+    LEMON_REQUIRE(rows >= 0 && width > 0 && (width & 15) == 0 && width <= 2048, "rows >= 0, width a multiple of 16, <= 2048");
     if (rows == 0) return LEMON_OK;
     LEMON_REQUIRE(x_dev && weight_dev && bias_dev && yt_dev, "null pointer");
     LEMON_REQUIRE(((((uintptr_t)x_dev) | ((uintptr_t)weight_dev) | ((uintptr_t)bias_dev) | ((uintptr_t)yt_dev)) & 15) == 0, "aligned pointers");
     hipStream_t stream = (hipStream_t)stream_;
     const dim3 grid((unsigned)((rows + 7) / 8)), block(256);
     const size_t lds = (size_t)(2 * (width / 8) + 1) * 8 * 16;         // 24.1 KB at width 768
+    if (lds > 65536)      // (width 2048: 65 664 B; the attribute is per device, this shape is rare: set on every such call)
+        LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_layernorm8_t<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (width <= 512) hipLaunchKernelGGL((k_layernorm8_t<1>), grid, block, lds, stream, x_dev, weight_dev, bias_dev, eps, rows, width, yt_dev);
     else if (width <= 1024) hipLaunchKernelGGL((k_layernorm8_t<2>), grid, block, lds, stream, x_dev, weight_dev, bias_dev, eps, rows, width, yt_dev);
     else hipLaunchKernelGGL((k_layernorm8_t<4>), grid, block, lds, stream, x_dev, weight_dev, bias_dev, eps, rows, width, yt_dev);
@@ -406,7 +408,7 @@ extern "C" int lemon_layernorm_f16x3t(const float *x_dev, const float *weight_de
 // The input side of a folded LayerNorm for a tensor no GEMM epilogue produced (the first block of a tower): x as the tile-major
 // operand + the rows' (rstd, -mean rstd).  Same statistics arithmetic as lemon_layernorm_f32.
 extern "C" int lemon_rowstats_f16x3t(const float *x_dev, float eps, int64_t rows, int width, uint16_t *yt_dev, float *row_aff_dev, void *stream_) {
-    LEMON_REQUIRE(rows >= 0 && width > 0 && (width & 15) == 0 && width <= 2032, "rows >= 0, width a multiple of 16, <= 2032 (the eight-row staging image must fit 64 KB of LDS)");
+    LEMON_REQUIRE(rows >= 0 && width > 0 && (width & 15) == 0 && width <= 2048, "rows >= 0, width a multiple of 16, <= 2048");
     if (rows == 0) return LEMON_OK;
     LEMON_REQUIRE(x_dev && yt_dev && row_aff_dev, "null pointer");
     LEMON_REQUIRE(((((uintptr_t)x_dev) | ((uintptr_t)yt_dev) | ((uintptr_t)row_aff_dev)) & 15) == 0, "aligned pointers");
@@ -414,6 +416,8 @@ extern "C" int lemon_rowstats_f16x3t(const float *x_dev, float eps, int64_t rows
     const dim3 grid((unsigned)((rows + 7) / 8)), block(256);
     const size_t lds = (size_t)(2 * (width / 8) + 1) * 8 * 16;
     float2 *aff = reinterpret_cast<float2 *>(row_aff_dev);
+    if (lds > 65536)
+        LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_layernorm8_t<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (width <= 512) hipLaunchKernelGGL((k_layernorm8_t<1, true>), grid, block, lds, stream, x_dev, nullptr, nullptr, eps, rows, width, yt_dev, aff);
     else if (width <= 1024) hipLaunchKernelGGL((k_layernorm8_t<2, true>), grid, block, lds, stream, x_dev, nullptr, nullptr, eps, rows, width, yt_dev, aff);
     else hipLaunchKernelGGL((k_layernorm8_t<4, true>), grid, block, lds, stream, x_dev, nullptr, nullptr, eps, rows, width, yt_dev, aff);
