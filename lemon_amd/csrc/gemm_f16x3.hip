@@ -366,7 +366,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
         PIN_ACC16();
         LSTAMP(lp_c);
         // slots t and t+1 have landed (this wave's share; the barrier makes it everyone's): the only younger DMAs are slot t+2's
+#if defined(LEMON_GEMM_ABLATE) && (LEMON_GEMM_ABLATE & 8)
+        if (t + 2 < KS) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         if (t + 2 < KS) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         __builtin_amdgcn_s_barrier();
 #ifdef LEMON_GEMM_PHASES
         if (t == 0) ph1 = __builtin_amdgcn_s_memtime();
@@ -425,10 +429,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
         const unsigned la3 = lds0 + p0 * STAGE + wave * (BLKA / 2), lw3 = lds0 + p0 * STAGE + 2 * BLKA + wave * (BLKW / 2);
         const unsigned la4 = lds0 + p1 * STAGE + wave * (BLKA / 2), lw4 = lds0 + p1 * STAGE + 2 * BLKA + wave * (BLKW / 2);
         static_assert(BLKA / 2048 == 2, "two activation pieces per wave and slot");
+#if defined(LEMON_GEMM_ABLATE) && (LEMON_GEMM_ABLATE & 8)
+        // (diagnostic: the activation pieces -- a third of the operand bytes -- are not fetched: what a third less delivery is worth)
+        MF_BLOCK(1);
+#else
         MF_BLOCK(1); if (d3) { dma1k(as3, va, la3); dma1k(as3, va + 1024, la3 + 1024); }
+#endif
         MF_BLOCK(2); if (d3) { dma1k(ws3, vw, lw3); dma1k(ws3, vw + 1024, lw3 + 1024); }
         MF_BLOCK(3); if (d3) { dma1k(ws3, vw + 2048, lw3 + 2048); dma1k(ws3, vw + 3072, lw3 + 3072); }
+#if defined(LEMON_GEMM_ABLATE) && (LEMON_GEMM_ABLATE & 8)
+        MF_BLOCK(4);
+#else
         MF_BLOCK(4); if (d4) { dma1k(as4, va, la4); dma1k(as4, va + 1024, la4 + 1024); }
+#endif
         MF_BLOCK(5); if (d4) { dma1k(ws4, vw, lw4); dma1k(ws4, vw + 1024, lw4 + 1024); }
         MF_BLOCK(6); if (d4) { dma1k(ws4, vw + 2048, lw4 + 2048); dma1k(ws4, vw + 3072, lw4 + 3072); }
         MF_BLOCK(7);
