@@ -3,6 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lemon_amd import _lib, ops
+if os.environ.get("DBG_SO"): _lib.SO_PATH = os.environ["DBG_SO"]
 lib = _lib.load()
 for B, L, H in ((256, 197, 12), (128, 257, 16), (332, 197, 12), (2620, 50, 12), (64, 77, 8)):
     qkv = torch.randn(B, L, 3 * H * 64, device="cuda")
