@@ -33,7 +33,7 @@ fi
 n=20
 # configs[2] / configs[4] encoders: ViT-B/16 (L = 197) and ViT-L/14 (L = 257) at 4 000 + 500 + 500 samples
 [[ $PART == *b* ]] && for a in vit-b-16 vit-l-14; do
-  eb=332; [ $a = vit-l-14 ] && eb=255
+  eb=664; [ $a = vit-l-14 ] && eb=510      # 1 022 / 1 024 row tiles of 128 token rows
   A="--arch $a --n_train 4000 --n_val 500 --n_test 500 --encoder_batch $eb $P"
   n=$((n+1))
   python3 $R/bench.py --steps 2 --warmup 1 $A > $OUT/bench_${a}_$TAG.json 2> $OUT/bench_${a}_$TAG.err || exit $n
