@@ -250,7 +250,7 @@ def test_long_sequence_attention_kernel_fits_four_waves_and_keeps_scratch_out_of
 #     epilogue values, never inside the MFMA loop;
 # (2) no packed fp32 instruction takes the HIGH dword of a register pair for its LOW lane (`op_sel:[..1..]`): with
 #     `v_pk_mul_f32 ... op_sel:[0,1]` on a (rstd, -mean rstd) pair that had just arrived from LDS / memory the low results of
-#     lanes 48-63 were wrong now and then on the GPU (round 4, tools/scratch history in DESIGN.md); the epilogues keep such
+#     lanes 48-63 were wrong now and then on the GPU (round 4: DESIGN.md "Hardware facts", profiles/r4/ln_fold_opsel_fault.txt); the epilogues keep such
 #     products in single registers, and this test keeps hipcc from quietly re-pairing them.
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_gemm16_variants_register_discipline():
