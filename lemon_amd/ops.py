@@ -370,12 +370,35 @@ def linear_t(at, wt, m, n, k, bias=None, residual=None, act=None, alpha=1.0, out
 LN_FOLD_MAX_SHIFT = 8.0     # csrc/common.hpp LEMON_LN_FOLD_MAX_SHIFT: rows with |mean| rstd beyond it get a NaN row affine (-> fallback)
 
 
+_forced_ln_fold = None            # set by ln_fold_forced(): overrides $LEMON_LNFOLD for the calls inside the context
+
+
+class ln_fold_forced:
+    """with ln_fold_forced(False): ... -- the towers run their LayerNorms as kernels for the calls inside, whatever $LEMON_LNFOLD
+    says (pipeline.Embedder re-runs a micro-batch whose rows were beyond the fold's mean bound this way first)."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _forced_ln_fold
+        self.prev, _forced_ln_fold = _forced_ln_fold, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _forced_ln_fold
+        _forced_ln_fold = self.prev
+        return False
+
+
 def ln_fold_enabled():
     """LEMON_LNFOLD (default 1): with LEMON_GEMM=f16x3 and LEMON_MLP=block the LayerNorms in front of QKV and fc1 are folded into
     the hand-written GEMMs (lemon_linear_f16x3t_ln): the output projection / fc2 write the residual stream also as the next
     GEMM's operand together with row statistics, QKV / fc1 apply (rstd, -mean rstd) and the weight-row sums in their epilogue --
     no LayerNorm pass over the token matrix.  0: LayerNorm kernels as before (A/B aid)."""
     import os
+    if _forced_ln_fold is not None:
+        return _forced_ln_fold
     return os.environ.get("LEMON_LNFOLD", "1") != "0"
 
 

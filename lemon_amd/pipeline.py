@@ -107,7 +107,8 @@ class Embedder:
     (3-way bf16 split GEMMs, fp32 attention: the same fp32-equivalent contract) -- counted in `fallback_batches`, reported by
     the CLI.  The same path catches the folded LayerNorm's bound (ops.ln_fold_enabled): a row whose mean lies more than
     ops.LN_FOLD_MAX_SHIFT standard deviations from 0 is given a NaN row affine by the kernels, so its micro-batch is flagged
-    and re-embedded here with LayerNorm kernels.  What is still not finite after that is not a range problem and raises in raise_if_nonfinite()."""
+    and re-embedded here -- first with the same f16x3 arithmetic and LayerNorm kernels (`fold_fallback_batches`), and only if it
+    is still not finite with the range-free scheme.  What is still not finite after that is not a range problem and raises in raise_if_nonfinite()."""
 
     def __init__(self, model, device, batch_size=128, dtype=torch.float32, text_dedup=False, text_batch_size=None, range_fallback=True):
         self.model = model.eval().to(device=device, dtype=dtype)
@@ -118,6 +119,7 @@ class Embedder:
         self._nonfinite = None        # device flag: some embedding so far was not finite (raise_if_nonfinite)
         self.range_fallback = range_fallback
         self.fallback_batches = 0     # micro-batches re-embedded with bf16x6 operands because fp16 overflowed
+        self.fold_fallback_batches = 0    # micro-batches re-embedded with LayerNorm kernels because a row's mean was beyond the fold's bound
 
     def _note(self, e):
         if e.is_cuda and e.shape[0]:
@@ -140,7 +142,17 @@ class Embedder:
         outs = [run_one(lo, hi).float() for lo, hi in spans]
         if outs and outs[0].is_cuda and self.range_fallback and ops.gemm_mode() == "f16x3":
             bad = torch.stack([~torch.isfinite(e).all() for e in outs]).cpu()          # the call's one host read
-            for j in bad.nonzero().flatten().tolist():
+            flagged = bad.nonzero().flatten().tolist()
+            if flagged and ops.ln_fold_enabled() and ops.mlp_mode() == "block":
+                # first the cheap cause: a row beyond the folded LayerNorm's mean bound (NaN row affine) -- the same arithmetic with
+                # LayerNorm kernels; what is still not finite after that (one more host read, only on this path) left the fp16 range
+                with ops.ln_fold_forced(False):
+                    for j in flagged:
+                        outs[j] = run_one(*spans[j]).float()
+                still = torch.stack([~torch.isfinite(outs[j]).all() for j in flagged]).cpu().tolist()
+                self.fold_fallback_batches += sum(1 for s_ in still if not s_)
+                flagged = [j for j, s_ in zip(flagged, still) if s_]
+            for j in flagged:
                 with ops.gemm_mode_forced("bf16x6"):
                     outs[j] = run_one(*spans[j]).float()
                 self.fallback_batches += 1
