@@ -250,8 +250,9 @@ int lemon_linear_f16x3t_ln(const uint16_t *at_dev, const uint16_t *wt_dev, const
 int lemon_ln_finalize(const float *partials_dev, int64_t rows, int width, float eps, float *row_aff_dev, void *stream);
 int lemon_rowstats_f16x3t(const float *x_dev, float eps, int64_t rows, int width, uint16_t *yt_dev, float *row_aff_dev, void *stream);
 /* Timing of the hand-written GEMM (no reference counterpart; bench.py's roofline object): while profiling is on every
- * lemon_linear_f16x3t launch of this process is bracketed by HIP events on its launch stream (a pool of 8 192 pairs, made
- * on the first call; launches beyond it are not bracketed).  profile_read waits for the recorded events, returns the number
+ * lemon_linear_f16x3t launch of this process is bracketed by HIP events on its launch stream (a pool that grows with the
+ * launches between two reads; a launch that cannot get its events fails with LEMON_E_HIP, none is silently left out).
+ * profile_read waits for the recorded events, returns the number
  * of bracketed launches, their summed durations and their summed arithmetic (2 m n 3k: the three fp16 products the kernel
  * executes per fp32 product), and rewinds the pool. */
 int lemon_linear_f16x3t_set_profiling(int on);

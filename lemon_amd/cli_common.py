@@ -188,12 +188,12 @@ def prepare(args):
         e_txt = embedder.embed_texts(torch.cat(toks)) if toks else torch.empty((0, d), device=device)
         embedder.raise_if_nonfinite()
         if getattr(embedder, "fold_fallback_batches", 0) and not getattr(embedder, "_fold_fallback_reported", 0) == embedder.fold_fallback_batches:
-            print(f"note: {embedder.fold_fallback_batches} encoder micro-batch(es) so far held a row whose mean lies beyond the folded LayerNorm's "
-                  "bound and were embedded again with LayerNorm kernels (same arithmetic otherwise)")
+            print(f"note: {getattr(embedder, 'fold_fallback_rows', 0)} sample(s) in {embedder.fold_fallback_batches} encoder micro-batch(es) so far held a row whose "
+                  "mean lies beyond the folded LayerNorm's bound and were embedded again with LayerNorm kernels (same arithmetic otherwise)")
             embedder._fold_fallback_reported = embedder.fold_fallback_batches
         if embedder.fallback_batches and not getattr(embedder, "_fallback_reported", 0) == embedder.fallback_batches:
-            print(f"note: {embedder.fallback_batches} encoder micro-batch(es) so far left the fp16 range of the split GEMM operands and were "
-                  "embedded again with bf16x6 operands / fp32 attention (same fp32-equivalent arithmetic, no range limit)")
+            print(f"note: {getattr(embedder, 'fallback_rows', 0)} sample(s) in {embedder.fallback_batches} encoder micro-batch(es) so far left the fp16 range of the "
+                  "split GEMM operands and were embedded again with bf16x6 operands / fp32 attention (same fp32-equivalent arithmetic, no range limit)")
             embedder._fallback_reported = embedder.fallback_batches
         meta["lo"] = lo
         if cache.root:

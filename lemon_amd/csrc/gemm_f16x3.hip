@@ -762,15 +762,17 @@ __global__ __launch_bounds__(256) void k_ln_finalize(const float *__restrict__ p
 constexpr int MAX_DEVICES = 64;
 std::mutex g_attr_mu;
 bool g_attr_set[MAX_DEVICES] = {};
-// optional timing of every launch (lemon_linear_f16x3t_set_profiling): HIP events on the launch stream from a pool made once,
-// read back (and the pool rewound) by lemon_linear_f16x3t_profile_read -- bench.py's roofline object for the step's dominant kernel
+// optional timing of every launch (lemon_linear_f16x3t_set_profiling): HIP events on the launch stream from a pool that GROWS with
+// the launches it has to bracket (round 4 had a fixed pool of 8 192 pairs and silently stopped recording behind it: a 20-step
+// bench region has 18 200 launches), read back (and the pool rewound) by lemon_linear_f16x3t_profile_read -- bench.py's roofline
+// object for the step's dominant kernel.  A launch that cannot get its events fails (LEMON_E_HIP): nothing is dropped.
 struct GemmProf {
     bool on = false;
     std::vector<hipEvent_t> ev;        // pairs
     std::vector<double> flops;
     size_t used = 0;                   // events handed out
 } g_prof;
-constexpr size_t PROF_POOL = 2 * 8192;
+constexpr size_t PROF_POOL = 2 * 1024; // events created when profiling is switched on; more are made as launches need them
 int g_gm = 0, g_gn = 0;                // tile-walk override (tools/micro); 0: the defaults
 #ifdef LEMON_GEMM_PHASES
 unsigned long long *g_phase_dbg = nullptr;
@@ -905,7 +907,12 @@ static int linear_f16x3t_impl(const uint16_t *at_dev, const uint16_t *wt_dev, co
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_attr_mu);
-        if (g_prof.on && g_prof.used + 2 <= g_prof.ev.size()) {
+        if (g_prof.on) {
+            while (g_prof.used + 2 > g_prof.ev.size()) {       // every launch of a profiled region is bracketed
+                hipEvent_t e = nullptr;
+                LEMON_HIP_CHECK(hipEventCreate(&e));
+                g_prof.ev.push_back(e);
+            }
             ev0 = g_prof.ev[g_prof.used]; ev1 = g_prof.ev[g_prof.used + 1];
             g_prof.used += 2;
             g_prof.flops.push_back(2.0 * (double)m * (double)n * 3.0 * (double)k);      // the kernel's own arithmetic: three fp16 products

@@ -1164,6 +1164,501 @@ __global__ __launch_bounds__(NT, 1) void k_scan_bf16_qs2(ScanParamsH p) {
 }
 
 // ======================================================================================
+// QS4 (round 5): the Q-stationary scan on v_mfma_f32_16x16x32_f16.
+//
+// Same work per workgroup as QS2 (256 queries, 64 per wave, 64-row database tiles, 4 x 16 KB LDS ring fed by LDS-DMA, one
+// wave per SIMD, 512 registers) and the same LDS bytes per flop, but the wave's 64 x 64 tile is 4 x 4 accumulator tiles of
+// 16 x 16 (4 registers each): per k32 step 4 database fragments (16 rows x 32 k) x 4 query fragments (16 queries x 32 k) =
+// 16 MFMAs of 16 cycles.  Why (tools/micro/qs3_loop.hip against qs2_loop.hip on one box, random operands, all workgroups
+// in step): the 16x16x32 form draws less power per flop -- the board holds 2.14 GHz instead of 1.89 -- and its issue
+// granularity lets everything else ride BETWEEN the MFMAs instead of in front of them:
+//   * fragment reads of step s + 1 and the stage's four DMA pieces are issued one per MFMA gap of step s (an MFMA holds
+//     the vector issue for 8 of its 16 cycles): loop replica 1 431 (QS2) -> 1 481 (same schedule) -> 1 527 (DMA spread)
+//     -> 1 565 TFLOP/s (reads interleaved too) on the slower of two boxes, 1 500 -> 1 615 on the faster;
+//   * the ring's barrier sits in the MIDDLE of a stage (behind step 1 of 4): stage t + 1 has landed for every wave two
+//     steps before anybody needs it, so the first fragments of a stage are read during the last step of the one before
+//     (QS2 reads them behind the barrier: one exposed LDS round trip per stage), and the slot of stage t - 1 is free for
+//     the DMA of stage t + 3 in steps 2 and 3;
+//   * the filter of tile j runs between the MFMAs of tile j + 1's FIRST step: that step is ordered by query group
+//     (b-major), the MFMAs of group b start from C = 0, and the filter of group b -- eight v_max3 over the lane's sixteen
+//     scores of that group, one compare, one scalar branch -- sits in front of them while the MFMAs of group b - 1 run.
+//     No accumulator read-out phase, no s_nop: the values a filter reads were finished twelve MFMAs earlier.
+// Accumulator layout C[row = 4 (lane >> 4) + i][col = lane & 15]: a QUERY lives on the four lanes c, c + 16, c + 32, c + 48,
+// each of which sees 16 of a tile's 64 rows; every lane appends to its own QUARTER of the query's list (128 entries, count
+// in a VGPR).  A light compaction reads the four quarters as one list and deals the survivors back round-robin, so the
+// quarters stay balanced and `full` (a quarter within one tile of its capacity) practically never fires.
+// Fragment homes: (group b, step s) -> index f = b NS + s; f < 64 in AccVGPRs, the rest in VGPRs, group 3's last PARK
+// steps in LDS (lane-linear).  Tiles, splits and chunks are counted in 64-ROW units, as in QS2.
+// ======================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int QCAP4 = CAPH / 4;    // entries per lane list (quarter of a query's list)
+
+template <bool BA, bool INIT>
+__device__ __forceinline__ void mfma16(f32x4 &acc, bf16x8 a, const bf16x8 &bq) {
+    // (the accumulator is "+v" in the C = 0 form too: the filter's reads of the finished tile must stay in front of it, and the
+    // new tile must take the old one's registers)
+    if (INIT) { if (BA) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "+v"(acc) : "v"(a), "a"(bq));
+                else    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "+v"(acc) : "v"(a), "v"(bq)); }
+    else      { if (BA) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(bq));
+                else    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(bq)); }
+}
+
+// one 1-KiB piece of a 64-row x 128-B slice: the wave's rows 16 wave + 8 half + lane / 8 (see qs2_dma_slice)
+__device__ __forceinline__ void qs4_dma_piece(const float *__restrict__ src, unsigned lds_bytes, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(src), "s"(lds_bytes) : "memory");
+}
+
+__device__ __forceinline__ unsigned append_slot4(int cnt) {      // (see append_slot: a broken invariant must not leave the list)
+    return (unsigned)cnt < (unsigned)(QCAP4 - 1) ? (unsigned)cnt : (unsigned)(QCAP4 - 1);
+}
+
+// the lane's sixteen scores of one query group: c<a>[i] = s~(row jb + 16 a + i, the lane's query of the group).  Returns whether
+// any lane of the wave appended (wave-uniform).
+template <bool l2>
+__device__ __forceinline__ bool qs4_filter_group(f32x4 &c0, f32x4 &c1, f32x4 &c2, f32x4 &c3, float th, unsigned jb, float qn,
+                                                 const float *__restrict__ xnorm, int &ccnt, char *__restrict__ panel_bytes,
+                                                 unsigned my_off) {
+    if (l2) {   // monotone proxy of the key -D: 2 s~ - |x|^2 = key + |q|^2 (th carries the same offset)
+        const float4 x0 = *reinterpret_cast<const float4 *>(&xnorm[jb]), x1 = *reinterpret_cast<const float4 *>(&xnorm[jb + 16]);
+        const float4 x2 = *reinterpret_cast<const float4 *>(&xnorm[jb + 32]), x3 = *reinterpret_cast<const float4 *>(&xnorm[jb + 48]);
+        c0[0] = __builtin_fmaf(2.0f, c0[0], -x0.x); c0[1] = __builtin_fmaf(2.0f, c0[1], -x0.y); c0[2] = __builtin_fmaf(2.0f, c0[2], -x0.z); c0[3] = __builtin_fmaf(2.0f, c0[3], -x0.w);
+        c1[0] = __builtin_fmaf(2.0f, c1[0], -x1.x); c1[1] = __builtin_fmaf(2.0f, c1[1], -x1.y); c1[2] = __builtin_fmaf(2.0f, c1[2], -x1.z); c1[3] = __builtin_fmaf(2.0f, c1[3], -x1.w);
+        c2[0] = __builtin_fmaf(2.0f, c2[0], -x2.x); c2[1] = __builtin_fmaf(2.0f, c2[1], -x2.y); c2[2] = __builtin_fmaf(2.0f, c2[2], -x2.z); c2[3] = __builtin_fmaf(2.0f, c2[3], -x2.w);
+        c3[0] = __builtin_fmaf(2.0f, c3[0], -x3.x); c3[1] = __builtin_fmaf(2.0f, c3[1], -x3.y); c3[2] = __builtin_fmaf(2.0f, c3[2], -x3.z); c3[3] = __builtin_fmaf(2.0f, c3[3], -x3.w);
+    }
+    const float m0 = max3(max3(c0[0], c0[1], c0[2]), c0[3], c0[3]), m1 = max3(max3(c1[0], c1[1], c1[2]), c1[3], c1[3]);
+    const float m2 = max3(max3(c2[0], c2[1], c2[2]), c2[3], c2[3]), m3 = max3(max3(c3[0], c3[1], c3[2]), c3[3], c3[3]);
+    const float m = max3(max3(m0, m1, m2), m3, m3);                 // 10 x v_max3_f32, then ONE compare + scalar branch
+    if (__ballot(m > th) == 0) return false;
+    // survivors are rare (a group sees one in ~half of the tiles): levels of wave ballots + scalar branches, as in qs_filter_tile
+    const u64 bq[4] = {__ballot(m0 > th), __ballot(m1 > th), __ballot(m2 > th), __ballot(m3 > th)};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        if (bq[a]) {                                    // scalar branch
+            const f32x4 &c = a == 0 ? c0 : a == 1 ? c1 : a == 2 ? c2 : c3;
+            u64 be[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) be[i] = __ballot(c[i] > th);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (be[i]) {                            // scalar branch
+                    if (c[i] > th) {                    // (rows >= n: -inf by the caller's masking MFMAs, last tile only)
+                        unsigned j = jb + 16 * a + i;
+                        asm volatile("" : "+v"(j));     // (opaque: no strength-reduced `~j` key words carried around the loop)
+                        const float sc = l2 ? fminf(0.0f, c[i] - qn) : c[i];
+                        *reinterpret_cast<u64 *>(panel_bytes + (my_off + 8u * append_slot4(ccnt))) = lemon_make_key(sc, j);
+                        ++ccnt;
+                    }
+                }
+            }
+        }
+    }
+    return true;
+}
+
+// entry e of a query's four quarter-lists read as ONE list of n0 + n1 + n2 + n3 keys (p1 = n0, p2 = n0 + n1, p3 = p2 + n2)
+__device__ __forceinline__ u64 qs4_load(const u64 *__restrict__ list, int e, int p1, int p2, int p3, int ntot) {
+    const int seg = (e >= p1) + (e >= p2) + (e >= p3);
+    const int base = seg == 0 ? 0 : seg == 1 ? p1 : seg == 2 ? p2 : p3;
+    return e < ntot ? list[seg * QCAP4 + (e - base)] : 0;
+}
+
+// light compaction of one query: bisection for (a lower bound of) the kk-th largest approximate score, survivors dealt
+// back ROUND-ROBIN over the four quarters (entry i -> quarter i & 3, slot i >> 2).  Returns kept.
+template <int NSL>
+__device__ __forceinline__ int qs4_compact_light_ns(u64 *__restrict__ list, int p1, int p2, int p3, int ntot, int kk, float eps,
+                                                    int lane, float *lo_out) {
+    u64 v[NSL];
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) v[i] = qs4_load(list, lane + 64 * i, p1, p2, p3, ntot);
+    u32 o[NSL];
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) o[i] = (u32)(v[i] >> 32);
+    u32 t = 0;                                          // (see qs_compact_light_ns: any lower bound of tau keeps the band a proof)
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; --bit) {
+        const u32 cand = t | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) c += __builtin_popcountll(__ballot(o[i] >= cand));
+        if (c >= kk) {
+            t = cand;
+            if (c <= kk + 8) break;
+        }
+    }
+    const float lo = bound_from_tau(lemon_ord2f(t), eps);
+    const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+        const bool keep = v[i] && lemon_key_score(v[i]) > lo;
+        const u64 m = __ballot(keep);
+        const int pos = base + __builtin_popcountll(m & below);
+        if (keep) list[(pos & 3) * QCAP4 + (pos >> 2)] = v[i];        // (all loads precede these stores)
+        base += __builtin_popcountll(m);
+    }
+    *lo_out = lo;
+    return base;
+}
+__device__ __forceinline__ int qs4_compact_light(u64 *__restrict__ list, int n0, int n1, int n2, int n3, int kk, float eps, int lane,
+                                                 float *lo_out) {
+    const int p1 = n0, p2 = n0 + n1, p3 = p2 + n2, ntot = p3 + n3;
+    const int ns = (ntot + 63) >> 6;                   // wave-uniform
+    if (ns <= 2) return qs4_compact_light_ns<2>(list, p1, p2, p3, ntot, kk, eps, lane, lo_out);
+    if (ns == 3) return qs4_compact_light_ns<3>(list, p1, p2, p3, ntot, kk, eps, lane, lo_out);
+    if (ns == 4) return qs4_compact_light_ns<4>(list, p1, p2, p3, ntot, kk, eps, lane, lo_out);
+    return qs4_compact_light_ns<8>(list, p1, p2, p3, ntot, kk, eps, lane, lo_out);
+}
+
+// exact compaction of one query whose `kept` keys sit round-robin in the quarters (right after a light compaction): exact
+// fp32-chain scores, the exact top-kk dealt back round-robin.  Returns how many exist (<= kk).
+__device__ __forceinline__ int qs4_compact_exact(const ScanParamsH &p, u64 *__restrict__ list, int kept, int64_t q, float qn, int lane,
+                                                 u64 *__restrict__ sk, u64 *__restrict__ sb, u64 *kth_out) {
+    const int kk = p.b.kk;
+    const float *qrow = p.q + q * (int64_t)p.d;
+    const bool l2 = p.b.metric == LEMON_METRIC_L2;
+    u64 best = 0;
+#pragma unroll 1
+    for (int base = 0; base < kept; base += 64) {
+        const int e = base + lane;
+        const u64 old = e < kept ? list[(e & 3) * QCAP4 + (e >> 2)] : 0;
+        u64 key = 0;
+        if (old) {
+            const u32 j = lemon_key_index(old);
+            const float *xrow = p.x + (int64_t)j * p.d;
+            const float s = exact_score(qrow, xrow, p.d, l2, qn, l2 ? p.b.xnorm[j] : 0.0f);
+            key = (s == s) ? lemon_make_key(s, j) : 0;
+        }
+        const Ranked r = wave_rank_keys(best, key, 0, 0, 128, sk, lane);
+        sb[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (best && r.r0 < kk) sb[r.r0] = best;
+        if (key && r.r1 < kk) sb[r.r1] = key;
+        __builtin_amdgcn_wave_barrier();
+        best = sb[lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < kk) list[(lane & 3) * QCAP4 + (lane >> 2)] = best;
+    *kth_out = __shfl(best, kk - 1);
+    return __builtin_popcountll(__ballot(best != 0));
+}
+
+template <int KT, int PARK, bool l2>
+__global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
+    constexpr int NS = 2 * KT;                 // k32 steps per tile
+    constexpr int KT2 = KT / 2;                // stages per tile: 2 x 64-wide k-slices = 4 k32 steps each
+    constexpr int NFR = 4 * NS - PARK;         // query fragments in registers: index f = b NS + s
+    constexpr int NB = 4;                      // LDS stage ring
+    constexpr int STG = 2 * RT2 * BK;          // floats per stage (16 KB)
+    constexpr int PK = PARK ? PARK : 1;
+    static_assert(NT == BQ2 && KT % 2 == 0 && PARK < NS && NFR >= 64, "fragment homes");
+    __shared__ __attribute__((aligned(16))) float smem[NB * STG + (NT / 64) * PK * 256 + 2 * BQ2 + (NT / 64) * (512 + 128)];
+    float *s_x = smem;                                   // [NB][2][64 * 32]
+    float *s_q = smem + NB * STG;                        // [4 waves][PARK][64 lanes x 16 B] parked group-3 fragments
+    float *s_qn = s_q + (NT / 64) * PK * 256;            // [256]
+    float *s_eps = s_qn + BQ2;                           // [256]
+    u64 *s_keys = reinterpret_cast<u64 *>(s_eps + BQ2);  // [4][256] rank-select scratch
+    u64 *s_best = s_keys + (NT / 64) * 256;              // [4][64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+
+    const int panel = blockIdx.x / p.b.splits;
+    const int64_t q0 = (int64_t)panel * BQ2;
+    int t_begin = (blockIdx.x % p.b.splits) * p.b.tiles_per_split;
+    int t_end = t_begin + p.b.tiles_per_split;
+    if (t_end > p.b.n_tiles) t_end = p.b.n_tiles;
+    if (p.b.splits == 1) { t_begin = p.chunk_t0; t_end = p.chunk_t1; }
+    const int ntile = t_end - t_begin;
+    const bool final_pass = (p.b.splits > 1) || p.last_chunk;
+    const int dpad = p.dpad_h / 2;             // row pitch in 4-byte words
+
+    {
+        const float qn = p.b.qnorm[q0 + tid];
+        s_eps[tid] = band_eps(p, qn, p.qres2[q0 + tid], l2);
+        s_qn[tid] = qn;
+    }
+
+    // ---- lane-private candidate state per query group b: query = 64 wave + 16 b + (lane & 15), quarter g4 = lane >> 4 ----
+    const int qrow0 = 64 * wave + l15;                   // group b: + 16 b
+    u64 *cand_panel = p.b.cand + (int64_t)blockIdx.x * BQ2 * CAPH;
+    char *panel_bytes = reinterpret_cast<char *>(cand_panel);
+    const unsigned my_off0 = (unsigned)(qrow0 * CAPH + g4 * QCAP4) * 8u;      // group b: + b * 16 * CAPH * 8
+    int ccnt0 = 0, ccnt1 = 0, ccnt2 = 0, ccnt3 = 0, clast0 = 0, clast1 = 0, clast2 = 0, clast3 = 0;
+    float thk0, thk1, thk2, thk3, qn0 = 0.f, qn1 = 0.f, qn2 = 0.f, qn3 = 0.f;
+    thk0 = (q0 + qrow0 < p.b.nq) ? -INFINITY : INFINITY;
+    thk1 = (q0 + qrow0 + 16 < p.b.nq) ? -INFINITY : INFINITY;
+    thk2 = (q0 + qrow0 + 32 < p.b.nq) ? -INFINITY : INFINITY;
+    thk3 = (q0 + qrow0 + 48 < p.b.nq) ? -INFINITY : INFINITY;
+    // (bit b: the lane's query of group b exists)
+    const unsigned qvalid = (unsigned)(q0 + qrow0 < p.b.nq) | ((unsigned)(q0 + qrow0 + 16 < p.b.nq) << 1) |
+                            ((unsigned)(q0 + qrow0 + 32 < p.b.nq) << 2) | ((unsigned)(q0 + qrow0 + 48 < p.b.nq) << 3);
+    if (l2) { qn0 = p.b.qnorm[q0 + qrow0]; qn1 = p.b.qnorm[q0 + qrow0 + 16]; qn2 = p.b.qnorm[q0 + qrow0 + 32]; qn3 = p.b.qnorm[q0 + qrow0 + 48]; }
+    if (p.b.splits == 1 && !p.first_chunk) {   // resume from the previous database chunk
+        const float *st = p.state + 16 * ((int64_t)blockIdx.x * NT + tid);
+        ccnt0 = __float_as_int(st[0]); clast0 = __float_as_int(st[1]); thk0 = st[2];
+        ccnt1 = __float_as_int(st[4]); clast1 = __float_as_int(st[5]); thk1 = st[6];
+        ccnt2 = __float_as_int(st[8]); clast2 = __float_as_int(st[9]); thk2 = st[10];
+        ccnt3 = __float_as_int(st[12]); clast3 = __float_as_int(st[13]); thk3 = st[14];
+    }
+    auto th_of = [&](float tk, float qn) -> float {      // what the filter compares against (L2: proxy carries +|q|^2)
+        if (!l2 || tk == -INFINITY || tk == INFINITY) return tk;
+        return (tk + qn) - (fabsf(tk) + qn) * 2.4e-7f - 1e-37f;
+    };
+    float th0 = th_of(thk0, qn0), th1 = th_of(thk1, qn1), th2 = th_of(thk2, qn2), th3 = th_of(thk3, qn3);
+
+    // ---- stationary operands: fragment (b, s) = the lane's query of group b, k = 32 s + 8 g4 .. + 7 ----
+    bf16x8 qf[NFR];
+    {
+        const lp16 *src = p.qh + (q0 + qrow0) * (int64_t)p.dpad_h + 8 * g4;
+#pragma unroll
+        for (int s = NS - PARK; s < NS; ++s)   // (prologue: before any LDS-DMA is in flight)
+            *reinterpret_cast<bf16x8 *>(s_q + ((wave * PK + (s - (NS - PARK))) * 64 + lane) * 4) =
+                *reinterpret_cast<const bf16x8 *>(src + (int64_t)48 * p.dpad_h + 32 * s);
+        __builtin_amdgcn_sched_barrier(0);
+        // (loads in groups of eight with a scheduling fence in between: see k_scan_bf16_qs2)
+#pragma unroll
+        for (int f = 0; f < NFR; ++f) {
+            const int b = f / NS, s2 = f % NS;
+            qf[f] = *reinterpret_cast<const bf16x8 *>(src + (int64_t)(16 * b) * p.dpad_h + 32 * s2);
+            if ((f & 7) == 7 || f == NFR - 1) {
+#pragma unroll
+                for (int f2 = f & ~7; f2 <= f; ++f2) { if (f2 < 64) asm volatile("" : "+a"(qf[f2])); else asm volatile("" : "+v"(qf[f2])); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    f32x4 acc[4][4];                            // acc[a][b]: rows 16 a .. + 15 of the tile x query group b
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // lane (l15, g4) reads row 16 a + l15, 16-byte chunk 4 (s & 1) + g4 of slice (s >> 1) & 1: two base addresses (the swizzle
+    // term repeats every 16 rows), a and the slice are immediate offsets, the ring slot is added per stage
+    unsigned fa0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float *)(s_x + swz(l15, g4));
+    unsigned fa1 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float *)(s_x + swz(l15, 4 + g4));
+    const unsigned vq = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float *)(s_q + (wave * PK * 64 + lane) * 4);
+
+    const float *xbase = reinterpret_cast<const float *>(p.xh + (int64_t)t_begin * RT2 * p.dpad_h);
+    const int total = ntile * KT2;
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) float *)s_x + (unsigned)wave * 2048u;
+    const unsigned voff0 = (unsigned)(((16 * wave + (lane >> 3)) * dpad + 4 * ((lane & 7) ^ ((lane >> 4) & 7))) * 4);
+    const unsigned voff1 = (unsigned)(((16 * wave + 8 + (lane >> 3)) * dpad + 4 * ((lane & 7) ^ ((4 + (lane >> 4)) & 7))) * 4);
+    // piece pc (0..3) of the stage kt2_ of the tile at tile_base into ring slot slot_: slice pc >> 1, row half pc & 1
+#define Q4_PIECE(tile_base, kt2_, slot_, pc)                                                                               \
+    qs4_dma_piece((tile_base) + (2 * (kt2_) + ((pc) >> 1)) * BK, lds0 + (unsigned)(((slot_) * STG + ((pc) >> 1) * RT2 * BK) * 4) + 1024u * ((pc) & 1), \
+                  ((pc) & 1) ? voff1 : voff0)
+#pragma unroll
+    for (int s0 = 0; s0 < NB - 1; ++s0)
+        if (s0 < total) {
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) Q4_PIECE(xbase + (int64_t)(s0 / KT2) * RT2 * dpad, s0 % KT2, s0, pc);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (prologue only)
+    __syncthreads();
+
+    bf16x8 fA[2][4], fP[2];                     // two fragment sets: database fragments a = 0..3 (+ the parked query fragment)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { fP[u] = bf16x8{}; for (int a = 0; a < 4; ++a) fA[u][a] = bf16x8{}; }
+    unsigned va0 = fa0, va1 = fa1;              // fragment addresses inside the ring slot being read (slot 0 first)
+    const bool filter_on = !(p.ablate & 1);
+    const bool nothing_passes = (p.ablate & 4) != 0;
+
+    // one database fragment of k32 step S (of the tile) into set U: address base VA0 / VA1 = the stage's slot
+#define Q4_LOADA(U, S, a_)                                                                                                 \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(fA[U][a_]) : "v"(((S) & 1) ? va1 : va0), "n"((((S) >> 1) & 1) * RT2 * 128 + 2048 * (a_)) : "memory")
+#define Q4_LOADP(U, S)                                                                                                     \
+    do { if (PARK && (S) >= NS - PARK) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(fP[U]) : "v"(vq), "n"(((S) >= NS - PARK ? (S) - (NS - PARK) : 0) * 1024) : "memory"); } while (0)
+#define Q4_WAIT(U) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fA[U][0]), "+v"(fA[U][1]), "+v"(fA[U][2]), "+v"(fA[U][3]), "+v"(fP[U]))
+    // MFMA i of step S: query group b = i >> 2 against database fragment a = i & 3
+#define Q4_MF(U, S, i_)                                                                                                    \
+    do {                                                                                                                   \
+        constexpr int b_ = (i_) >> 2, a_ = (i_) & 3, f_ = b_ * NS + (S);                                                   \
+        if (f_ >= NFR)      mfma16<false, (S) == 0>(acc[a_][b_], fA[U][a_], fP[U]);                                        \
+        else if (f_ < 64)   mfma16<true, (S) == 0>(acc[a_][b_], fA[U][a_], qf[f_ < NFR ? f_ : 0]);                         \
+        else                mfma16<false, (S) == 0>(acc[a_][b_], fA[U][a_], qf[f_ < NFR ? f_ : 0]);                        \
+    } while (0)
+
+    // ---- maintenance: light compaction of the queries whose lists need it (all four groups; b, c wave-uniform) ----
+#define Q4_SEL(b_, x0, x1, x2, x3) ((b_) == 0 ? (x0) : (b_) == 1 ? (x1) : (b_) == 2 ? (x2) : (x3))
+    auto maintain = [&]() {
+        u64 todo = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int cc = Q4_SEL(b, ccnt0, ccnt1, ccnt2, ccnt3), cl = Q4_SEL(b, clast0, clast1, clast2, clast3);
+            const float tk = Q4_SEL(b, thk0, thk1, thk2, thk3);
+            int tot = cc + __shfl_xor(cc, 16);
+            tot += __shfl_xor(tot, 32);
+            const bool warm = tk == -INFINITY && tot >= p.b.kk;
+            const bool stale = tot >= p.b.kk && tot - cl >= p.b.stale;
+            const bool full = cc > QCAP4 - 16;            // my quarter could overflow on the next tile (<= 16 appends)
+            u64 m = __ballot(((qvalid >> b) & 1u) && (warm || stale || full));
+            m = (m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffull;       // one bit per query of the group
+            todo |= m << (16 * b);
+        }
+        if (!todo) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's appends are visible
+        do {
+            const int r = __ffsll((long long)todo) - 1;     // = 16 b + c: the query's row inside the wave's 64
+            todo &= todo - 1;
+            const int b = r >> 4, c = r & 15;
+            const int row = 64 * wave + r;
+            u64 *list = cand_panel + (int64_t)row * CAPH;
+            const int cc = Q4_SEL(b, ccnt0, ccnt1, ccnt2, ccnt3);
+            const int n0 = __builtin_amdgcn_readlane(cc, c), n1 = __builtin_amdgcn_readlane(cc, c + 16);
+            const int n2 = __builtin_amdgcn_readlane(cc, c + 32), n3 = __builtin_amdgcn_readlane(cc, c + 48);
+            float lo;
+            int kept = qs4_compact_light(list, n0, n1, n2, n3, p.b.kk, s_eps[row], lane, &lo);
+            if (kept > CAPH - 64) {            // the band itself leaves no room for a tile's appends: settle it exactly
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                u64 kth;
+                kept = qs4_compact_exact(p, list, kept, q0 + row, s_qn[row], lane, s_keys + wave * 256, s_best + wave * 64, &kth);
+                if (kept == p.b.kk) lo = bound_from_tau(lemon_key_score(kth), s_eps[row]);
+            }
+            const int mine = (kept + 3 - g4) >> 2;        // round-robin deal: quarter g holds entries g, g + 4, ...
+            const bool me = l15 == c;
+            if (me && b == 0) { ccnt0 = mine; clast0 = kept; thk0 = lo; th0 = th_of(lo, qn0); }
+            if (me && b == 1) { ccnt1 = mine; clast1 = kept; thk1 = lo; th1 = th_of(lo, qn1); }
+            if (me && b == 2) { ccnt2 = mine; clast2 = kept; thk2 = lo; th2 = th_of(lo, qn2); }
+            if (me && b == 3) { ccnt3 = mine; clast3 = kept; thk3 = lo; th3 = th_of(lo, qn3); }
+        } while (todo);
+    };
+    // the filter of query group b_ on the finished tile whose first row is jt_ (wave-uniform `any` |= appended)
+#define Q4_FILTER(b_, jt_)                                                                                                 \
+    do {                                                                                                                   \
+        const unsigned jb_ = (jt_) + 4u * (unsigned)g4;                                                                    \
+        const float tinf_ = INFINITY;                                                                                      \
+        if ((b_) == 0) any |= qs4_filter_group<l2>(acc[0][0], acc[1][0], acc[2][0], acc[3][0], nothing_passes ? tinf_ : th0, jb_, qn0, p.b.xnorm, ccnt0, panel_bytes, my_off0); \
+        if ((b_) == 1) any |= qs4_filter_group<l2>(acc[0][1], acc[1][1], acc[2][1], acc[3][1], nothing_passes ? tinf_ : th1, jb_, qn1, p.b.xnorm, ccnt1, panel_bytes, my_off0 + 16u * CAPH * 8u); \
+        if ((b_) == 2) any |= qs4_filter_group<l2>(acc[0][2], acc[1][2], acc[2][2], acc[3][2], nothing_passes ? tinf_ : th2, jb_, qn2, p.b.xnorm, ccnt2, panel_bytes, my_off0 + 32u * CAPH * 8u); \
+        if ((b_) == 3) any |= qs4_filter_group<l2>(acc[0][3], acc[1][3], acc[2][3], acc[3][3], nothing_passes ? tinf_ : th3, jb_, qn3, p.b.xnorm, ccnt3, panel_bytes, my_off0 + 48u * CAPH * 8u); \
+    } while (0)
+
+    // k32 step S (compile-time) of the tile on fragment set S & 1.  In the gaps between its MFMAs: the reads of step S + 1
+    // (the next stage's slot once S + 1 starts a stage), in steps 2 and 3 of a stage the DMA pieces of stage t + 3, and in
+    // step 0 of a tile the filter of the previous tile (group b in front of group b's first MFMA).
+#define Q4_STEP(S)                                                                                                         \
+    do {                                                                                                                   \
+        constexpr int U_ = (S) & 1, N_ = ((S) + 1) % NS, sq_ = (S) & 3;                                                    \
+        Q4_WAIT(U_);                                                                                                       \
+        if (sq_ == 3) {   /* the next step opens a stage: its slot */                                                      \
+            const unsigned sbn_ = (unsigned)(((t + 1) & (NB - 1)) * STG * 4);                                              \
+            va0 = fa0 + sbn_; va1 = fa1 + sbn_;                                                                            \
+        }                                                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                                                                \
+            if ((S) == 0 && (i_ & 3) == 0 && do_filter) {                                                                  \
+                if (i_ == 0) Q4_FILTER(0, jprev); if (i_ == 4) Q4_FILTER(1, jprev);                                        \
+                if (i_ == 8) Q4_FILTER(2, jprev); if (i_ == 12) Q4_FILTER(3, jprev);                                       \
+            }                                                                                                              \
+            switch (i_) {                                                                                                  \
+                case 0: Q4_MF(U_, S, 0); break; case 1: Q4_MF(U_, S, 1); break; case 2: Q4_MF(U_, S, 2); break; case 3: Q4_MF(U_, S, 3); break; \
+                case 4: Q4_MF(U_, S, 4); break; case 5: Q4_MF(U_, S, 5); break; case 6: Q4_MF(U_, S, 6); break; case 7: Q4_MF(U_, S, 7); break; \
+                case 8: Q4_MF(U_, S, 8); break; case 9: Q4_MF(U_, S, 9); break; case 10: Q4_MF(U_, S, 10); break; case 11: Q4_MF(U_, S, 11); break; \
+                case 12: Q4_MF(U_, S, 12); break; case 13: Q4_MF(U_, S, 13); break; case 14: Q4_MF(U_, S, 14); break; default: Q4_MF(U_, S, 15); break; \
+            }                                                                                                              \
+            if (i_ == 1) Q4_LOADA(U_ ^ 1, N_, 0);                                                                          \
+            if (i_ == 3) Q4_LOADA(U_ ^ 1, N_, 1);                                                                          \
+            if (i_ == 5) Q4_LOADA(U_ ^ 1, N_, 2);                                                                          \
+            if (i_ == 7) Q4_LOADA(U_ ^ 1, N_, 3);                                                                          \
+            if (i_ == 9) Q4_LOADP(U_ ^ 1, N_);                                                                             \
+            if (sq_ >= 2 && more && (i_ == 11 || i_ == 13)) {                                                              \
+                constexpr int kn_ = (S) / 4 + 3;                                                                           \
+                Q4_PIECE(xt + (int64_t)(kn_ / KT2) * RT2 * dpad, kn_ % KT2, (t + 3) & (NB - 1), 2 * (sq_ - 2) + (i_ == 13)); \
+            }                                                                                                              \
+        }                                                                                                                  \
+        if (sq_ == 1) {                                                                                                    \
+            /* stage t + 1 has landed (this wave's pieces: at most the four of stage t + 2 may still be in flight; younger */ \
+            /* appends only make the wait longer), then the rendezvous: everybody's pieces, and everybody is done with stage t - 1 */ \
+            if (t + 2 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                            \
+            else               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
+            __builtin_amdgcn_s_barrier();                                                                                  \
+        }                                                                                                                  \
+    } while (0)
+
+    // the first step's fragments (slot 0)
+    if (ntile > 0) {
+        Q4_LOADA(0, 0, 0); Q4_LOADA(0, 0, 1); Q4_LOADA(0, 0, 2); Q4_LOADA(0, 0, 3);
+    }
+    // (stages written out with literal indices: fragment homes and offsets are template / immediate operands)
+#define Q4_STAGE(K)                                                                                                        \
+    do {                                                                                                                   \
+        const int t = jl * KT2 + (K);                                                                                      \
+        const bool more = t + 3 < total;                                                                                   \
+        Q4_STEP(4 * (K) + 0);                                                                                              \
+        if ((K) == 0 && any) maintain();                                                                                   \
+        Q4_STEP(4 * (K) + 1);                                                                                              \
+        Q4_STEP(4 * (K) + 2);                                                                                              \
+        Q4_STEP(4 * (K) + 3);                                                                                              \
+    } while (0)
+    for (int jl = 0; jl < ntile; ++jl) {
+        const float *xt = xbase + (int64_t)jl * RT2 * dpad;
+        const bool do_filter = filter_on && jl > 0;
+        const unsigned jprev = (unsigned)(t_begin + jl - 1) * RT2;
+        bool any = false;
+        Q4_STAGE(0); Q4_STAGE(1); Q4_STAGE(2); Q4_STAGE(3);
+        if constexpr (KT2 > 4) { Q4_STAGE(4); Q4_STAGE(5); }
+        static_assert(KT2 == 4 || KT2 == 6, "stages per tile written out for d = 512 and d = 768");
+    }
+#undef Q4_STAGE
+    Q4_WAIT(0);                                 // (the reads the last step issued for a tile that does not exist: retired, unused)
+#undef Q4_STEP
+#undef Q4_MF
+#undef Q4_WAIT
+#undef Q4_LOADP
+#undef Q4_LOADA
+#undef Q4_PIECE
+    // ---- the last tile of the launch: its filter has no next tile to ride on ----
+    if (ntile > 0 && filter_on) {
+        const unsigned jt = (unsigned)(t_end - 1) * RT2;
+        if ((unsigned)t_end * RT2 > (unsigned)p.b.n) {
+            // last tile of the database: its padding rows must never pass.  One more MFMA per accumulator tile: A' = -inf in
+            // k-slot 0 of the padding rows (0 elsewhere), B' = 1 in k-slot 0 -> padding rows' scores become -inf, valid rows' + 0
+            typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+            u16x8 ones = {}, mk0 = {}, mk1 = {}, mk2 = {}, mk3 = {};
+            ones[0] = g4 == 0 ? (unsigned short)0x3c00u : (unsigned short)0;
+            mk0[0] = (g4 == 0 && jt + (unsigned)l15 >= (unsigned)p.b.n) ? (unsigned short)0xfc00u : (unsigned short)0;
+            mk1[0] = (g4 == 0 && jt + 16u + (unsigned)l15 >= (unsigned)p.b.n) ? (unsigned short)0xfc00u : (unsigned short)0;
+            mk2[0] = (g4 == 0 && jt + 32u + (unsigned)l15 >= (unsigned)p.b.n) ? (unsigned short)0xfc00u : (unsigned short)0;
+            mk3[0] = (g4 == 0 && jt + 48u + (unsigned)l15 >= (unsigned)p.b.n) ? (unsigned short)0xfc00u : (unsigned short)0;
+            bf16x8 b1 = __builtin_bit_cast(bf16x8, ones), a0 = __builtin_bit_cast(bf16x8, mk0), a1 = __builtin_bit_cast(bf16x8, mk1);
+            bf16x8 a2 = __builtin_bit_cast(bf16x8, mk2), a3 = __builtin_bit_cast(bf16x8, mk3);
+            // (VALU -> asm MFMA: hipcc pads nothing in front of an asm statement)
+            asm volatile("s_nop 4" : "+v"(b1), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                mfma16<false, false>(acc[0][b], a0, b1); mfma16<false, false>(acc[1][b], a1, b1);
+                mfma16<false, false>(acc[2][b], a2, b1); mfma16<false, false>(acc[3][b], a3, b1);
+            }
+        }
+        // MFMA results are read by VALU next: wait out the matrix pipe (hipcc pads nothing around asm)
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]));
+        asm volatile("" : "+v"(acc[0][1]), "+v"(acc[1][1]), "+v"(acc[2][1]), "+v"(acc[3][1]));
+        asm volatile("" : "+v"(acc[0][2]), "+v"(acc[1][2]), "+v"(acc[2][2]), "+v"(acc[3][2]));
+        asm volatile("" : "+v"(acc[0][3]), "+v"(acc[1][3]), "+v"(acc[2][3]), "+v"(acc[3][3]));
+        bool any = false;
+        Q4_FILTER(0, jt); Q4_FILTER(1, jt); Q4_FILTER(2, jt); Q4_FILTER(3, jt);
+        if (any) maintain();
+    }
+#undef Q4_FILTER
+#undef Q4_SEL
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!final_pass) {      // park the lane-private state for the next database chunk
+        float *st = p.state + 16 * ((int64_t)blockIdx.x * NT + tid);
+        st[0] = __int_as_float(ccnt0); st[1] = __int_as_float(clast0); st[2] = thk0;
+        st[4] = __int_as_float(ccnt1); st[5] = __int_as_float(clast1); st[6] = thk1;
+        st[8] = __int_as_float(ccnt2); st[9] = __int_as_float(clast2); st[10] = thk2;
+        st[12] = __int_as_float(ccnt3); st[13] = __int_as_float(clast3); st[14] = thk3;
+        return;
+    }
+    // ---- end of the scan: counts for k_bf16_final (exact re-scoring + exact top-k, one wave per query) ----
+    int *cn = p.cnt + 4 * ((int64_t)blockIdx.x * BQ2 + qrow0) + g4;
+    cn[0] = ccnt0; cn[4 * 16] = ccnt1; cn[4 * 32] = ccnt2; cn[4 * 48] = ccnt3;
+}
+
+// ======================================================================================
 // Final pass of the Q-stationary scans: exact fp32-chain re-scoring of every surviving candidate + exact top-k.
 //
 // Inside the scan kernel this ran with ONE wave per SIMD, one lane per candidate row, every lane walking its own 3 KB row
@@ -1178,8 +1673,9 @@ constexpr int FIN_PITCH = 36;      // floats per transposed row (conflict-free 1
 struct FinalParams {
     ScanParams b;              // D / I / part / nq / kk / metric / splits / nq_pad / xnorm / qnorm / cand
     const float *q, *x;        // originals, row-major [nq, d], [n, d]
-    const int *cnt;            // [lists][2]
+    const int *cnt;            // [lists][segs]
     int d, rows_per_wg;        // queries per scan workgroup (128 / 256)
+    int segs;                  // lane lists per query: 2 halves of 256 (QS, QS2) or 4 quarters of 128 (QS4)
     int64_t n_lists;
 };
 
@@ -1266,7 +1762,10 @@ __global__ __launch_bounds__(256) void k_bf16_final(FinalParams p) {
     const int64_t q = panel * p.rows_per_wg + row;
     if (q >= p.b.nq) return;
     const u64 *list = p.b.cand + L * CAPH;
-    const int n0 = p.cnt[2 * L], n1 = p.cnt[2 * L + 1];
+    // the query's lane lists read as one: segment s holds cnt[s] keys at list[s * CAPH / segs ...]; p1..p3 = prefix counts
+    const int segs = p.segs, seg_cap = CAPH / segs;
+    const int p1 = p.cnt[segs * L], p2 = p1 + p.cnt[segs * L + 1];
+    const int p3 = segs > 2 ? p2 + p.cnt[segs * L + 2] : p2, c = segs > 2 ? p3 + p.cnt[segs * L + 3] : p2;
     const int kk = p.b.kk, d = p.d;
     const float *qrow = p.q + q * (int64_t)d;
     const float qn = l2 ? p.b.qnorm[q] : 0.0f;
@@ -1276,12 +1775,13 @@ __global__ __launch_bounds__(256) void k_bf16_final(FinalParams p) {
         __builtin_amdgcn_wave_barrier();
     }
     u64 best = 0;                                         // lane i: i-th best exact key so far
-    const int c = n0 + n1;
 #pragma unroll 1
     for (int base = 0; base < c; base += 64) {
         const int e = base + lane;
         const bool valid = e < c;
-        const u64 old = valid ? list[e < n0 ? e : CAPH / 2 + (e - n0)] : 0;
+        const int seg = (e >= p1) + (segs > 2 ? (e >= p2) + (e >= p3) : 0);
+        const int sbase = seg == 0 ? 0 : seg == 1 ? p1 : seg == 2 ? p2 : p3;
+        const u64 old = valid ? list[seg * seg_cap + (e - sbase)] : 0;
         const u32 j = valid ? lemon_key_index(old) : 0u;   // idle lanes shadow row 0 (always allocated)
         const float *xrow = p.x + (int64_t)j * d;
         float dot;
@@ -1380,6 +1880,22 @@ static void launch_qs2(int kt, unsigned grid, hipStream_t stream, const ScanPara
     }
 }
 
+// QS4 = the QS2 work decomposition on v_mfma_f32_16x16x32_f16 (round 5); LEMON_QS4=0 selects QS2 (A/B aid)
+static bool use_qs4() {
+    const char *e = getenv("LEMON_QS4");
+    return !(e && e[0] == '0');
+}
+
+// (the L2 epilogue's |x|^2 loads and |q|^2 registers do not fit next to d = 768's fragments -- 14 spilled registers with 20 parked
+// steps, and 21 is what the LDS holds --, so squared-L2 at pitch 768 stays on QS2)
+static bool qs4_serves(int kt, bool l2) { return kt == 8 || !l2; }
+
+template <bool l2>
+static void launch_qs4(int kt, unsigned grid, hipStream_t stream, const ScanParamsH &p) {
+    if (kt == 8) hipLaunchKernelGGL((k_scan_f16_qs4<8, 0, l2>), dim3(grid), dim3(NT), 0, stream, p);
+    else if (!l2) hipLaunchKernelGGL((k_scan_f16_qs4<12, 16, false>), dim3(grid), dim3(NT), 0, stream, p);
+}
+
 int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k, float *D_dev,
                       int64_t *I_dev, hipStream_t stream) {
     const int d = idx->d;
@@ -1405,6 +1921,7 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
     for (int64_t c0 = 0; c0 < nq; c0 += cn) {
         cn = (nq - c0) < QCHUNK_H ? (nq - c0) : QCHUNK_H;
         const bool qs2 = qs && use_qs2() && dpad_h >= 512 && cn >= (int64_t)qs2_min * BQ2;
+        const bool qs4 = qs2 && use_qs4() && qs4_serves(dpad_h / BKH, idx->metric == LEMON_METRIC_L2);
         if (qs2 && cn < QCHUNK_H) {
             // Whole rounds first.  The chunked scan runs ONE workgroup per CU, all of equal length: 1 859 workgroups take
             // eight rounds of 256 like 2 048 do (1 M queries = 2 048 + 1 859 panels: 4.6 % of the scan spent in a quarter-full
@@ -1460,8 +1977,8 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
             if (chunk_tiles > n_tiles) chunk_tiles = n_tiles;
         }
         // per-lane state carried between chunk launches (splits == 1) + the half-list counts handed to k_bf16_final
-        const int64_t state_elems = (qs && splits == 1) ? (int64_t)grid * NT * (qs2 ? 8 : 4) : 0;
-        const int64_t cnt_elems = qs ? (int64_t)grid * bqw * 2 : 0;
+        const int64_t state_elems = (qs && splits == 1) ? (int64_t)grid * NT * (qs4 ? 16 : qs2 ? 8 : 4) : 0;
+        const int64_t cnt_elems = qs ? (int64_t)grid * bqw * (qs4 ? 4 : 2) : 0;
         if (state_elems + cnt_elems > idx->ws_state_elems) {
             LEMON_HIP_CHECK(hipStreamSynchronize(stream));
             if (idx->ws_state) (void)hipFree(idx->ws_state);
@@ -1476,7 +1993,7 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
         p.cnt = reinterpret_cast<int *>(idx->ws_state + state_elems);
         const bool l2m_ = idx->metric == LEMON_METRIC_L2;
         FinalParams fp;
-        fp.b = p.b; fp.q = p.q; fp.x = p.x; fp.cnt = p.cnt; fp.d = d; fp.rows_per_wg = bqw; fp.n_lists = (int64_t)grid * bqw;
+        fp.b = p.b; fp.q = p.q; fp.x = p.x; fp.cnt = p.cnt; fp.d = d; fp.rows_per_wg = bqw; fp.segs = qs4 ? 4 : 2; fp.n_lists = (int64_t)grid * bqw;
         auto launch_final = [&]() {     // exact re-scoring + exact top-k of every (query, split) list, one wave each
             const unsigned fg = (unsigned)((fp.n_lists + 3) / 4);
             const bool staged = (d % 4) == 0 && d <= 1024;
@@ -1494,6 +2011,12 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
             const double flops = 2.0 * (double)cn * rows * (double)d;
             const double bytes = 2.0 * d * ((double)nq_pad / BQ * rows) + (p.last_chunk ? 2.0 * d * cn + 12.0 * k * (double)cn : 0.0);
             LemonProfScope prof(idx, stream, flops, bytes);
+            if (qs4) {
+                if (l2m) launch_qs4<true>(dpad_h / BKH, grid, stream, p);
+                else     launch_qs4<false>(dpad_h / BKH, grid, stream, p);
+                if (p.last_chunk) launch_final();
+                continue;
+            }
             if (qs && dpad_h / BKH == 12 && !l2m && getenv("LEMON_PHASE_PROF")) {   // diagnostic build: phase cycle sums
                 static unsigned long long *dbg = nullptr;
                 if (!dbg) { (void)hipMalloc(&dbg, 64); (void)hipMemset(dbg, 0, 64); }

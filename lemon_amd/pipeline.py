@@ -103,11 +103,11 @@ class Embedder:
     Range fallback.  The default GEMM mode (LEMON_GEMM=f16x3) carries the fp32 operands of the block GEMMs (and q, k, v of
     the attention kernels) as fp16 pairs: a value beyond +-65 504 turns into inf / NaN there instead of being clamped.  Every
     micro-batch leaves a device flag "not finite"; the flags of one embed_images / embed_texts call are read with ONE host
-    transfer after all its micro-batches are queued, and a flagged micro-batch is embedded again with the range-free scheme
-    (3-way bf16 split GEMMs, fp32 attention: the same fp32-equivalent contract) -- counted in `fallback_batches`, reported by
-    the CLI.  The same path catches the folded LayerNorm's bound (ops.ln_fold_enabled): a row whose mean lies more than
+    transfer after all its micro-batches are queued, and the non-finite SAMPLES of a flagged micro-batch (samples are
+    independent) are gathered and embedded again with the range-free scheme (3-way bf16 split GEMMs, fp32 attention: the same
+    fp32-equivalent contract) -- counted in `fallback_rows` / `fallback_batches`, reported by the CLI and by bench.py's JSON line.  The same path catches the folded LayerNorm's bound (ops.ln_fold_enabled): a row whose mean lies more than
     ops.LN_FOLD_MAX_SHIFT standard deviations from 0 is given a NaN row affine by the kernels, so its micro-batch is flagged
-    and re-embedded here -- first with the same f16x3 arithmetic and LayerNorm kernels (`fold_fallback_batches`), and only if it
+    and its poisoned samples are re-embedded here -- first with the same f16x3 arithmetic and LayerNorm kernels (`fold_fallback_rows`), and only if it
     is still not finite with the range-free scheme.  What is still not finite after that is not a range problem and raises in raise_if_nonfinite()."""
 
     def __init__(self, model, device, batch_size=128, dtype=torch.float32, text_dedup=False, text_batch_size=None, range_fallback=True):
@@ -118,8 +118,10 @@ class Embedder:
         self.text_batch_size = text_batch_size or 4 * batch_size
         self._nonfinite = None        # device flag: some embedding so far was not finite (raise_if_nonfinite)
         self.range_fallback = range_fallback
-        self.fallback_batches = 0     # micro-batches re-embedded with bf16x6 operands because fp16 overflowed
-        self.fold_fallback_batches = 0    # micro-batches re-embedded with LayerNorm kernels because a row's mean was beyond the fold's bound
+        self.fallback_batches = 0     # micro-batches that held a sample re-embedded with bf16x6 operands because fp16 overflowed
+        self.fold_fallback_batches = 0    # ... with LayerNorm kernels because a row's mean was beyond the fold's bound
+        self.fallback_rows = 0        # the samples themselves (only they are embedded again, in sub-batches)
+        self.fold_fallback_rows = 0
 
     def _note(self, e):
         if e.is_cuda and e.shape[0]:
@@ -137,26 +139,49 @@ class Embedder:
                    else "also with range-free operands (bf16x6 GEMMs, fp32 attention): the weights or inputs themselves produce inf / NaN")
             raise FloatingPointError(f"non-finite embeddings (LEMON_GEMM={ops.gemm_mode()}): {how}")
 
-    def _run_batches(self, spans, run_one):
-        """[run_one(lo, hi) for the spans], with the fp16-range fallback of the class docstring."""
-        outs = [run_one(lo, hi).float() for lo, hi in spans]
-        if outs and outs[0].is_cuda and self.range_fallback and ops.gemm_mode() == "f16x3":
-            bad = torch.stack([~torch.isfinite(e).all() for e in outs]).cpu()          # the call's one host read
-            flagged = bad.nonzero().flatten().tolist()
-            if flagged and ops.ln_fold_enabled() and ops.mlp_mode() == "block":
-                # first the cheap cause: a row beyond the folded LayerNorm's mean bound (NaN row affine) -- the same arithmetic with
-                # LayerNorm kernels; what is still not finite after that (one more host read, only on this path) left the fp16 range
-                with ops.ln_fold_forced(False):
-                    for j in flagged:
-                        outs[j] = run_one(*spans[j]).float()
-                still = torch.stack([~torch.isfinite(outs[j]).all() for j in flagged]).cpu().tolist()
-                self.fold_fallback_batches += sum(1 for s_ in still if not s_)
-                flagged = [j for j, s_ in zip(flagged, still) if s_]
-            for j in flagged:
-                with ops.gemm_mode_forced("bf16x6"):
-                    outs[j] = run_one(*spans[j]).float()
-                self.fallback_batches += 1
-        return outs
+    def _run_batches(self, n, bs, run):
+        """torch.cat of run(slice) over the micro-batches of n samples, with the fallback of the class docstring.  `run(sel)` embeds
+        the samples `sel` selects (a slice, or a LongTensor of sample indices).  Samples are independent, so what is embedded again
+        is the flagged SAMPLES (gathered into sub-batches of at most bs), not their micro-batches: one poisoned image costs one
+        image's work, not 5 240."""
+        spans = [(i, min(n, i + bs)) for i in range(0, n, bs)]
+        outs = [run(slice(lo, hi)).float() for lo, hi in spans]
+        if not outs:
+            return None
+        if not (outs[0].is_cuda and self.range_fallback and ops.gemm_mode() == "f16x3"):
+            return torch.cat(outs)
+        rowbad = [~torch.isfinite(e).all(dim=1) for e in outs]
+        bad = torch.stack([r.any() for r in rowbad]).cpu()                  # the call's one host read
+        flagged = bad.nonzero().flatten().tolist()
+        e = torch.cat(outs)
+        if not flagged:
+            return e
+        # (second host read, only on this path: which samples)
+        idx = torch.cat([spans[j][0] + rowbad[j].nonzero().flatten() for j in flagged]).cpu()
+
+        def redo(rows):
+            return torch.cat([run(rows[i:i + bs]).float() for i in range(0, rows.numel(), bs)])
+
+        def batches_of(rows):
+            return int(torch.unique(rows // bs).numel())
+
+        if ops.ln_fold_enabled() and ops.mlp_mode() == "block":
+            # first the cheap cause: a row beyond the folded LayerNorm's mean bound (NaN row affine) -- the same arithmetic with
+            # LayerNorm kernels; what is still not finite after that (one more host read) left the fp16 range
+            with ops.ln_fold_forced(False):
+                new = redo(idx)
+            ok = torch.isfinite(new).all(dim=1).cpu()
+            if bool(ok.any()):
+                e[idx[ok].to(e.device)] = new[ok.to(new.device)]
+                self.fold_fallback_rows += int(ok.sum())
+                self.fold_fallback_batches += batches_of(idx[ok])
+            idx = idx[~ok]
+        if idx.numel():
+            with ops.gemm_mode_forced("bf16x6"):
+                e[idx.to(e.device)] = redo(idx)
+            self.fallback_rows += int(idx.numel())
+            self.fallback_batches += batches_of(idx)
+        return e
 
     @torch.no_grad()
     def embed_images(self, pixel_values):
@@ -166,8 +191,8 @@ class Embedder:
         if raw:
             from .data import gpu_transform_batch, patch_operand_supported
 
-        def one(lo, hi):
-            px = pixel_values[lo:hi].to(self.device, non_blocking=True)
+        def one(sel):
+            px = pixel_values[sel if isinstance(sel, slice) else sel.to(pixel_values.device)].to(self.device, non_blocking=True)
             if raw:
                 # f16x3 with the hand-written GEMM: the transform writes the patch-embedding GEMM's operand itself
                 cfg = self.model.cfg
@@ -177,9 +202,9 @@ class Embedder:
                 px = gpu_transform_batch(px, cfg.image_size, patch=cfg.patch_size, operand=operand)
             return self.model.encode_image(px)
 
-        n = pixel_values.shape[0]
-        outs = self._run_batches([(i, min(n, i + self.batch_size)) for i in range(0, n, self.batch_size)], one)
-        e = torch.cat(outs) if outs else torch.empty((0, self.model.cfg.embed_dim), device=self.device)
+        e = self._run_batches(pixel_values.shape[0], self.batch_size, one)
+        if e is None:
+            e = torch.empty((0, self.model.cfg.embed_dim), device=self.device)
         return ops.normalize_vectors(self._note(e)) if e.shape[0] else e              # :164 / :233
 
     @torch.no_grad()
@@ -203,13 +228,13 @@ class Embedder:
             eot = ids.argmax(dim=-1).cpu()
         bucketed = eot is not None and hasattr(tower, "seq_len_for")
 
-        def one(lo, hi):
+        def one(sel):
+            rows = ids[sel if isinstance(sel, slice) else sel.to(ids.device)]
             if bucketed:
-                return self.model.encode_text(ids[lo:hi], seq_len=tower.seq_len_for(int(eot[lo:hi].max())))
-            return self.model.encode_text(ids[lo:hi])
+                return self.model.encode_text(rows, seq_len=tower.seq_len_for(int(eot[sel].max())))
+            return self.model.encode_text(rows)
 
-        n, tb = ids.shape[0], self.text_batch_size
-        return torch.cat(self._run_batches([(i, min(n, i + tb)) for i in range(0, n, tb)], one))
+        return self._run_batches(ids.shape[0], self.text_batch_size, one)
 
 
 def score_splits(db, splits, k, hparams=None, discrete=False):

@@ -11,6 +11,8 @@ TEST INFRASTRUCTURE ONLY (oracle/): used by tests/ and by bench.py's cpu_baselin
                           and cross-modal distances (:264-273, :284-289), the sign quirk (:269-270, :285-286), one dict per
                           sample (:291-307)
   vectorised              the same arithmetic for a whole split in numpy (what a CPU user would write instead of the loop)
+  adjudicate_near_ties    for the queries on which two float32 searches return different neighbour SETS: the float64 scores of
+                          the rows in dispute, which side holds the float64-exact set, and how far apart the swapped rows are
 """
 import numpy as np
 import torch
@@ -120,3 +122,40 @@ def vectorised(sname, img_q, txt_q, emb_img_tr, emb_txt_tr, dists_tr, index_img,
 
 def stack(logs, key):
     return np.stack([np.asarray(l[key]) for l in logs])
+
+
+def adjudicate_near_ties(q, x, I_a, I_b, metric="cosine", exclude=None):
+    """Two exact float32 searches of the same queries (I_a, I_b: int [nq, k] neighbour indices, any order) can disagree where
+    the k-th and (k+1)-th scores are closer than float32 summation noise (hard part 2: the GPU scan sums in chain
+    order, torch.mm in blocked order).  For every query whose two SETS differ this computes, in float64 over the WHOLE database,
+    the exact top-k set (ties to the lower index; `exclude[i]` = a row to leave out, the self match of a train query, or -1) and
+      gap = max - min float64 score over the symmetric difference of the two sets: how far apart the rows in dispute are.
+    Returns {rows, rows_differing, rows_a_equals_f64_set, rows_b_equals_f64_set (both over ALL rows, identical rows counted as
+    agreeing with float64 only if they do), max_gap_at_swap, worst_row}."""
+    q = np.asarray(q, dtype=np.float64); x = np.asarray(x, dtype=np.float64)
+    Sa, Sb = np.sort(np.asarray(I_a), 1), np.sort(np.asarray(I_b), 1)
+    nq, k = Sa.shape
+    differ = np.nonzero((Sa != Sb).any(1))[0]
+    a_ok = b_ok = nq - len(differ)          # rows on which both agree: checked against float64 below as well
+    max_gap, worst = 0.0, -1
+    check = list(differ)
+    # a sample of the agreeing rows too (all of them when there are few): agreement of two float32 searches is not proof
+    agree = np.setdiff1d(np.arange(nq), differ)
+    check_agree = agree[:: max(1, len(agree) // 256)]
+    for i in list(differ) + list(check_agree):
+        s = x @ q[i] if metric == "cosine" else -((x - q[i][None, :]) ** 2).sum(1)
+        if exclude is not None and exclude[i] >= 0:
+            s[exclude[i]] = -np.inf
+        order = np.lexsort((np.arange(len(s)), -s))[:k]          # score descending, index ascending
+        exact = np.sort(order)
+        if i in check_agree and not (Sa[i] != Sb[i]).any():
+            if not np.array_equal(exact, Sa[i]):
+                a_ok -= 1; b_ok -= 1
+            continue
+        a_ok += int(np.array_equal(exact, Sa[i])); b_ok += int(np.array_equal(exact, Sb[i]))
+        sym = np.setxor1d(Sa[i], Sb[i])
+        gap = float(s[sym].max() - s[sym].min())
+        if gap > max_gap:
+            max_gap, worst = gap, int(i)
+    return {"rows": int(nq), "rows_differing": int(len(differ)), "rows_a_equals_f64_set": a_ok / nq, "rows_b_equals_f64_set": b_ok / nq,
+            "max_gap_at_swap": max_gap, "worst_row": worst, "agreeing_rows_checked_against_f64": int(len(check_agree))}
