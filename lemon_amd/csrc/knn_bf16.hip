@@ -107,13 +107,16 @@ struct ScanParamsH {
 };
 
 // proven bound on |s~ - s| for one query (see file header); for L2 the bound on the key -D
-__device__ __forceinline__ float band_eps(const ScanParamsH &p, float qn, float qres2, bool l2) {
-    const float xn2 = __uint_as_float(p.xstat[0]), xr2 = __uint_as_float(p.xstat[1]), xh2 = __uint_as_float(p.xstat[2]);
+__device__ __forceinline__ float band_eps_raw(const unsigned *__restrict__ xstat, int d, float qn, float qres2, bool l2) {
+    const float xn2 = __uint_as_float(xstat[0]), xr2 = __uint_as_float(xstat[1]), xh2 = __uint_as_float(xstat[2]);
     const float nq = sqrtf(qn) * 1.0005f;
     float eps = (nq * sqrtf(xr2) + sqrtf(qres2) * sqrtf(xh2)) * 1.002f
-              + 3.0f * (float)p.d * 5.9604645e-8f * nq * sqrtf(xn2) * 1.002f + 1e-30f;
+              + 3.0f * (float)d * 5.9604645e-8f * nq * sqrtf(xn2) * 1.002f + 1e-30f;
     if (l2) eps = 2.0f * eps + 4.8e-7f * (qn + xn2);
     return eps;
+}
+__device__ __forceinline__ float band_eps(const ScanParamsH &p, float qn, float qres2, bool l2) {
+    return band_eps_raw(p.xstat, p.d, qn, qres2, l2);
 }
 
 // exact score of the numeric contract for (query row, db row j); key to MAXIMISE
@@ -1212,12 +1215,10 @@ __device__ __forceinline__ unsigned append_slot4(int cnt) {      // (see append_
     return (unsigned)cnt < (unsigned)(QCAP4 - 1) ? (unsigned)cnt : (unsigned)(QCAP4 - 1);
 }
 
-// the lane's sixteen scores of one query group: c<a>[i] = s~(row jb + 16 a + i, the lane's query of the group).  Returns whether
-// any lane of the wave appended (wave-uniform).
+// the lane's sixteen scores of one query group: c<a>[i] = s~(row jb + 16 a + i, the lane's query of the group).
+// qs4_group_max: (L2: the scores become the monotone proxy of the key in place, then) their maximum -- eight v_max3_f32.
 template <bool l2>
-__device__ __forceinline__ bool qs4_filter_group(f32x4 &c0, f32x4 &c1, f32x4 &c2, f32x4 &c3, float th, unsigned jb, float qn,
-                                                 const float *__restrict__ xnorm, int &ccnt, char *__restrict__ panel_bytes,
-                                                 unsigned my_off) {
+__device__ __forceinline__ float qs4_group_max(f32x4 &c0, f32x4 &c1, f32x4 &c2, f32x4 &c3, unsigned jb, const float *__restrict__ xnorm) {
     if (l2) {   // monotone proxy of the key -D: 2 s~ - |x|^2 = key + |q|^2 (th carries the same offset)
         const float4 x0 = *reinterpret_cast<const float4 *>(&xnorm[jb]), x1 = *reinterpret_cast<const float4 *>(&xnorm[jb + 16]);
         const float4 x2 = *reinterpret_cast<const float4 *>(&xnorm[jb + 32]), x3 = *reinterpret_cast<const float4 *>(&xnorm[jb + 48]);
@@ -1226,11 +1227,22 @@ __device__ __forceinline__ bool qs4_filter_group(f32x4 &c0, f32x4 &c1, f32x4 &c2
         c2[0] = __builtin_fmaf(2.0f, c2[0], -x2.x); c2[1] = __builtin_fmaf(2.0f, c2[1], -x2.y); c2[2] = __builtin_fmaf(2.0f, c2[2], -x2.z); c2[3] = __builtin_fmaf(2.0f, c2[3], -x2.w);
         c3[0] = __builtin_fmaf(2.0f, c3[0], -x3.x); c3[1] = __builtin_fmaf(2.0f, c3[1], -x3.y); c3[2] = __builtin_fmaf(2.0f, c3[2], -x3.z); c3[3] = __builtin_fmaf(2.0f, c3[3], -x3.w);
     }
+    // (a tree, not a chain: five independent v_max3 over fifteen values, then two, then one -- three dependent hops instead of eight)
+    const float a0 = max3(c0[0], c0[1], c0[2]), a1 = max3(c0[3], c1[0], c1[1]), a2 = max3(c1[2], c1[3], c2[0]);
+    const float a3 = max3(c2[1], c2[2], c2[3]), a4 = max3(c3[0], c3[1], c3[2]);
+    const float b0 = max3(a0, a1, a2), b1 = max3(a3, a4, c3[3]);
+    return max3(b0, b1, b1);
+}
+// the appends of a group in which some lane's maximum passed (rare: a group sees a survivor in ~7 % of the steady-state tiles):
+// levels of wave ballots + scalar branches, as in qs_filter_tile
+template <bool l2>
+__device__ __forceinline__ void qs4_filter_slow(const f32x4 &c0, const f32x4 &c1, const f32x4 &c2, const f32x4 &c3, float th, unsigned &jb, float qn,
+                                                int &ccnt, char *__restrict__ panel_bytes, unsigned my_off) {
+    // (the row base is made opaque HERE: otherwise hipcc computes the sixteen row numbers of a group in front of the fast path,
+    // every tile, for every group)
+    asm volatile("" : "+v"(jb));
     const float m0 = max3(max3(c0[0], c0[1], c0[2]), c0[3], c0[3]), m1 = max3(max3(c1[0], c1[1], c1[2]), c1[3], c1[3]);
     const float m2 = max3(max3(c2[0], c2[1], c2[2]), c2[3], c2[3]), m3 = max3(max3(c3[0], c3[1], c3[2]), c3[3], c3[3]);
-    const float m = max3(max3(m0, m1, m2), m3, m3);                 // 10 x v_max3_f32, then ONE compare + scalar branch
-    if (__ballot(m > th) == 0) return false;
-    // survivors are rare (a group sees one in ~half of the tiles): levels of wave ballots + scalar branches, as in qs_filter_tile
     const u64 bq[4] = {__ballot(m0 > th), __ballot(m1 > th), __ballot(m2 > th), __ballot(m3 > th)};
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -1243,8 +1255,7 @@ __device__ __forceinline__ bool qs4_filter_group(f32x4 &c0, f32x4 &c1, f32x4 &c2
             for (int i = 0; i < 4; ++i) {
                 if (be[i]) {                            // scalar branch
                     if (c[i] > th) {                    // (rows >= n: -inf by the caller's masking MFMAs, last tile only)
-                        unsigned j = jb + 16 * a + i;
-                        asm volatile("" : "+v"(j));     // (opaque: no strength-reduced `~j` key words carried around the loop)
+                        const unsigned j = jb + 16 * a + i;
                         const float sc = l2 ? fminf(0.0f, c[i] - qn) : c[i];
                         *reinterpret_cast<u64 *>(panel_bytes + (my_off + 8u * append_slot4(ccnt))) = lemon_make_key(sc, j);
                         ++ccnt;
@@ -1253,7 +1264,6 @@ __device__ __forceinline__ bool qs4_filter_group(f32x4 &c0, f32x4 &c1, f32x4 &c2
             }
         }
     }
-    return true;
 }
 
 // entry e of a query's four quarter-lists read as ONE list of n0 + n1 + n2 + n3 keys (p1 = n0, p2 = n0 + n1, p3 = p2 + n2)
@@ -1345,6 +1355,13 @@ __device__ __forceinline__ int qs4_compact_exact(const ScanParamsH &p, u64 *__re
 
 template <int KT, int PARK, bool l2>
 __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
+    // issue slots (MFMA index of a step behind which something else is issued): the five fragment reads of the next step behind
+    // MFMAs RD0, RD0 + RDS, ...; the two DMA pieces of a step behind MFMAs DM0 and DM1
+#ifndef LEMON_QS4_SLOTS
+    constexpr int RD0 = 0, RDS = 1, DM0 = 8, DM1 = 12;
+#else
+    constexpr int RD0 = (LEMON_QS4_SLOTS) / 1000 % 10, RDS = (LEMON_QS4_SLOTS) / 100 % 10, DM0 = (LEMON_QS4_SLOTS) / 10 % 10 + 6, DM1 = (LEMON_QS4_SLOTS) % 10 + 6;
+#endif
     constexpr int NS = 2 * KT;                 // k32 steps per tile
     constexpr int KT2 = KT / 2;                // stages per tile: 2 x 64-wide k-slices = 4 k32 steps each
     constexpr int NFR = 4 * NS - PARK;         // query fragments in registers: index f = b NS + s
@@ -1465,7 +1482,8 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
     for (int u = 0; u < 2; ++u) { fP[u] = bf16x8{}; for (int a = 0; a < 4; ++a) fA[u][a] = bf16x8{}; }
     unsigned va0 = fa0, va1 = fa1;              // fragment addresses inside the ring slot being read (slot 0 first)
     const bool filter_on = !(p.ablate & 1);
-    const bool nothing_passes = (p.ablate & 4) != 0;
+    if (p.ablate & 4) th0 = th1 = th2 = th3 = INFINITY;      // (diagnostic, results invalid: nothing passes the filter, so nothing re-arms it)
+    const int lim4 = (p.b.stale + 3) >> 2;                   // a lane's share of `stale` new candidates per query
 
     // one database fragment of k32 step S (of the tile) into set U: address base VA0 / VA1 = the stage's slot
 #define Q4_LOADA(U, S, a_)                                                                                                 \
@@ -1484,22 +1502,13 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
 
     // ---- maintenance: light compaction of the queries whose lists need it (all four groups; b, c wave-uniform) ----
 #define Q4_SEL(b_, x0, x1, x2, x3) ((b_) == 0 ? (x0) : (b_) == 1 ? (x1) : (b_) == 2 ? (x2) : (x3))
-    auto maintain = [&]() {
-        u64 todo = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int cc = Q4_SEL(b, ccnt0, ccnt1, ccnt2, ccnt3), cl = Q4_SEL(b, clast0, clast1, clast2, clast3);
-            const float tk = Q4_SEL(b, thk0, thk1, thk2, thk3);
-            int tot = cc + __shfl_xor(cc, 16);
-            tot += __shfl_xor(tot, 32);
-            const bool warm = tk == -INFINITY && tot >= p.b.kk;
-            const bool stale = tot >= p.b.kk && tot - cl >= p.b.stale;
-            const bool full = cc > QCAP4 - 16;            // my quarter could overflow on the next tile (<= 16 appends)
-            u64 m = __ballot(((qvalid >> b) & 1u) && (warm || stale || full));
-            m = (m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffull;       // one bit per query of the group
-            todo |= m << (16 * b);
-        }
-        if (!todo) return;
+    // `todo`: bit 16 b + c = query c of group b asked for it (Q4_SLOW, right behind the appends that brought it there).  The
+    // triggers are PER LANE -- my quarter grew by a quarter of `stale` since the last compaction, or is within one tile of its
+    // capacity, or holds a first tile's worth while the query has no bound yet -- so that a tile with appends costs no cross-lane
+    // traffic at all (round-5 measurement: with the four-lane sums of QS2's rule made after every tile that appended anything, the
+    // appends + compactions + the barrier skew they cause took 15 % of the 1 M x 768 scan, against 10 % in QS2; any compaction
+    // cadence gives the same bits, the final selection is exact)
+    auto maintain = [&](u64 todo) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's appends are visible
         do {
             const int r = __ffsll((long long)todo) - 1;     // = 16 b + c: the query's row inside the wave's 64
@@ -1510,6 +1519,7 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
             const int cc = Q4_SEL(b, ccnt0, ccnt1, ccnt2, ccnt3);
             const int n0 = __builtin_amdgcn_readlane(cc, c), n1 = __builtin_amdgcn_readlane(cc, c + 16);
             const int n2 = __builtin_amdgcn_readlane(cc, c + 32), n3 = __builtin_amdgcn_readlane(cc, c + 48);
+            if (n0 + n1 + n2 + n3 < p.b.kk) continue;   // (a lane trigger before the query holds kk keys: nothing to select yet)
             float lo;
             int kept = qs4_compact_light(list, n0, n1, n2, n3, p.b.kk, s_eps[row], lane, &lo);
             if (kept > CAPH - 64) {            // the band itself leaves no room for a tile's appends: settle it exactly
@@ -1520,21 +1530,28 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
             }
             const int mine = (kept + 3 - g4) >> 2;        // round-robin deal: quarter g holds entries g, g + 4, ...
             const bool me = l15 == c;
-            if (me && b == 0) { ccnt0 = mine; clast0 = kept; thk0 = lo; th0 = th_of(lo, qn0); }
-            if (me && b == 1) { ccnt1 = mine; clast1 = kept; thk1 = lo; th1 = th_of(lo, qn1); }
-            if (me && b == 2) { ccnt2 = mine; clast2 = kept; thk2 = lo; th2 = th_of(lo, qn2); }
-            if (me && b == 3) { ccnt3 = mine; clast3 = kept; thk3 = lo; th3 = th_of(lo, qn3); }
+            if (me && b == 0) { ccnt0 = mine; clast0 = mine; thk0 = lo; th0 = th_of(lo, qn0); }
+            if (me && b == 1) { ccnt1 = mine; clast1 = mine; thk1 = lo; th1 = th_of(lo, qn1); }
+            if (me && b == 2) { ccnt2 = mine; clast2 = mine; thk2 = lo; th2 = th_of(lo, qn2); }
+            if (me && b == 3) { ccnt3 = mine; clast3 = mine; thk3 = lo; th3 = th_of(lo, qn3); }
         } while (todo);
     };
-    // the filter of query group b_ on the finished tile whose first row is jt_ (wave-uniform `any` |= appended)
-#define Q4_FILTER(b_, jt_)                                                                                                 \
+    // the filter of the finished tile whose first row is jt_, per query group b_: Q4_GMAX = the group's pass mask (a wave ballot of
+    // "my maximum beats my threshold"), Q4_SLOW = its appends when the mask is not empty (wave-uniform `any` |= appended).  In the
+    // loop a group's mask is made one group AHEAD of its branch (compare -> scalar branch is a dependent hop the wave would wait on)
+#define Q4_ACC(b_) acc[0][b_], acc[1][b_], acc[2][b_], acc[3][b_]
+#define Q4_TH(b_) ((b_) == 0 ? th0 : (b_) == 1 ? th1 : (b_) == 2 ? th2 : th3)
+#define Q4_GMAX(b_, jt_) (__ballot(qs4_group_max<l2>(Q4_ACC(b_), (jt_) + 4u * (unsigned)g4, p.b.xnorm) > Q4_TH(b_)))
+#define Q4_NEED(b_, cc_, cl_, tk_) (((qvalid >> (b_)) & 1u) && ((cc_) - (cl_) >= lim4 || (cc_) > QCAP4 - 16 || ((tk_) == -INFINITY && (cc_) >= 16)))
+#define Q4_SLOW(b_, jt_)                                                                                                   \
     do {                                                                                                                   \
-        const unsigned jb_ = (jt_) + 4u * (unsigned)g4;                                                                    \
-        const float tinf_ = INFINITY;                                                                                      \
-        if ((b_) == 0) any |= qs4_filter_group<l2>(acc[0][0], acc[1][0], acc[2][0], acc[3][0], nothing_passes ? tinf_ : th0, jb_, qn0, p.b.xnorm, ccnt0, panel_bytes, my_off0); \
-        if ((b_) == 1) any |= qs4_filter_group<l2>(acc[0][1], acc[1][1], acc[2][1], acc[3][1], nothing_passes ? tinf_ : th1, jb_, qn1, p.b.xnorm, ccnt1, panel_bytes, my_off0 + 16u * CAPH * 8u); \
-        if ((b_) == 2) any |= qs4_filter_group<l2>(acc[0][2], acc[1][2], acc[2][2], acc[3][2], nothing_passes ? tinf_ : th2, jb_, qn2, p.b.xnorm, ccnt2, panel_bytes, my_off0 + 32u * CAPH * 8u); \
-        if ((b_) == 3) any |= qs4_filter_group<l2>(acc[0][3], acc[1][3], acc[2][3], acc[3][3], nothing_passes ? tinf_ : th3, jb_, qn3, p.b.xnorm, ccnt3, panel_bytes, my_off0 + 48u * CAPH * 8u); \
+        unsigned jb_ = (jt_) + 4u * (unsigned)g4;                                                                          \
+        u64 nd_ = 0;                                                                                                       \
+        if ((b_) == 0) { qs4_filter_slow<l2>(Q4_ACC(0), Q4_TH(0), jb_, qn0, ccnt0, panel_bytes, my_off0); nd_ = __ballot(Q4_NEED(0, ccnt0, clast0, thk0)); } \
+        if ((b_) == 1) { qs4_filter_slow<l2>(Q4_ACC(1), Q4_TH(1), jb_, qn1, ccnt1, panel_bytes, my_off0 + 16u * CAPH * 8u); nd_ = __ballot(Q4_NEED(1, ccnt1, clast1, thk1)); } \
+        if ((b_) == 2) { qs4_filter_slow<l2>(Q4_ACC(2), Q4_TH(2), jb_, qn2, ccnt2, panel_bytes, my_off0 + 32u * CAPH * 8u); nd_ = __ballot(Q4_NEED(2, ccnt2, clast2, thk2)); } \
+        if ((b_) == 3) { qs4_filter_slow<l2>(Q4_ACC(3), Q4_TH(3), jb_, qn3, ccnt3, panel_bytes, my_off0 + 48u * CAPH * 8u); nd_ = __ballot(Q4_NEED(3, ccnt3, clast3, thk3)); } \
+        todo |= ((nd_ | (nd_ >> 16) | (nd_ >> 32) | (nd_ >> 48)) & 0xffffull) << (16 * (b_));                              \
     } while (0)
 
     // k32 step S (compile-time) of the tile on fragment set S & 1.  In the gaps between its MFMAs: the reads of step S + 1
@@ -1550,8 +1567,10 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
         }                                                                                                                  \
         _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                                                                \
             if ((S) == 0 && (i_ & 3) == 0 && do_filter) {                                                                  \
-                if (i_ == 0) Q4_FILTER(0, jprev); if (i_ == 4) Q4_FILTER(1, jprev);                                        \
-                if (i_ == 8) Q4_FILTER(2, jprev); if (i_ == 12) Q4_FILTER(3, jprev);                                       \
+                if (i_ == 0)  { pm0 = Q4_GMAX(0, jprev); pm1 = Q4_GMAX(1, jprev); if (pm0) Q4_SLOW(0, jprev); }            \
+                if (i_ == 4)  { pm2 = Q4_GMAX(2, jprev); if (pm1) Q4_SLOW(1, jprev); }                                     \
+                if (i_ == 8)  { pm3 = Q4_GMAX(3, jprev); if (pm2) Q4_SLOW(2, jprev); }                                     \
+                if (i_ == 12) { if (pm3) Q4_SLOW(3, jprev); }                                                              \
             }                                                                                                              \
             switch (i_) {                                                                                                  \
                 case 0: Q4_MF(U_, S, 0); break; case 1: Q4_MF(U_, S, 1); break; case 2: Q4_MF(U_, S, 2); break; case 3: Q4_MF(U_, S, 3); break; \
@@ -1559,14 +1578,14 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
                 case 8: Q4_MF(U_, S, 8); break; case 9: Q4_MF(U_, S, 9); break; case 10: Q4_MF(U_, S, 10); break; case 11: Q4_MF(U_, S, 11); break; \
                 case 12: Q4_MF(U_, S, 12); break; case 13: Q4_MF(U_, S, 13); break; case 14: Q4_MF(U_, S, 14); break; default: Q4_MF(U_, S, 15); break; \
             }                                                                                                              \
-            if (i_ == 1) Q4_LOADA(U_ ^ 1, N_, 0);                                                                          \
-            if (i_ == 3) Q4_LOADA(U_ ^ 1, N_, 1);                                                                          \
-            if (i_ == 5) Q4_LOADA(U_ ^ 1, N_, 2);                                                                          \
-            if (i_ == 7) Q4_LOADA(U_ ^ 1, N_, 3);                                                                          \
-            if (i_ == 9) Q4_LOADP(U_ ^ 1, N_);                                                                             \
-            if (sq_ >= 2 && more && (i_ == 11 || i_ == 13)) {                                                              \
+            if (i_ == RD0) Q4_LOADA(U_ ^ 1, N_, 0);                                                                        \
+            if (i_ == RD0 + RDS) Q4_LOADA(U_ ^ 1, N_, 1);                                                                  \
+            if (i_ == RD0 + 2 * RDS) Q4_LOADA(U_ ^ 1, N_, 2);                                                              \
+            if (i_ == RD0 + 3 * RDS) Q4_LOADA(U_ ^ 1, N_, 3);                                                              \
+            if (i_ == RD0 + 4 * RDS) Q4_LOADP(U_ ^ 1, N_);                                                                 \
+            if (sq_ >= 2 && more && (i_ == DM0 || i_ == DM1)) {                                                            \
                 constexpr int kn_ = (S) / 4 + 3;                                                                           \
-                Q4_PIECE(xt + (int64_t)(kn_ / KT2) * RT2 * dpad, kn_ % KT2, (t + 3) & (NB - 1), 2 * (sq_ - 2) + (i_ == 13)); \
+                Q4_PIECE(xt + (int64_t)(kn_ / KT2) * RT2 * dpad, kn_ % KT2, (t + 3) & (NB - 1), 2 * (sq_ - 2) + (i_ == DM1)); \
             }                                                                                                              \
         }                                                                                                                  \
         if (sq_ == 1) {                                                                                                    \
@@ -1588,7 +1607,7 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
         const int t = jl * KT2 + (K);                                                                                      \
         const bool more = t + 3 < total;                                                                                   \
         Q4_STEP(4 * (K) + 0);                                                                                              \
-        if ((K) == 0 && any) maintain();                                                                                   \
+        if ((K) == 0 && todo) maintain(todo);                                                                              \
         Q4_STEP(4 * (K) + 1);                                                                                              \
         Q4_STEP(4 * (K) + 2);                                                                                              \
         Q4_STEP(4 * (K) + 3);                                                                                              \
@@ -1597,7 +1616,8 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
         const float *xt = xbase + (int64_t)jl * RT2 * dpad;
         const bool do_filter = filter_on && jl > 0;
         const unsigned jprev = (unsigned)(t_begin + jl - 1) * RT2;
-        bool any = false;
+        u64 todo = 0;
+        u64 pm0 = 0, pm1 = 0, pm2 = 0, pm3 = 0;
         Q4_STAGE(0); Q4_STAGE(1); Q4_STAGE(2); Q4_STAGE(3);
         if constexpr (KT2 > 4) { Q4_STAGE(4); Q4_STAGE(5); }
         static_assert(KT2 == 4 || KT2 == 6, "stages per tile written out for d = 512 and d = 768");
@@ -1638,11 +1658,18 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
         asm volatile("" : "+v"(acc[0][1]), "+v"(acc[1][1]), "+v"(acc[2][1]), "+v"(acc[3][1]));
         asm volatile("" : "+v"(acc[0][2]), "+v"(acc[1][2]), "+v"(acc[2][2]), "+v"(acc[3][2]));
         asm volatile("" : "+v"(acc[0][3]), "+v"(acc[1][3]), "+v"(acc[2][3]), "+v"(acc[3][3]));
-        bool any = false;
-        Q4_FILTER(0, jt); Q4_FILTER(1, jt); Q4_FILTER(2, jt); Q4_FILTER(3, jt);
-        if (any) maintain();
+        u64 todo = 0;
+        if (Q4_GMAX(0, jt)) Q4_SLOW(0, jt);
+        if (Q4_GMAX(1, jt)) Q4_SLOW(1, jt);
+        if (Q4_GMAX(2, jt)) Q4_SLOW(2, jt);
+        if (Q4_GMAX(3, jt)) Q4_SLOW(3, jt);
+        if (todo) maintain(todo);
     }
-#undef Q4_FILTER
+#undef Q4_SLOW
+#undef Q4_NEED
+#undef Q4_GMAX
+#undef Q4_TH
+#undef Q4_ACC
 #undef Q4_SEL
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!final_pass) {      // park the lane-private state for the next database chunk
@@ -1677,6 +1704,9 @@ struct FinalParams {
     int d, rows_per_wg;        // queries per scan workgroup (128 / 256)
     int segs;                  // lane lists per query: 2 halves of 256 (QS, QS2) or 4 quarters of 128 (QS4)
     int64_t n_lists;
+    const float *qres2;        // [nq_pad] measured ||q - qh||^2 (band_eps)
+    const unsigned *xstat;     // database maxima (band_eps)
+    int prefilter;             // 1: a last light compaction on the approximate keys before any row is fetched
 };
 
 // dot(q, x_row) by the chain contract for 64 rows at once: lane l owns x_row (its candidate); rows are fetched one 128-B line
@@ -1744,6 +1774,51 @@ __device__ __forceinline__ float chain_dot_wave_q(const float *__restrict__ q_ld
     return acc;
 }
 
+// A query's list as the scan leaves it holds the survivors of its LAST light compaction plus everything appended since (up to
+// `stale` keys, ~100 entries in all at k = 51), but only the keys within the band of the FINAL k-th best approximate score can
+// be in the exact top-k (~60): one more light compaction -- the scan's own rule, no database access -- before the gather cuts the
+// rows k_bf16_final fetches by a third.  Survivors go to `sk` (256 keys of LDS); returns their number, or -1 when they do not
+// fit (band-crowded data: the caller walks the list itself).
+template <int NSL>
+__device__ __forceinline__ int final_prefilter_ns(const u64 *__restrict__ list, int seg_cap, int p1, int p2, int p3, int c, int kk, float eps,
+                                                  int lane, u64 *__restrict__ sk) {
+    u64 v[NSL];
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+        const int e = lane + 64 * i;
+        const int seg = (e >= p1) + (e >= p2) + (e >= p3);
+        const int sbase = seg == 0 ? 0 : seg == 1 ? p1 : seg == 2 ? p2 : p3;
+        v[i] = e < c ? list[seg * seg_cap + (e - sbase)] : 0;
+    }
+    u32 t = 0;
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; --bit) {
+        const u32 cand = t | (1u << bit);
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) n += __builtin_popcountll(__ballot((u32)(v[i] >> 32) >= cand));
+        if (n >= kk) {
+            t = cand;
+            if (n <= kk + 2) break;
+        }
+    }
+    const float lo = bound_from_tau(lemon_ord2f(t), eps);
+    const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int kept = 0;
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) kept += __builtin_popcountll(__ballot(v[i] && lemon_key_score(v[i]) > lo));
+    if (kept > 256) return -1;
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+        const bool keep = v[i] && lemon_key_score(v[i]) > lo;
+        const u64 m = __ballot(keep);
+        if (keep) sk[base + __builtin_popcountll(m & below)] = v[i];
+        base += __builtin_popcountll(m);
+    }
+    return kept;
+}
+
 // one wave per candidate list (= per query, or per (query, database split)); STAGED needs d % 4 == 0
 template <bool l2, bool STAGED>
 __global__ __launch_bounds__(256) void k_bf16_final(FinalParams p) {
@@ -1752,6 +1827,7 @@ __global__ __launch_bounds__(256) void k_bf16_final(FinalParams p) {
     __shared__ __attribute__((aligned(16))) float s_x[4][STAGED ? 64 * FIN_PITCH : 4];
     __shared__ __attribute__((aligned(16))) u64 s_keys[4][256];
     __shared__ __attribute__((aligned(16))) u64 s_best[4][64];
+    __shared__ __attribute__((aligned(16))) u64 s_surv[4][256];   // the list after the last light compaction (final_prefilter_ns)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t L = (int64_t)blockIdx.x * 4 + wave;     // list = (scan workgroup, row inside it)
     if (L >= p.n_lists) return;
@@ -1765,7 +1841,7 @@ __global__ __launch_bounds__(256) void k_bf16_final(FinalParams p) {
     // the query's lane lists read as one: segment s holds cnt[s] keys at list[s * CAPH / segs ...]; p1..p3 = prefix counts
     const int segs = p.segs, seg_cap = CAPH / segs;
     const int p1 = p.cnt[segs * L], p2 = p1 + p.cnt[segs * L + 1];
-    const int p3 = segs > 2 ? p2 + p.cnt[segs * L + 2] : p2, c = segs > 2 ? p3 + p.cnt[segs * L + 3] : p2;
+    const int p3 = segs > 2 ? p2 + p.cnt[segs * L + 2] : p2, c_all = segs > 2 ? p3 + p.cnt[segs * L + 3] : p2;
     const int kk = p.b.kk, d = p.d;
     const float *qrow = p.q + q * (int64_t)d;
     const float qn = l2 ? p.b.qnorm[q] : 0.0f;
@@ -1775,13 +1851,25 @@ __global__ __launch_bounds__(256) void k_bf16_final(FinalParams p) {
         __builtin_amdgcn_wave_barrier();
     }
     u64 best = 0;                                         // lane i: i-th best exact key so far
+    int c = c_all;
+    bool in_lds = false;
+    if (p.prefilter && c_all > kk) {
+        const float eps = band_eps_raw(p.xstat, d, l2 ? qn : p.b.qnorm[q], p.qres2[q], l2);
+        const int ns = (c_all + 63) >> 6;                 // wave-uniform
+        const int kept = ns <= 2 ? final_prefilter_ns<2>(list, seg_cap, p1, p2, p3, c_all, kk, eps, lane, s_surv[wave])
+                       : ns == 3 ? final_prefilter_ns<3>(list, seg_cap, p1, p2, p3, c_all, kk, eps, lane, s_surv[wave])
+                       : ns == 4 ? final_prefilter_ns<4>(list, seg_cap, p1, p2, p3, c_all, kk, eps, lane, s_surv[wave])
+                                 : final_prefilter_ns<8>(list, seg_cap, p1, p2, p3, c_all, kk, eps, lane, s_surv[wave]);
+        if (kept >= 0) { c = kept; in_lds = true; }
+        __builtin_amdgcn_wave_barrier();
+    }
 #pragma unroll 1
     for (int base = 0; base < c; base += 64) {
         const int e = base + lane;
         const bool valid = e < c;
-        const int seg = (e >= p1) + (segs > 2 ? (e >= p2) + (e >= p3) : 0);
+        const int seg = (e >= p1) + (e >= p2) + (e >= p3);
         const int sbase = seg == 0 ? 0 : seg == 1 ? p1 : seg == 2 ? p2 : p3;
-        const u64 old = valid ? list[seg * seg_cap + (e - sbase)] : 0;
+        const u64 old = !valid ? 0 : in_lds ? s_surv[wave][e] : list[seg * seg_cap + (e - sbase)];
         const u32 j = valid ? lemon_key_index(old) : 0u;   // idle lanes shadow row 0 (always allocated)
         const float *xrow = p.x + (int64_t)j * d;
         float dot;
@@ -1917,11 +2005,26 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
         return c > 0 ? c : 256;
     }();
     const int n_tiles128 = (int)((idx->n + BX - 1) / BX);
+    static const bool rest_qs4 = [] { const char *e = getenv("LEMON_QS4_REST"); return !(e && e[0] == '0'); }();   // (A/B aid)
+    bool prev_qs4 = false;
     int64_t cn = 0;
     for (int64_t c0 = 0; c0 < nq; c0 += cn) {
         cn = (nq - c0) < QCHUNK_H ? (nq - c0) : QCHUNK_H;
-        const bool qs2 = qs && use_qs2() && dpad_h >= 512 && cn >= (int64_t)qs2_min * BQ2;
-        const bool qs4 = qs2 && use_qs4() && qs4_serves(dpad_h / BKH, idx->metric == LEMON_METRIC_L2);
+        bool qs2 = qs && use_qs2() && dpad_h >= 512 && cn >= (int64_t)qs2_min * BQ2;
+        bool qs4 = qs2 && use_qs4() && qs4_serves(dpad_h / BKH, idx->metric == LEMON_METRIC_L2);
+        // The ragged rest behind whole-round QS4 chunks (1 M queries: 16 960 = 67 panels of 256): the same kernel with the database
+        // split between a few workgroups per panel -- the smallest split count that fills at least three quarters of the rounds it
+        // takes (67 panels x 3 = 201 of 256 slots) -- instead of 133 one-block panels x 6 splits (39 ms per modality at 1 M x 768).
+        int rest_splits = 0;
+        if (!qs2 && prev_qs4 && c0 > 0 && rest_qs4) {
+            const int panels_r = (int)((cn + BQ2 - 1) / BQ2);
+            for (int sp = 1; sp <= 16 && !rest_splits; ++sp) {
+                const int64_t wgs = (int64_t)panels_r * sp, rounds = (wgs + cus - 1) / cus;
+                if (wgs * 4 >= rounds * cus * 3 && n_tiles128 / sp >= 64) rest_splits = sp;
+            }
+            if (rest_splits) qs2 = qs4 = true;
+        }
+        prev_qs4 = qs4;
         if (qs2 && cn < QCHUNK_H) {
             // Whole rounds first.  The chunked scan runs ONE workgroup per CU, all of equal length: 1 859 workgroups take
             // eight rounds of 256 like 2 048 do (1 M queries = 2 048 + 1 859 panels: 4.6 % of the scan spent in a quarter-full
@@ -1938,6 +2041,10 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
         const int panels = (int)(nq_pad / bqw);
         int splits, tiles_per_split;
         lemon_plan_splits(panels, n_tiles128, &splits, &tiles_per_split);
+        if (rest_splits) {
+            tiles_per_split = (n_tiles128 + rest_splits - 1) / rest_splits;
+            splits = (n_tiles128 + tiles_per_split - 1) / tiles_per_split;
+        }
         if (qs2) tiles_per_split *= BX / RT2;            // (the plan counts 128-row tiles)
         rc = lemon_ensure_search_ws(idx, nq_pad, splits, (int64_t)panels * splits * (bqw / BQ), dpad_h * 2, CAPH, stream);
         if (rc) return rc;
@@ -1994,6 +2101,9 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
         const bool l2m_ = idx->metric == LEMON_METRIC_L2;
         FinalParams fp;
         fp.b = p.b; fp.q = p.q; fp.x = p.x; fp.cnt = p.cnt; fp.d = d; fp.rows_per_wg = bqw; fp.segs = qs4 ? 4 : 2; fp.n_lists = (int64_t)grid * bqw;
+        fp.qres2 = qres2; fp.xstat = idx->xn2max_dev;
+        static const int prefilter = [] { const char *e = getenv("LEMON_FINAL_PREFILTER"); return !(e && e[0] == '0'); }();   // (A/B aid)
+        fp.prefilter = prefilter;
         auto launch_final = [&]() {     // exact re-scoring + exact top-k of every (query, split) list, one wave each
             const unsigned fg = (unsigned)((fp.n_lists + 3) / 4);
             const bool staged = (d % 4) == 0 && d <= 1024;
