@@ -12,6 +12,10 @@ N x 40 000 rows), 40 % pair-flip label noise, cosine distance, k = 50.  Rank 0 p
 Other workloads (not the headline line; used for profiles and DESIGN.md numbers):
   --workload knn      synthetic N x d unit embeddings, self-join with self-exclusion (configs[3] shape,
                       default 1M x 768, k=50): kNN + scoring only, no encoder.
+  --workload mscoco   BASELINE configs[2] shape: ViT-B/16, 82 783 + 5 000 + 5 000 image / caption pairs, every caption
+                      distinct and 8 ... 77 tokens long, DB = a random 50 000-row subset of the train split
+                      (run_lemon.py:121-127), one GPU.  The N = 1 headline line carries a bounded-size run of it
+                      (`mscoco`: 8 000 + 500 + 500 samples).
 """
 import argparse
 import json
@@ -129,11 +133,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cifar100", choices=["cifar100", "knn"])
-    ap.add_argument("--arch", default="vit-b-32")
-    ap.add_argument("--n_train", type=int, default=40000)
+    ap.add_argument("--workload", default="cifar100", choices=["cifar100", "knn", "mscoco"])
+    ap.add_argument("--arch", default=None, help="vit-b-32 (cifar100 default), vit-b-16 (mscoco default), vit-l-14")
+    ap.add_argument("--n_train", type=int, default=None, help="default 40 000 (cifar100) / 82 783 (mscoco)")
     ap.add_argument("--n_val", type=int, default=5000)
     ap.add_argument("--n_test", type=int, default=5000)
+    ap.add_argument("--db_limit", type=int, default=50000,
+                    help="mscoco: --compr_dataset_size_limit of run_lemon.py:48 (DB = a random subset of the train split, :121-127)")
+    ap.add_argument("--image_hw", default="256x320", help="mscoco: height x width of the decoded uint8 images resident in HBM")
+    ap.add_argument("--no_length_bucketing", action="store_true", help="mscoco: captions not sorted by length (every micro-batch runs ~77 tokens)")
     ap.add_argument("--knn_k", type=int, default=50)
     ap.add_argument("--dist_type", default="cosine", choices=["cosine", "euclidean"])
     ap.add_argument("--encoder_batch", type=int, default=5240,
@@ -155,12 +163,21 @@ def parse():
     ap.add_argument("--cpu_sample_queries", type=int, default=2048)
     ap.add_argument("--no_knn_1m", action="store_true",
                     help="skip the extra 1M x 768 self-join object (`knn_1m`) the N=1 headline line carries")
+    ap.add_argument("--no_mscoco", action="store_true",
+                    help="skip the bounded caption-shaped run (`mscoco`: BASELINE configs[2] at 8 000 + 500 + 500 samples) the N=1 headline line carries")
     ap.add_argument("--rccl_world1", action="store_true",
                     help="N = 1 only: initialise a one-rank RCCL process group and send the DB all-gathers through ncclAllGather anyway "
                          "(the line then carries `exchange`)")
     ap.add_argument("--knn_cpu_queries", type=int, default=10000,
                     help="query slice of the kNN workload's CPU baseline (BASELINE.md 3.5: 10 000 queries against the full DB)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.arch is None:
+        args.arch = "vit-b-16" if args.workload == "mscoco" else "vit-b-32"
+    if args.n_train is None:
+        args.n_train = 82783 if args.workload == "mscoco" else 40000
+    if args.workload == "mscoco" and args.encoder_batch == 5240:
+        args.encoder_batch = 664                 # 664 x 197 tokens = 1 022 row tiles of 128 (ViT-B/16: see tools/gpu_profile.sh)
+    return args
 
 
 def launch_ranks(args):
@@ -328,6 +345,47 @@ def make_cifar_like(args, cfg, rank, dev):
     return data
 
 
+def make_mscoco_like(args, cfg, rank, dev):
+    """Synthetic mscoco-shaped input (BASELINE configs[2]; lib/datasets/utils.py:275-323), resident in HBM: decoded uint8 images
+    [n, H, W, 3] (generic_transform -- bicubic Resize(224, shorter side) + CenterCrop + Normalize, lib/datasets/utils.py:163-170 --
+    runs inside the timed step, on the GPU) and one caption per image as token ids: BOS, 6 ... 75 random word tokens, EOT, zero
+    padding to the 77-token context (what `tokenizer(texts, padding="max_length", truncation=True)` hands over, run_lemon.py:151-154)
+    -- every caption distinct, lengths uniform on 8 ... 77 tokens.  Noise: 40 % of the samples carry another sample's caption.
+    The DB is a random `--db_limit` subset of the train split, drawn as run_lemon.py:121-124 draws it."""
+    H, W = (int(v) for v in args.image_hw.lower().split("x"))
+    g = torch.Generator(device=dev).manual_seed(2000 + rank)
+    rng = np.random.default_rng(2000 + rank)
+    eos, bos = cfg.eos_token_id, cfg.eos_token_id - 1
+    data = {}
+    for name, n in (("train", args.n_train), ("val", args.n_val), ("test", args.n_test)):
+        px = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
+        for i in range(0, n, 4096):                                # chunked: keeps the RNG workspace small
+            m = min(4096, n - i)
+            base = torch.randint(0, 256, (m, H // 16, W // 16, 3), dtype=torch.uint8, device=dev, generator=g)     # blocky content + pixel noise
+            px[i:i + m] = (base.repeat_interleave(16, 1).repeat_interleave(16, 2).to(torch.int16)
+                           + torch.randint(-24, 25, (m, H, W, 3), dtype=torch.int16, device=dev, generator=g)).clamp_(0, 255).to(torch.uint8)
+        length = rng.integers(8, cfg.context_length + 1, n)          # tokens incl. BOS and EOT
+        ids = np.zeros((n, cfg.context_length), dtype=np.int64)
+        words = rng.integers(1, bos, (n, cfg.context_length))
+        col = np.arange(cfg.context_length)[None, :]
+        ids = np.where(col < (length - 1)[:, None], words, 0)
+        ids[:, 0] = bos
+        ids[np.arange(n), length - 1] = eos
+        flip = rng.random(n) < 0.4
+        src = np.arange(n)
+        src[flip] = rng.permutation(src[flip])                       # a noisy sample gets another noisy sample's caption
+        data[name] = dict(pixels=px, ids=torch.from_numpy(ids[src]), label_id=None, clean=np.arange(n), noisy=src,
+                          caption_tokens=length[src])
+    n_tr = args.n_train
+    if n_tr > args.db_limit:
+        np.random.seed(0)                                             # run_lemon.py:81 seeds, :123 draws (first consumer of the stream)
+        sel = np.random.choice(np.arange(n_tr), args.db_limit, replace=False)
+        mask = np.zeros(n_tr, dtype=np.uint8)
+        mask[sel] = 1
+        data["train"]["db_index"], data["train"]["in_db"] = sel, mask
+    return data
+
+
 def bench_cifar(args, world, rank, dev):
     from lemon_amd import _lib
     from lemon_amd.clip import ClipConfig, LemonCLIP, encoder_flops
@@ -343,8 +401,16 @@ def bench_cifar(args, world, rank, dev):
     while tb > 8 * args.encoder_batch and tb % 2 == 0:
         tb //= 2
     text_batch = tb if min(2 * args.encoder_batch, 4000) <= tb <= 8 * args.encoder_batch else None
-    emb = Embedder(model, dev, batch_size=args.encoder_batch, text_dedup=args.text_dedup, text_batch_size=text_batch)
-    data = make_cifar_like(args, cfg, rank, dev)
+    coco = args.workload == "mscoco"
+    if coco:
+        assert world == 1, "the mscoco workload is a one-GPU measurement (the DB subset is drawn over the whole train split)"
+        # captions run 8 ... 77 tokens: micro-batches of ~2 500 captions (up to 197 000 token rows at 77 tokens) sorted by length
+        emb = Embedder(model, dev, batch_size=args.encoder_batch, text_batch_size=4 * args.encoder_batch,
+                       length_bucketing=not args.no_length_bucketing)
+        data = make_mscoco_like(args, cfg, rank, dev)
+    else:
+        emb = Embedder(model, dev, batch_size=args.encoder_batch, text_dedup=args.text_dedup, text_batch_size=text_batch)
+        data = make_cifar_like(args, cfg, rank, dev)
     data["train"]["n_total"] = args.n_train * world
     algo = {"auto": None, "f32": _lib.ALGO_F32_MFMA, "bf16": _lib.ALGO_BF16_FILTER}[args.algo]
     n_scored = args.n_train + args.n_val + args.n_test
@@ -379,6 +445,7 @@ def bench_cifar(args, world, rank, dev):
     # of the timed region: recorded on the launch stream inside the library, read back only after the region ends
     _ops.gemm_profiling(True)
     fb0 = (emb.fallback_batches, emb.fold_fallback_batches, emb.fallback_rows, emb.fold_fallback_rows)
+    tok0 = emb.text_tokens_run
     t0 = time.perf_counter()
     timed = []
     gemm_prof = {"launches": 0, "kernel_ms": 0.0, "flops": 0.0}
@@ -388,6 +455,7 @@ def bench_cifar(args, world, rank, dev):
     barrier_sync(world, dev)
     elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
     fb1 = (emb.fallback_batches, emb.fold_fallback_batches, emb.fallback_rows, emb.fold_fallback_rows)
+    text_tokens_per_caption = (emb.text_tokens_run - tok0) / max(args.steps * n_scored, 1)
     gp = _ops.gemm_profile_read()
     _ops.gemm_profiling(False)
     for k_ in gemm_prof:
@@ -404,6 +472,14 @@ def bench_cifar(args, world, rank, dev):
     info = db.index_img.last_search_info()
     # text tokens actually run: the longest prompt rounded up to the tower's bucket (clip.TextTower.seq_len_for)
     f_img, f_txt = encoder_flops(cfg, n_tokens_text=model.text.seq_len_for(int(data["train"]["ids"].argmax(-1).max().item())))
+    if coco:
+        # captions: FLOPs of the tokens the tower RAN (micro-batches sorted by length run their longest caption's bucket), averaged per
+        # caption from a per-length table; the reference pads every caption to 77 tokens (run_lemon.py:151-154): `ref_padded` below
+        f_txt_padded = encoder_flops(cfg, n_tokens_text=cfg.context_length)[1]
+        Lbar = max(text_tokens_per_caption, 1.0)
+        lo_, hi_ = int(np.floor(Lbar)), int(np.ceil(Lbar))
+        f_lo, f_hi = encoder_flops(cfg, n_tokens_text=max(lo_, 1))[1], encoder_flops(cfg, n_tokens_text=max(hi_, 1))[1]
+        f_txt = f_lo + (f_hi - f_lo) * (Lbar - lo_)
 
     value = n_scored * world * args.steps / elapsed
     from lemon_amd.ops import gemm_mode as _gm
@@ -458,7 +534,39 @@ def bench_cifar(args, world, rank, dev):
                             "cores (fp32-equivalent results; 16-bit MFMA peak / 6 = 416.7, / 3 = 833 TFLOP/s-equivalent), the patch "
                             "embedding with them; the two final projections (1 000 pooled rows per micro-batch) stay fp32 GEMMs"},
     }
-    if world == 1 and not args.text_dedup and not args.no_f32_gemm_check:
+    if coco:
+        H_, W_ = (int(v) for v in args.image_hw.lower().split("x"))
+        line["metric"] = "label-error scores/sec (embed+kNN), mscoco-shaped captions noise=0.4"
+        line["scaling"] = "none (one GPU)"
+        line["config"]["workload"] = (
+            f"mscoco shape (BASELINE configs[2]): {args.n_train} train + {args.n_val} val + {args.n_test} test image/caption pairs; decoded "
+            f"{H_}x{W_} uint8 images resident in HBM (bicubic resize to 224 + centre crop + normalise in the step), one DISTINCT caption per "
+            f"image, 8 ... {cfg.context_length} tokens, CLIP {args.arch} random-init fp32 encoder -> {cfg.embed_dim}-d; DB = a random "
+            f"{min(args.db_limit, args.n_train)}-row subset of the train split (run_lemon.py:121-127), {args.dist_type} brute-force kNN "
+            f"k={args.knn_k}, every one of the {n_scored} samples scored (train queries with self-exclusion where they are DB rows)")
+        line["config"]["noise"] = "40 % of the samples carry another sample's caption (synthetic stand-in for 'cat' noise, lib/datasets/utils.py:300-309)"
+        line["config"]["text_dedup"] = False
+        line["config"]["length_bucketing"] = bool(emb.length_bucketing)
+        line["config"]["text_tokens_run_per_caption"] = text_tokens_per_caption
+        line["config"]["text_tokens_mean_caption"] = float(np.mean(np.concatenate([data[n_]["caption_tokens"] for n_ in data])))
+        line["encoder"]["text_flops_note"] = ("text FLOPs = the tokens the tower ran (captions sorted by length, a micro-batch runs its longest caption's "
+                                              "8-token bucket); padded to 77 tokens as upstream the same captions cost "
+                                              f"{f_txt_padded / 1e9:.2f} GFLOP each instead of {f_txt / 1e9:.2f}")
+        # the hand-written GEMM per tower (the same kernels meet other shapes in the text tower: width 512, 3 ... 20 x fewer rows per
+        # launch): one untimed image-only and one text-only pass over the val split, HIP events around every launch
+        by_tower = {}
+        for tname, fn in (("image", lambda: emb.embed_images(data["val"]["pixels"])), ("text", lambda: emb.embed_texts(data["val"]["ids"]))):
+            fn(); torch.cuda.synchronize(dev)
+            _ops.gemm_profiling(True)
+            fn()
+            gpt = _ops.gemm_profile_read()
+            _ops.gemm_profiling(False)
+            if gpt["launches"]:
+                tf_ = gpt["flops"] / (gpt["kernel_ms"] / 1e3) / 1e12
+                by_tower[tname] = {"launches": gpt["launches"], "avg_launch_ms": gpt["kernel_ms"] / gpt["launches"], "achieved": tf_,
+                                   "frac": tf_ / PEAK_BF16_MFMA_TFLOPS}
+        line["gemm_by_tower"] = by_tower
+    if world == 1 and not args.text_dedup and not args.no_f32_gemm_check and not coco:
         # what `python -m lemon_amd.run_lemon` does by default (cli_common: --no_text_dedup turns it off): every DISTINCT prompt is
         # embedded once and gathered -- 100 prompts instead of 50 000 on this workload.  One extra step, an untimed region of its
         # own; NOT the headline (which encodes every sample's prompt, as upstream does, run_lemon.py:140-161,207-233)
@@ -472,7 +580,7 @@ def bench_cifar(args, world, rank, dev):
             "max_abs_val_score_diff_vs_headline": float((recs_d["val"]["score"] - recs["val"]["score"]).abs().max().item()),
             "note": "run_lemon's default text path (distinct prompts embedded once); reported beside the headline, never as `value`"}
         del recs_d, emb_d
-    if gemm_mode != "f32" and world == 1 and not args.no_f32_gemm_check:
+    if gemm_mode != "f32" and world == 1 and not args.no_f32_gemm_check and not coco:
         # the same step once more, untimed region of its own, with every GEMM on the fp32 matrix cores (LEMON_GEMM=f32): what
         # the split GEMMs buy, and the score difference between the two modes on the val split
         os.environ["LEMON_GEMM"] = "f32"
@@ -535,11 +643,28 @@ def bench_cifar(args, world, rank, dev):
     if world > 1 or args.rccl_world1:
         line["exchange"] = exchange_report(glog, world, info, db, args.steps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"], line["auroc_check"] = cpu_baseline_cifar(args, cfg, model, data, recs, db, n_scored)
-    if world == 1 and not args.no_knn_1m:
-        # north_star's second target inside the same driver-timed run: the 1M x 768, k=50 self-join on this GPU
+        if coco:
+            cores = __import__("oracle.oracle", fromlist=["usable_cores"]).usable_cores()
+            line["cpu_baseline"] = cpu_reference_style(args, cfg, data, recs, db, n_scored, cores, 0.0)
+            line["cpu_baseline"]["preprocess_note"] = "image decoding / resizing not timed on the CPU side (generous to the CPU)"
+        else:
+            line["cpu_baseline"], line["auroc_check"] = cpu_baseline_cifar(args, cfg, model, data, recs, db, n_scored)
+    if world == 1 and not coco and not (args.no_knn_1m and args.no_mscoco):
         del recs, db, data, emb, model
         torch.cuda.empty_cache()
+    if world == 1 and not args.no_mscoco and not coco:
+        # BASELINE configs[2] (caption-shaped: every text row distinct, 8 ... 77 tokens, ViT-B/16, DB = random subset) at a BOUNDED
+        # size inside the same driver run; the full-size line is committed under profiles/ (tools/gpu_profile.sh)
+        ma = argparse.Namespace(**{**vars(args), "workload": "mscoco", "arch": "vit-b-16", "n_train": 8000, "n_val": 500, "n_test": 500,
+                                   "db_limit": 5000, "encoder_batch": 664, "steps": 2, "warmup": 1, "no_cpu_baseline": True,
+                                   "no_knn_1m": True, "no_mscoco": True, "no_f32_gemm_check": True, "text_dedup": False, "algo": "auto",
+                                   "input": "u8", "knn_k": 50, "dist_type": "cosine", "rccl_world1": False})
+        m1 = bench_cifar(ma, world, rank, dev)
+        line["mscoco"] = {k_: m1[k_] for k_ in ("metric", "value", "unit", "ms_per_step", "config", "stages_s", "encoder", "roofline",
+                                                  "gemm_by_tower", "fallback_rows", "fold_fallback_rows") if k_ in m1}
+        torch.cuda.empty_cache()
+    if world == 1 and not args.no_knn_1m and not coco:
+        # north_star's second target inside the same driver-timed run: the 1M x 768, k=50 self-join on this GPU
         ka = argparse.Namespace(**{**vars(args), "knn_n": 1_000_000, "knn_d": 768, "knn_k": 50, "steps": 1, "warmup": 0,
                                    "algo": "auto", "dist_type": "cosine"})
         k1 = bench_knn(ka, world, rank, dev)
@@ -708,7 +833,10 @@ def cpu_reference_style(args, cfg, data, recs, db, n_scored, cores, t_pre):
     n_tr_q = min(2048, recs["train"]["emb_img"].shape[0])
     n_va_q = min(1024, recs["val"]["emb_img"].shape[0])
     splits = (("train", recs["train"], n_tr_q), ("val", recs["val"], n_va_q))
-    in_compr = np.arange(img_tr.shape[0])                           # single GPU: the DB is the whole train split, in order
+    # single GPU: the DB is the whole train split in order, or (mscoco) the drawn subset of it
+    in_compr = np.asarray(data["train"].get("db_index")) if data["train"].get("db_index") is not None else np.arange(img_tr.shape[0])
+    pos_in_db = np.full(recs["train"]["emb_img"].shape[0], -1, dtype=np.int64)
+    pos_in_db[in_compr] = np.arange(len(in_compr))
     t_search = t_loop = t_vec = 0.0
     nq_tot = 0
     rows_same = 0
@@ -726,7 +854,7 @@ def cpu_reference_style(args, cfg, data, recs, db, n_scored, cores, t_pre):
         t_loop += time.perf_counter() - t0
         t0 = time.perf_counter()
         vec = rl.vectorised(sname, qi.numpy(), qt.numpy(), img_tr.numpy(), txt_tr.numpy(), dists_tr.numpy(), ii, it, args.knn_k, 128,
-                            np.ones(nq, bool), args.dist_type)
+                            pos_in_db[:nq] >= 0, args.dist_type)
         t_vec += time.perf_counter() - t0
         nq_tot += nq
         # against the GPU records: image-side neighbour sets and d_1.  (torch.mm's float32 summation order is not the chain order
@@ -736,7 +864,7 @@ def cpu_reference_style(args, cfg, data, recs, db, n_scored, cores, t_pre):
         d1_diff = max(d1_diff, float(np.abs(rl.stack(logs, "d_1") - rv["d_1"][:nq].cpu().numpy()).max()))
         # which side is right where they differ: float64 scores over the whole DB for every differing query (train: self excluded)
         a_ = rl.adjudicate_near_ties(qi.numpy(), img_tr.numpy(), I_gpu, I_cpu, args.dist_type,
-                                     exclude=(np.arange(nq) if sname == "train" else None))
+                                     exclude=(pos_in_db[:nq] if sname == "train" else None))
         adj["rows"] += a_["rows"]; adj["rows_differing"] += a_["rows_differing"]
         adj["gpu_ok"] += a_["rows_a_equals_f64_set"] * a_["rows"]; adj["cpu_ok"] += a_["rows_b_equals_f64_set"] * a_["rows"]
         adj["max_gap_at_swap"] = max(adj["max_gap_at_swap"], a_["max_gap_at_swap"])
@@ -884,7 +1012,7 @@ def main():
     world, rank, dev = init_dist(args)
     from lemon_amd import _lib
     _lib.load()                                   # fail loudly if the HIP library is missing
-    line = bench_cifar(args, world, rank, dev) if args.workload == "cifar100" else bench_knn(args, world, rank, dev)
+    line = bench_knn(args, world, rank, dev) if args.workload == "knn" else bench_cifar(args, world, rank, dev)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1 or args.rccl_world1:

@@ -1557,38 +1557,37 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
     // k32 step S (compile-time) of the tile on fragment set S & 1.  In the gaps between its MFMAs: the reads of step S + 1
     // (the next stage's slot once S + 1 starts a stage), in steps 2 and 3 of a stage the DMA pieces of stage t + 3, and in
     // step 0 of a tile the filter of the previous tile (group b in front of group b's first MFMA).
+    // (written out slot by slot, no loop for hipcc to unroll: where it declined to -- the L2 instantiation at pitch 512 once --
+    // the fragment registers of in-flight asm reads were copied around a 16-way switch; tests/test_build_guard.py)
+#define Q4_SLOT(S, i_)                                                                                                     \
+    do {                                                                                                                   \
+        if ((S) == 0 && ((i_) & 3) == 0 && do_filter) {                                                                    \
+            if ((i_) == 0)  { pm0 = Q4_GMAX(0, jprev); pm1 = Q4_GMAX(1, jprev); if (pm0) Q4_SLOW(0, jprev); }              \
+            if ((i_) == 4)  { pm2 = Q4_GMAX(2, jprev); if (pm1) Q4_SLOW(1, jprev); }                                       \
+            if ((i_) == 8)  { pm3 = Q4_GMAX(3, jprev); if (pm2) Q4_SLOW(2, jprev); }                                       \
+            if ((i_) == 12) { if (pm3) Q4_SLOW(3, jprev); }                                                                \
+        }                                                                                                                  \
+        Q4_MF((S) & 1, S, i_);                                                                                             \
+        if ((i_) == RD0) Q4_LOADA(((S) & 1) ^ 1, ((S) + 1) % NS, 0);                                                       \
+        if ((i_) == RD0 + RDS) Q4_LOADA(((S) & 1) ^ 1, ((S) + 1) % NS, 1);                                                 \
+        if ((i_) == RD0 + 2 * RDS) Q4_LOADA(((S) & 1) ^ 1, ((S) + 1) % NS, 2);                                             \
+        if ((i_) == RD0 + 3 * RDS) Q4_LOADA(((S) & 1) ^ 1, ((S) + 1) % NS, 3);                                             \
+        if ((i_) == RD0 + 4 * RDS) Q4_LOADP(((S) & 1) ^ 1, ((S) + 1) % NS);                                                \
+        if (((S) & 3) >= 2 && ((i_) == DM0 || (i_) == DM1) && more) {                                                      \
+            constexpr int kn_ = (S) / 4 + 3;                                                                               \
+            Q4_PIECE(xt + (int64_t)(kn_ / KT2) * RT2 * dpad, kn_ % KT2, (t + 3) & (NB - 1), 2 * (((S) & 3) - 2) + ((i_) == DM1)); \
+        }                                                                                                                  \
+    } while (0)
 #define Q4_STEP(S)                                                                                                         \
     do {                                                                                                                   \
-        constexpr int U_ = (S) & 1, N_ = ((S) + 1) % NS, sq_ = (S) & 3;                                                    \
-        Q4_WAIT(U_);                                                                                                       \
-        if (sq_ == 3) {   /* the next step opens a stage: its slot */                                                      \
+        Q4_WAIT((S) & 1);                                                                                                  \
+        if (((S) & 3) == 3) {   /* the next step opens a stage: its slot */                                                \
             const unsigned sbn_ = (unsigned)(((t + 1) & (NB - 1)) * STG * 4);                                              \
             va0 = fa0 + sbn_; va1 = fa1 + sbn_;                                                                            \
         }                                                                                                                  \
-        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                                                                \
-            if ((S) == 0 && (i_ & 3) == 0 && do_filter) {                                                                  \
-                if (i_ == 0)  { pm0 = Q4_GMAX(0, jprev); pm1 = Q4_GMAX(1, jprev); if (pm0) Q4_SLOW(0, jprev); }            \
-                if (i_ == 4)  { pm2 = Q4_GMAX(2, jprev); if (pm1) Q4_SLOW(1, jprev); }                                     \
-                if (i_ == 8)  { pm3 = Q4_GMAX(3, jprev); if (pm2) Q4_SLOW(2, jprev); }                                     \
-                if (i_ == 12) { if (pm3) Q4_SLOW(3, jprev); }                                                              \
-            }                                                                                                              \
-            switch (i_) {                                                                                                  \
-                case 0: Q4_MF(U_, S, 0); break; case 1: Q4_MF(U_, S, 1); break; case 2: Q4_MF(U_, S, 2); break; case 3: Q4_MF(U_, S, 3); break; \
-                case 4: Q4_MF(U_, S, 4); break; case 5: Q4_MF(U_, S, 5); break; case 6: Q4_MF(U_, S, 6); break; case 7: Q4_MF(U_, S, 7); break; \
-                case 8: Q4_MF(U_, S, 8); break; case 9: Q4_MF(U_, S, 9); break; case 10: Q4_MF(U_, S, 10); break; case 11: Q4_MF(U_, S, 11); break; \
-                case 12: Q4_MF(U_, S, 12); break; case 13: Q4_MF(U_, S, 13); break; case 14: Q4_MF(U_, S, 14); break; default: Q4_MF(U_, S, 15); break; \
-            }                                                                                                              \
-            if (i_ == RD0) Q4_LOADA(U_ ^ 1, N_, 0);                                                                        \
-            if (i_ == RD0 + RDS) Q4_LOADA(U_ ^ 1, N_, 1);                                                                  \
-            if (i_ == RD0 + 2 * RDS) Q4_LOADA(U_ ^ 1, N_, 2);                                                              \
-            if (i_ == RD0 + 3 * RDS) Q4_LOADA(U_ ^ 1, N_, 3);                                                              \
-            if (i_ == RD0 + 4 * RDS) Q4_LOADP(U_ ^ 1, N_);                                                                 \
-            if (sq_ >= 2 && more && (i_ == DM0 || i_ == DM1)) {                                                            \
-                constexpr int kn_ = (S) / 4 + 3;                                                                           \
-                Q4_PIECE(xt + (int64_t)(kn_ / KT2) * RT2 * dpad, kn_ % KT2, (t + 3) & (NB - 1), 2 * (sq_ - 2) + (i_ == DM1)); \
-            }                                                                                                              \
-        }                                                                                                                  \
-        if (sq_ == 1) {                                                                                                    \
+        Q4_SLOT(S, 0); Q4_SLOT(S, 1); Q4_SLOT(S, 2); Q4_SLOT(S, 3); Q4_SLOT(S, 4); Q4_SLOT(S, 5); Q4_SLOT(S, 6); Q4_SLOT(S, 7);    \
+        Q4_SLOT(S, 8); Q4_SLOT(S, 9); Q4_SLOT(S, 10); Q4_SLOT(S, 11); Q4_SLOT(S, 12); Q4_SLOT(S, 13); Q4_SLOT(S, 14); Q4_SLOT(S, 15); \
+        if (((S) & 3) == 1) {                                                                                              \
             /* stage t + 1 has landed (this wave's pieces: at most the four of stage t + 2 may still be in flight; younger */ \
             /* appends only make the wait longer), then the rendezvous: everybody's pieces, and everybody is done with stage t - 1 */ \
             if (t + 2 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                            \
@@ -1625,6 +1624,7 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
 #undef Q4_STAGE
     Q4_WAIT(0);                                 // (the reads the last step issued for a tile that does not exist: retired, unused)
 #undef Q4_STEP
+#undef Q4_SLOT
 #undef Q4_MF
 #undef Q4_WAIT
 #undef Q4_LOADP

@@ -110,7 +110,8 @@ class Embedder:
     and its poisoned samples are re-embedded here -- first with the same f16x3 arithmetic and LayerNorm kernels (`fold_fallback_rows`), and only if it
     is still not finite with the range-free scheme.  What is still not finite after that is not a range problem and raises in raise_if_nonfinite()."""
 
-    def __init__(self, model, device, batch_size=128, dtype=torch.float32, text_dedup=False, text_batch_size=None, range_fallback=True):
+    def __init__(self, model, device, batch_size=128, dtype=torch.float32, text_dedup=False, text_batch_size=None, range_fallback=True,
+                 length_bucketing=False):
         self.model = model.eval().to(device=device, dtype=dtype)
         self.device, self.batch_size, self.dtype, self.text_dedup = device, batch_size, dtype, text_dedup
         # prompts are ~7x shorter than the image token sequence: a 4x larger text micro-batch keeps the
@@ -122,6 +123,12 @@ class Embedder:
         self.fold_fallback_batches = 0    # ... with LayerNorm kernels because a row's mean was beyond the fold's bound
         self.fallback_rows = 0        # the samples themselves (only they are embedded again, in sub-batches)
         self.fold_fallback_rows = 0
+        # captions (run_lemon.py:140-154 pads every one to the 77-token context): sorted by length before they are cut into
+        # micro-batches, so that a micro-batch runs the tokens of ITS longest caption only (exact under the causal mask, like the
+        # per-batch truncation without it; a caption's embedding does not depend on its batch mates).  Off by default: on
+        # classification prompts all lengths fall into one or two 8-token buckets anyway
+        self.length_bucketing = length_bucketing
+        self.text_tokens_run = 0      # token rows the text tower actually ran (bucketed length x captions), for FLOP accounting
 
     def _note(self, e):
         if e.is_cuda and e.shape[0]:
@@ -228,13 +235,26 @@ class Embedder:
             eot = ids.argmax(dim=-1).cpu()
         bucketed = eot is not None and hasattr(tower, "seq_len_for")
 
+        perm = None
+        if bucketed and self.length_bucketing and ids.shape[0] > self.text_batch_size:
+            perm = torch.argsort(eot, stable=True)           # host: shortest captions first
+
         def one(sel):
+            if perm is not None:                             # sel addresses the length-sorted order
+                sel = perm[sel]
             rows = ids[sel if isinstance(sel, slice) else sel.to(ids.device)]
             if bucketed:
-                return self.model.encode_text(rows, seq_len=tower.seq_len_for(int(eot[sel].max())))
+                L = tower.seq_len_for(int(eot[sel].max()))
+                self.text_tokens_run += int(L) * int(rows.shape[0])
+                return self.model.encode_text(rows, seq_len=L)
             return self.model.encode_text(rows)
 
-        return self._run_batches(ids.shape[0], self.text_batch_size, one)
+        e = self._run_batches(ids.shape[0], self.text_batch_size, one)
+        if perm is not None:
+            out = torch.empty_like(e)
+            out[perm.to(e.device)] = e
+            e = out
+        return e
 
 
 def score_splits(db, splits, k, hparams=None, discrete=False):
@@ -304,6 +324,11 @@ def run_hot_path(embedder, data, k=5, dist_type="cosine", hparams=FIXED_HPARAMS,
     txt_tr = all_gather_rows(emb["train"][1], n_train_total, log=gather_log, name="emb_txt_tr")
     lab = data["train"].get("label_id")
     lab_tr = all_gather_rows(lab.to(dev), n_train_total, log=gather_log, name="label_id_tr") if (discrete and lab is not None) else None
+    db_index = data["train"].get("db_index")
+    if db_index is not None:                # DB = a subset of the train split, in the order drawn (run_lemon.py:121-127); the train
+        sel = torch.as_tensor(db_index).to(dev)     # queries then carry data["train"]["in_db"] (self-exclusion, :256-263)
+        img_tr, txt_tr = img_tr[sel].contiguous(), txt_tr[sel].contiguous()
+        lab_tr = lab_tr[sel].contiguous() if lab_tr is not None else None
     db = LemonDB(img_tr, txt_tr, dist_type, tr_label_id=lab_tr, algo=algo)
     if profile_index:
         db.index_img.set_profiling(True)

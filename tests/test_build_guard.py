@@ -1,6 +1,6 @@
 """CPU (hipcc cross-compiles gfx950 here): the hand-scheduled scan kernels must not spill.
 
-The main loops of k_scan_f32 / k_scan_bf16_qs / k_scan_bf16_qs2 issue their loads by hand (inline asm, counted waits) and pin
+The main loops of k_scan_f32 / k_scan_bf16_qs / k_scan_bf16_qs2 / k_scan_f16_qs4 issue their loads by hand (inline asm, counted waits) and pin
 operands to register classes; their correctness and speed both assume that hipcc keeps every staging / fragment / stationary
 register where it was put.  A spill would (a) reload the stationary query fragments from scratch inside the MFMA loop behind a
 `vmcnt(0)` that drains the LDS-DMA queue (seen while building k_scan_bf16_qs2: DESIGN.md section 4) and (b) let the compiler
@@ -55,7 +55,9 @@ def _kernel_meta(src):
     ("knn_f32.hip", ["k_scan_f32ILb0ELb0ELb0E", "k_scan_f32ILb1ELb0ELb0E"]),
     ("knn_bf16.hip", ["k_scan_bf16_qsILi12ELb0ELb0E", "k_scan_bf16_qsILi8ELb0ELb0E", "k_scan_bf16_qsILi4ELb0ELb0E",
                       "k_scan_bf16_qs2ILi12ELi16ELb0ELb0ELb1E", "k_scan_bf16_qs2ILi12ELi20ELb1ELb0ELb1E",
-                      "k_scan_bf16_qs2ILi8ELi0ELb0ELb0ELb1E", "k_bf16_finalILb0ELb1E", "k_bf16_finalILb1ELb1E"]),
+                      "k_scan_bf16_qs2ILi8ELi0ELb0ELb0ELb1E", "k_bf16_finalILb0ELb1E", "k_bf16_finalILb1ELb1E",
+                      # round 5: the same scan on v_mfma_f32_16x16x32_f16 (IP at pitches 768 / 512, squared L2 at pitch 512)
+                      "k_scan_f16_qs4ILi12ELi16ELb0E", "k_scan_f16_qs4ILi8ELi0ELb0E", "k_scan_f16_qs4ILi8ELi0ELb1E"]),
     # the hand-written GEMM (asm LDS-DMA / ds_read / MFMA with pinned accumulators: two workgroups per CU need <= 256 registers)
     # and the attention kernels (three waves per SIMD)
     ("gemm_f16x3.hip", ["k_gemm_f16x3tILi0E", "k_gemm_f16x3tILi1E"]),
@@ -186,7 +188,7 @@ def _check_asm_discipline(name, lines):
 @pytest.mark.parametrize("src,kernels", [
     ("gemm_f16x3.hip", ["k_gemm_f16x3tILi0E", "k_gemm_f16x3tILi1E", "k_gemm_f16x3t16ILi0E", "k_gemm_f16x3t16ILi1E"]),
     ("knn_bf16.hip", ["k_scan_bf16_qs2ILi12ELi16ELb0ELb0ELb1E", "k_scan_bf16_qs2ILi12ELi20ELb1ELb0ELb1E", "k_scan_bf16_qs2ILi8ELi0ELb0ELb0ELb1E",
-                      ]),
+                      "k_scan_f16_qs4ILi12ELi16ELb0E", "k_scan_f16_qs4ILi8ELi0ELb0E", "k_scan_f16_qs4ILi8ELi0ELb1E"]),
     ("knn_f32.hip", ["k_scan_f32ILb0ELb0ELb0E", "k_scan_f32ILb1ELb0ELb0E"]),
 ])
 def test_hand_issued_asm_is_left_alone_by_the_compiler(src, kernels):
