@@ -37,7 +37,7 @@ PEAK_HBM_GBS = 8000.0          # HBM3E spec peak (6.3 TB/s achievable)
 def pmc_summary(kernel_substr, fname="bench_default_pmc.csv"):
     """{counter: row} of the longest-running launch group of a kernel in a COMMITTED PMC summary (profiles/rN/<fname>), + path."""
     import csv
-    path = next((p for p in (os.path.join(ROOT, "profiles", r, fname) for r in ("r4", "r3", "r2", "r1")) if os.path.exists(p)), None)
+    path = next((p for p in (os.path.join(ROOT, "profiles", r, fname) for r in ("r5", "r4", "r3", "r2", "r1")) if os.path.exists(p)), None)
     if path is None:
         return {}, None
     best = {}
@@ -57,7 +57,7 @@ def pmc_traffic(kernel_substr):
     from inside the timed process, so this is NOT a measurement of the current run: the file it came from is
     reported next to it as `traffic_source`.  (None, None) when no summary is committed."""
     import csv
-    path = next((p for p in (os.path.join(ROOT, "profiles", r, "bench_default_pmc.csv") for r in ("r4", "r3", "r2", "r1"))
+    path = next((p for p in (os.path.join(ROOT, "profiles", r, "bench_default_pmc.csv") for r in ("r5", "r4", "r3", "r2", "r1"))
                  if os.path.exists(p)), None)
     if path is None:
         return None, None
@@ -93,7 +93,7 @@ def pmc_gemm_summary():
     summary of the headline command (profiles/rN/encoder_gemm_pmc.csv, tools/gpu_profile.sh): FETCH_SIZE x 2 + WRITE_SIZE bytes
     per launch, MFMA-busy fraction and shader clock.  Not a measurement of the current run."""
     import csv
-    path = next((p for p in (os.path.join(ROOT, "profiles", r, "encoder_gemm_pmc.csv") for r in ("r4",)) if os.path.exists(p)), None)
+    path = next((p for p in (os.path.join(ROOT, "profiles", r, "encoder_gemm_pmc.csv") for r in ("r5", "r4")) if os.path.exists(p)), None)
     if path is None:
         return {}, None
     best = {}
@@ -118,7 +118,7 @@ def sustained_bf16_peak():
     (tools/micro/mfma_peak.hip; the board's power management lowers the shader clock), read from the COMMITTED output of
     that micro-benchmark -- context for the bf16 scan's `frac` of the data-sheet peak, not a measurement of this run."""
     import re
-    path = next((p for p in (os.path.join(ROOT, "profiles", r, "micro_mfma_peak.txt") for r in ("r4", "r3", "r2")) if os.path.exists(p)), None)
+    path = next((p for p in (os.path.join(ROOT, "profiles", r, "micro_mfma_peak.txt") for r in ("r5", "r4", "r3", "r2")) if os.path.exists(p)), None)
     if path is None:
         return None, None
     for ln in open(path):
@@ -553,9 +553,11 @@ def bench_cifar(args, world, rank, dev):
                                               "8-token bucket); padded to 77 tokens as upstream the same captions cost "
                                               f"{f_txt_padded / 1e9:.2f} GFLOP each instead of {f_txt / 1e9:.2f}")
         # the hand-written GEMM per tower (the same kernels meet other shapes in the text tower: width 512, 3 ... 20 x fewer rows per
-        # launch): one untimed image-only and one text-only pass over the val split, HIP events around every launch
+        # launch): one untimed image-only and one text-only pass over (at most 20 000 samples of) the train split, HIP events around
+        # every launch
+        nbt = min(20000, args.n_train)
         by_tower = {}
-        for tname, fn in (("image", lambda: emb.embed_images(data["val"]["pixels"])), ("text", lambda: emb.embed_texts(data["val"]["ids"]))):
+        for tname, fn in (("image", lambda: emb.embed_images(data["train"]["pixels"][:nbt])), ("text", lambda: emb.embed_texts(data["train"]["ids"][:nbt]))):
             fn(); torch.cuda.synchronize(dev)
             _ops.gemm_profiling(True)
             fn()
@@ -955,7 +957,7 @@ def bench_knn(args, world, rank, dev):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"synthetic {n}x{d} unit embeddings per modality, self-join k={k} (+1 self-exclusion), "
                                f"{args.dist_type}, query-sharded over {world} GPU(s), DB all-gathered"},
-        "roofline": {"kernel": "k_scan_f32" if f32 else "k_scan_bf16", "bound": "mfma",
+        "roofline": {"kernel": "k_scan_f32" if f32 else "k_scan_f16_qs4 + k_bf16_final (fp16 filter scan on v_mfma_f32_16x16x32_f16 + exact fp32 re-score)", "bound": "mfma",
                      "achieved": prof["algo_flops"] / sec / 1e12, "peak": peak, "unit": "TFLOP/s",
                      "frac": prof["algo_flops"] / sec / 1e12 / peak, "traffic": None,
                      "launches": prof["launches"], "avg_launch_ms": prof["kernel_ms"] / max(prof["launches"], 1),
@@ -964,7 +966,9 @@ def bench_knn(args, world, rank, dev):
     if not f32 and n == 1000000 and d == 768:
         # counter figures of the steady-state chunk launch from the committed PMC passes of THIS command (tools/gpu_profile.sh):
         # not a measurement of the current run, the source file is named
-        pm, src = pmc_summary("k_scan_bf16_qs2", "knn_1000000x768_pmc.csv")
+        pm, src = pmc_summary("k_scan_f16_qs4", "knn_1000000x768_pmc.csv")
+        if not pm:                               # (no round-5 summary committed yet: the round-4 one describes k_scan_bf16_qs2)
+            pm, src = pmc_summary("k_scan_bf16_qs2", "knn_1000000x768_pmc.csv")
         if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
             line["roofline"]["traffic"] = (2.0 * float(pm["FETCH_SIZE"]["value_KB"]) + float(pm["WRITE_SIZE"]["value_KB"])) * 1024.0
             line["roofline"]["traffic_source"] = src

@@ -1,7 +1,7 @@
 """Copy the judged summaries of a tools/gpu_profile.sh run from gpurun_out/ into profiles/<tag>/.
 python tools/collect_profiles.py [tag]"""
 import csv, glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles", tag)
 os.makedirs(P, exist_ok=True)
@@ -47,11 +47,13 @@ def write_pmc(name, dirs):
     print(name, len(out), "rows (from", len(rows), "launch records)")
 
 for src, dst in ((f"bench_{tag}.json", "bench_default.json"), (f"prof_knn_{tag}.json", "knn_1000000x768.json"),
-                 (f"bench_vit-b-16_{tag}.json", "bench_vit-b-16.json"), (f"bench_vit-l-14_{tag}.json", "bench_vit-l-14.json")):
+                 (f"bench_vit-b-16_{tag}.json", "bench_vit-b-16.json"), (f"bench_vit-l-14_{tag}.json", "bench_vit-l-14.json"),
+                 (f"bench_mscoco_{tag}.json", "bench_mscoco.json")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copyfile(os.path.join(G, src), os.path.join(P, dst)); print(dst)
 for d, dst in ((f"prof_bench_{tag}", "bench_default_kernel_stats.csv"), (f"prof_knn_{tag}", "knn_1000000x768_kernel_stats.csv"),
-               (f"prof_vit-b-16_{tag}", "bench_vit-b-16_kernel_stats.csv"), (f"prof_vit-l-14_{tag}", "bench_vit-l-14_kernel_stats.csv")):
+               (f"prof_vit-b-16_{tag}", "bench_vit-b-16_kernel_stats.csv"), (f"prof_vit-l-14_{tag}", "bench_vit-l-14_kernel_stats.csv"),
+               (f"prof_mscoco_{tag}", "bench_mscoco_kernel_stats.csv")):
     f = one(f"{d}/**/*kernel_stats.csv")
     if f:
         shutil.copyfile(f, os.path.join(P, dst)); print(dst)
@@ -72,5 +74,5 @@ if os.path.exists(src):
             with open(os.path.join(P, name), "w", newline="") as f:
                 w = _csv.DictWriter(f, fieldnames=list(sel[0].keys())); w.writeheader(); w.writerows(sel)
             print(name, len(sel), "rows")
-for a in ("vit-b-16", "vit-l-14"):
+for a in ("vit-b-16", "vit-l-14", "mscoco"):
     write_pmc(f"bench_{a}_pmc.csv", [f"pmc_{a}_{c}_{tag}" for c in CS])

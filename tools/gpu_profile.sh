@@ -8,13 +8,13 @@ set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
-TAG=${1:-r4}
+TAG=${1:-r5}
 cd /tmp && export TMPDIR=/tmp
 K1M="--workload knn --knn_n 1000000 --knn_d 768 --steps 1 --warmup 0 --no_cpu_baseline"
-P="--no_cpu_baseline --no_knn_1m --no_f32_gemm_check"
+P="--no_cpu_baseline --no_knn_1m --no_mscoco --no_f32_gemm_check"
 SCAN="k_scan|k_bf16_final|k_neighbors|k_merge"
 ENC="Cijk|k_attention|k_gemm_f16x3t|k_layernorm|k_vision|k_preprocess"
-PART=${PART:-ab}      # a: headline + 1M kNN passes, b: the ViT-B/16 and ViT-L/14 passes (two gpurun calls: each stays inside the 20-minute limit)
+PART=${PART:-abc}     # a: headline + 1M kNN passes, b: the ViT-B/16 and ViT-L/14 passes, c: the full-size mscoco workload (one gpurun call each: inside the 20-minute limit)
 if [[ $PART == *a* ]]; then
 python3 $R/bench.py --steps 2 --warmup 1 > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench_$TAG -- python3 $R/bench.py --steps 2 --warmup 1 $P > $OUT/prof_bench_$TAG.json 2> $OUT/prof_bench_$TAG.err || exit 2
@@ -43,5 +43,15 @@ n=20
     rocprofv3 --pmc $c --kernel-include-regex "$ENC" --output-format csv -d $OUT/pmc_${a}_${t}_$TAG -- python3 $R/bench.py --steps 1 --warmup 0 $A > /dev/null 2> $OUT/pmc_${a}_${t}_$TAG.err || exit $n
   done
 done
+# configs[2] at full size: ViT-B/16, 82 783 + 5 000 + 5 000 image / caption pairs, DB = 50 000-row subset (round 5)
+if [[ $PART == *c* ]]; then
+  C="--workload mscoco --steps 2 --warmup 1"
+  python3 $R/bench.py $C > $OUT/bench_mscoco_$TAG.json 2> $OUT/bench_mscoco_$TAG.err || exit 31
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_mscoco_$TAG -- python3 $R/bench.py --workload mscoco --steps 1 --warmup 1 --no_cpu_baseline > /dev/null 2> $OUT/prof_mscoco_$TAG.err || exit 32
+  for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
+    t=$(echo $c | cut -d' ' -f1)
+    rocprofv3 --pmc $c --kernel-include-regex "$ENC" --output-format csv -d $OUT/pmc_mscoco_${t}_$TAG -- python3 $R/bench.py --workload mscoco --n_train 20000 --db_limit 12000 --steps 1 --warmup 0 --no_cpu_baseline > /dev/null 2> $OUT/pmc_mscoco_${t}_$TAG.err || exit 33
+  done
+fi
 find $OUT -name "*_kernel_trace.csv" -size +20M -delete
 ls $OUT | head -60
