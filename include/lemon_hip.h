@@ -123,8 +123,9 @@ int lemon_preprocess_u8_f16x3t(const uint8_t *img_dev, int64_t batch, int in_h, 
  * accumulate; error vs float64 at the level of the all-fp32 form).  RANGE: |q|, |k|, |v| must stay below 65 520, beyond that
  * the fp16 parts are inf and the result NaN (loud, not wrong); PRECISION: the short kernels (seq_len <= 64) scale lo by 2^11
  * (full relative precision), the general kernel stores lo unscaled (absolute precision 2^-25: values below 2^-3 keep less than
- * 22 bits, still >= 2^-25 absolute).  lemon_attention_set_f16(0) switches the process to v_mfma_f32_32x32x2_f32 for both
- * products (no range limit, the fp32 GEMM modes select it; returns the previous setting); $LEMON_ATTN_F16=0 starts there. */
+ * 22 bits, still >= 2^-25 absolute).  lemon_attention_set_f16(0) switches the CALLING THREAD to v_mfma_f32_32x32x2_f32 for both
+ * products (no range limit, the fp32 GEMM modes select it; returns the thread's previous setting); $LEMON_ATTN_F16=0 starts
+ * every thread there. */
 int lemon_attention_f32(const float *qkv_dev, int64_t batch, int seq_len, int heads, int head_dim,
                         int causal, float *out_dev, void *stream);
 int lemon_attention_set_f16(int on);

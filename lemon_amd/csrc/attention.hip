@@ -728,10 +728,16 @@ __global__ __launch_bounds__(64 * TJ, 3) void k_attention_hd64_short(const float
 
 // Arithmetic of the two products: 1 = split products on the fp16 matrix cores (q, k, v and the probabilities carried as fp16
 // pairs: inputs must stay inside +-65 504, see include/lemon_hip.h), 0 = v_mfma_f32_32x32x2_f32 (no range limit).
-// Process-wide, set by lemon_attention_set_f16 (the host mirror selects it per GEMM mode); $LEMON_ATTN_F16=0 starts with 0.
-static int g_attn_f16 = [] { const char *e = getenv("LEMON_ATTN_F16"); return (e && e[0] == '0') ? 0 : 1; }();
+// Per calling THREAD (round 5: it was one unsynchronised process-wide int, so two embedders in different GEMM modes -- or a bf16x6
+// re-embedding next to an f16x3 pass -- could pick each other's kernel): set by lemon_attention_set_f16, which the host mirror
+// calls in front of every tower pass; $LEMON_ATTN_F16=0 starts every thread with 0.
+static int attn_f16_default() {
+    static const int v = [] { const char *e = getenv("LEMON_ATTN_F16"); return (e && e[0] == '0') ? 0 : 1; }();
+    return v;
+}
+static thread_local int g_attn_f16 = attn_f16_default();
 
-static int g_attn_old_general = 0;      // lemon_attention_set_f16(2): fp16 arithmetic with the FIRST general kernel (tests: bit equality)
+static thread_local int g_attn_old_general = 0;   // lemon_attention_set_f16(2): fp16 arithmetic with the FIRST general kernel (tests: bit equality)
 
 extern "C" int lemon_attention_set_f16(int on) {
     g_attn_old_general = on == 2;

@@ -175,19 +175,20 @@ class gemm_mode_forced:
         return False
 
 
-_attn_f16_state = None
+_attn_f16_state = None            # (kept for callers that reset it; the library is asked every time now)
 
 
 def select_attention_arithmetic(mode):
     """The attention kernels' arithmetic follows the GEMM mode: split products on the fp16 matrix cores with 'f16x3' (inputs
     must stay inside the fp16 range, like the GEMM operands of that mode), v_mfma_f32_32x32x2_f32 with 'bf16x6' (the mode whose
-    point is to have no range limit) and 'f32'.  $LEMON_ATTN_F16=0 keeps the fp32 form in every mode."""
+    point is to have no range limit) and 'f32'.  $LEMON_ATTN_F16=0 keeps the fp32 form in every mode.  The library keeps the
+    selection per calling thread (lemon_attention_set_f16) and this is called in front of every tower pass WITHOUT a host-side
+    cache: a direct lemon_attention_set_f16 call, another embedder or another thread cannot leave a stale choice behind."""
     global _attn_f16_state
     import os
     want = 1 if (mode == "f16x3" and os.environ.get("LEMON_ATTN_F16", "1") != "0") else 0
-    if want != _attn_f16_state:
-        _lib.load().lemon_attention_set_f16(want)
-        _attn_f16_state = want
+    _lib.load().lemon_attention_set_f16(want)
+    _attn_f16_state = want
 
 
 def gemm_mode():

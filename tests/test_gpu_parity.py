@@ -458,6 +458,30 @@ def test_bf16_filter_chunked_database_state_carry(hip, oracle, monkeypatch, d, n
     assert np.array_equal(out[1][1][:512].cpu().numpy(), Ir)
 
 
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+def test_ragged_query_rest_behind_whole_round_chunks_uses_the_split_kernel(hip, oracle, monkeypatch, metric):
+    # 1 M queries leave a ragged rest of 67 panels behind the whole-round chunks; since round 5 it goes through k_scan_f16_qs4 with
+    # the database split between a few workgroups per panel (lemon_search_bf16: rest_splits) and k_merge.  Scaled down: with 256
+    # panels as the QS2 / QS4 entry, 94 536 queries = one whole round of 256 panels + a rest of 114 panels (x 2 splits at 20 000 rows).
+    monkeypatch.setenv("LEMON_QS2_MIN_PANELS", "256")
+    d, n, nq = 512, 20000, 256 * 256 + 29000
+    g = torch.Generator(device="cuda").manual_seed(21)
+    X = hip.normalize_vectors(torch.randn(n, d, generator=g, device="cuda"))
+    Q = hip.normalize_vectors(torch.randn(nq, d, generator=g, device="cuda"))
+    if metric == "l2":
+        X = X * (0.5 + 1.5 * torch.rand(n, 1, generator=g, device="cuda"))
+    out = []
+    for algo in (1, BF16):
+        idx = (hip.IndexFlatIP if metric == "ip" else hip.IndexFlatL2)(d)
+        idx.set_algo(algo)
+        idx.add(X)
+        out.append(idx.search(Q, 51))
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][0], out[1][0])
+    rows = torch.cat([torch.arange(0, 256), torch.arange(nq - 256, nq)])
+    Dr, Ir = oracle.knn(metric, X.cpu().numpy(), Q[rows.cuda()].cpu().numpy(), 51)
+    assert np.array_equal(out[1][1][rows.cuda()].cpu().numpy(), Ir)
+
+
 def test_auto_picks_bf16_on_spread_data_and_f32_on_band_crowded_data(hip):
     g = torch.Generator(device="cuda").manual_seed(3)
     n, nq, d = 65536, 131072, 64

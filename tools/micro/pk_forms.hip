@@ -21,7 +21,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
-// FORM: 0..14 the shipped forms in the order above; 15..17 the banned controls (mul / add / fma with op_sel:[0,1](,0))
+// FORM: 0..14 the shipped forms in the order above; 15..17 the banned controls (mul / add / fma with op_sel:[0,1](,0)); 18..19 the
+// op_sel bit on the other operands (src0 of a multiply, src2 of an fma)
 template <int FORM>
 __device__ __forceinline__ void packed_and_scalar(f32x2 a, f32x2 b, f32x2 c, f32x2 &pk, float &s0, float &s1) {
     const f32x2 bx = {b[0], b[0]}, by = {b[1], b[1]}, ax = {a[0], a[0]}, cx = {c[0], c[0]};
@@ -45,7 +46,9 @@ __device__ __forceinline__ void packed_and_scalar(f32x2 a, f32x2 b, f32x2 c, f32
         case 14: pk = __builtin_elementwise_fma(a, b, cx);     s0 = __builtin_fmaf(a0, b0, c0);   s1 = __builtin_fmaf(a1, b1, c0); break;
         case 15: pk = a * by;                                  s0 = a0 * b1;                      s1 = a1 * b1; break;      // banned: op_sel:[0,1]
         case 16: pk = a + by;                                  s0 = a0 + b1;                      s1 = a1 + b1; break;      // banned
-        default: pk = __builtin_elementwise_fma(a, by, c);     s0 = __builtin_fmaf(a0, b1, c0);   s1 = __builtin_fmaf(a1, b1, c1); break;   // banned
+        case 17: pk = __builtin_elementwise_fma(a, by, c);     s0 = __builtin_fmaf(a0, b1, c0);   s1 = __builtin_fmaf(a1, b1, c1); break;   // banned
+        case 18: pk = by * a;                                  s0 = b1 * a0;                      s1 = b1 * a1; break;      // banned: op_sel:[1,0]
+        default: pk = __builtin_elementwise_fma(a, c, by);     s0 = __builtin_fmaf(a0, c0, b1);   s1 = __builtin_fmaf(a1, c1, b1); break;   // banned: op_sel:[0,0,1]
     }
     asm volatile("" : "+v"(s0), "+v"(s1));
 }
@@ -122,5 +125,7 @@ int main(int argc, char **argv) {
     run<15>(in, bad, iters, "15 BANNED v_pk_mul_f32 op_sel:[0,1]");
     run<16>(in, bad, iters, "16 BANNED v_pk_add_f32 op_sel:[0,1]");
     run<17>(in, bad, iters, "17 BANNED v_pk_fma_f32 op_sel:[0,1,0]");
+    run<18>(in, bad, iters, "18 BANNED v_pk_mul_f32 op_sel on src0");
+    run<19>(in, bad, iters, "19 BANNED v_pk_fma_f32 op_sel on src2");
     return 0;
 }
