@@ -240,7 +240,8 @@ def test_bf16_filter_bit_exact(hip, oracle, metric, nq, n, d, k):
 @pytest.mark.parametrize("qs4", ["1", "0"])
 @pytest.mark.parametrize("metric", ["ip", "l2"])
 @pytest.mark.parametrize("nq,n,d,k", [(300, 2049, 768, 5), (64, 5000, 512, 50), (513, 1300, 300, 51), (1000, 9000, 700, 64),
-                                       (257, 63, 768, 10), (130, 129, 400, 64), (700, 20000, 768, 51), (256, 64 * 7 + 1, 512, 64)])
+                                       (257, 63, 768, 10), (130, 129, 400, 64), (700, 20000, 768, 51), (256, 64 * 7 + 1, 512, 64), (300, 3000, 768, 1),
+                                       (1025, 64 * 9, 640, 2)])
 def test_bf16_two_block_kernel_forced_on_small_shapes(hip, oracle, monkeypatch, metric, nq, n, d, k, qs4):
     # k_scan_f16_qs4 (16x16x32 MFMAs, round 5; LEMON_QS4=0: its predecessor k_scan_bf16_qs2) normally serves >= 196 608 queries;
     # LEMON_QS2_MIN_PANELS=0 puts the oracle-sized cases through them:

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 TAG=${1:-a}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r5_prof_knn_$TAG -- python3 $R/bench.py --workload knn --knn_n 1000000 --knn_d 768 --steps 1 --warmup 0 --no_cpu_baseline > $OUT/r5_prof_knn_$TAG.json 2> $OUT/r5_prof_knn_$TAG.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r5_prof_knn_$TAG -- python3 $R/bench.py --workload knn --knn_n 1000000 --knn_d 768 --steps 1 --warmup 0 --no_cpu_baseline $EXTRA > $OUT/r5_prof_knn_$TAG.json 2> $OUT/r5_prof_knn_$TAG.err || exit 1
 cd $R
 f=$(find $OUT/r5_prof_knn_$TAG -name "*kernel_stats.csv" | head -1); head -6 $f | cut -c1-220
 t=$(find $OUT/r5_prof_knn_$TAG -name "*kernel_trace.csv" | head -1)
