@@ -146,12 +146,13 @@ class Embedder:
                    else "also with range-free operands (bf16x6 GEMMs, fp32 attention): the weights or inputs themselves produce inf / NaN")
             raise FloatingPointError(f"non-finite embeddings (LEMON_GEMM={ops.gemm_mode()}): {how}")
 
-    def _run_batches(self, n, bs, run):
+    def _run_batches(self, n, bs, run, spans=None):
         """torch.cat of run(slice) over the micro-batches of n samples, with the fallback of the class docstring.  `run(sel)` embeds
         the samples `sel` selects (a slice, or a LongTensor of sample indices).  Samples are independent, so what is embedded again
         is the flagged SAMPLES (gathered into sub-batches of at most bs), not their micro-batches: one poisoned image costs one
         image's work, not 5 240."""
-        spans = [(i, min(n, i + bs)) for i in range(0, n, bs)]
+        if spans is None:
+            spans = [(i, min(n, i + bs)) for i in range(0, n, bs)]
         outs = [run(slice(lo, hi)).float() for lo, hi in spans]
         if not outs:
             return None
@@ -169,8 +170,10 @@ class Embedder:
         def redo(rows):
             return torch.cat([run(rows[i:i + bs]).float() for i in range(0, rows.numel(), bs)])
 
+        starts = torch.tensor([lo for lo, _ in spans])
+
         def batches_of(rows):
-            return int(torch.unique(rows // bs).numel())
+            return int(torch.unique(torch.bucketize(rows, starts, right=True)).numel())
 
         if ops.ln_fold_enabled() and ops.mlp_mode() == "block":
             # first the cheap cause: a row beyond the folded LayerNorm's mean bound (NaN row affine) -- the same arithmetic with
@@ -235,9 +238,16 @@ class Embedder:
             eot = ids.argmax(dim=-1).cpu()
         bucketed = eot is not None and hasattr(tower, "seq_len_for")
 
-        perm = None
+        perm = spans = None
         if bucketed and self.length_bucketing and ids.shape[0] > self.text_batch_size:
             perm = torch.argsort(eot, stable=True)           # host: shortest captions first
+            # micro-batches never straddle a token bucket: every caption runs exactly its own bucket's tokens
+            L_sorted = torch.tensor([tower.seq_len_for(int(v)) for v in eot[perm].tolist()])
+            spans, lo = [], 0
+            for Lb, cnt in zip(*[t.tolist() for t in torch.unique_consecutive(L_sorted, return_counts=True)]):
+                for i in range(lo, lo + cnt, self.text_batch_size):
+                    spans.append((i, min(lo + cnt, i + self.text_batch_size)))
+                lo += cnt
 
         def one(sel):
             if perm is not None:                             # sel addresses the length-sorted order
@@ -249,7 +259,7 @@ class Embedder:
                 return self.model.encode_text(rows, seq_len=L)
             return self.model.encode_text(rows)
 
-        e = self._run_batches(ids.shape[0], self.text_batch_size, one)
+        e = self._run_batches(ids.shape[0], self.text_batch_size, one, spans=spans)
         if perm is not None:
             out = torch.empty_like(e)
             out[perm.to(e.device)] = e
