@@ -255,3 +255,63 @@ def test_scan_plan_covers_every_unit_once(panels, tiles):
     work = np.array([segs[sb[b]:sb[b + 1], 2].sum() + 3 * (sb[b + 1] - sb[b]) for b in range(grid)])   # tiles + 3 per segment
     share = (panels * tiles + 3 * len(segs)) / grid
     assert work.max() <= 1.25 * share + tiles * 0 + 8, (work.max(), share)
+
+
+def test_caption_length_bucketing_is_exact_and_cuts_batches_at_bucket_boundaries():
+    # pipeline.Embedder(length_bucketing=True): captions sorted by length, micro-batches cut at the text tower's 8-token bucket
+    # boundaries, every caption run at its own bucket's token count -- exact under the causal mask (run_lemon.py:140-154 pads every
+    # caption to the full context instead).  CPU, tiny model: same embeddings as the plain order, in the caller's order.
+    import torch
+    from lemon_amd.clip import ClipConfig, LemonCLIP
+    from lemon_amd.pipeline import Embedder
+    cfg = ClipConfig.named("tiny")
+    model = LemonCLIP(cfg).eval()
+    g = torch.Generator().manual_seed(3)
+    n = 37
+    length = torch.randint(3, cfg.context_length + 1, (n,), generator=g)
+    ids = torch.zeros((n, cfg.context_length), dtype=torch.long)
+    for i, L in enumerate(length.tolist()):
+        ids[i, :L - 1] = torch.randint(1, cfg.eos_token_id, (L - 1,), generator=g)
+        ids[i, L - 1] = cfg.eos_token_id
+    plain = Embedder(model, torch.device("cpu"), batch_size=4, text_batch_size=5)
+    bucketed = Embedder(model, torch.device("cpu"), batch_size=4, text_batch_size=5, length_bucketing=True)
+    calls = []
+    real = model.encode_text
+    model.encode_text = lambda x, *a, **k: (calls.append((int(x.shape[0]), k.get("seq_len"))), real(x, *a, **k))[1]
+    try:
+        eot = ids.argmax(-1)                                   # (the un-normalised embeddings: normalize_vectors is a GPU kernel)
+        e0 = plain._embed_texts(ids, eot)
+        calls.clear()
+        e1 = bucketed._embed_texts(ids, eot)
+    finally:
+        model.encode_text = real
+    assert float((e0 - e1).abs().max()) < 2e-6
+    # every micro-batch holds captions of ONE bucket, at most text_batch_size of them, and runs exactly that bucket's tokens
+    assert sum(c[0] for c in calls) == n and all(c[0] <= 5 for c in calls)
+    buckets = sorted(model.text.seq_len_for(int(L) - 1) for L in length.tolist())
+    ran = sorted(L for cnt, L in calls for _ in range(cnt))
+    assert ran == buckets
+    assert bucketed.text_tokens_run == sum(buckets) and plain.text_tokens_run >= bucketed.text_tokens_run
+
+
+def test_near_tie_adjudication_names_the_side_that_holds_the_float64_set():
+    # oracle/reference_loop.adjudicate_near_ties (bench.py's cpu_baseline leg, tests/test_gpu_parity.py): two searches that differ
+    # in one row; the float64 top-k over the whole DB decides, the gap is the float64 distance of the rows in dispute
+    import numpy as np
+    from oracle import reference_loop as rl
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((3000, 64)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    q = x[:200].copy()
+    s = q.astype(np.float64) @ x.astype(np.float64).T
+    order = np.argsort(-s, 1)
+    I = order[:, :10].copy()
+    J = I.copy()
+    J[5, 9] = order[5, 10]                                   # row 5 of the second search holds the 11th best instead of the 10th
+    rep = rl.adjudicate_near_ties(q, x, I, J)
+    assert rep["rows_differing"] == 1 and rep["worst_row"] == 5
+    assert rep["rows_a_equals_f64_set"] == 1.0 and abs(rep["rows_b_equals_f64_set"] - 199 / 200) < 1e-12
+    assert abs(rep["max_gap_at_swap"] - (s[5, order[5, 9]] - s[5, order[5, 10]])) < 1e-12
+    # train queries: the self match is left out of the float64 ranking
+    rep = rl.adjudicate_near_ties(q, x, order[:, 1:11], order[:, 1:11], exclude=np.arange(200))
+    assert rep["rows_differing"] == 0 and rep["rows_a_equals_f64_set"] == 1.0
