@@ -1409,9 +1409,6 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
     thk1 = (q0 + qrow0 + 16 < p.b.nq) ? -INFINITY : INFINITY;
     thk2 = (q0 + qrow0 + 32 < p.b.nq) ? -INFINITY : INFINITY;
     thk3 = (q0 + qrow0 + 48 < p.b.nq) ? -INFINITY : INFINITY;
-    // (bit b: the lane's query of group b exists)
-    const unsigned qvalid = (unsigned)(q0 + qrow0 < p.b.nq) | ((unsigned)(q0 + qrow0 + 16 < p.b.nq) << 1) |
-                            ((unsigned)(q0 + qrow0 + 32 < p.b.nq) << 2) | ((unsigned)(q0 + qrow0 + 48 < p.b.nq) << 3);
     if (l2) { qn0 = p.b.qnorm[q0 + qrow0]; qn1 = p.b.qnorm[q0 + qrow0 + 16]; qn2 = p.b.qnorm[q0 + qrow0 + 32]; qn3 = p.b.qnorm[q0 + qrow0 + 48]; }
     if (p.b.splits == 1 && !p.first_chunk) {   // resume from the previous database chunk
         const float *st = p.state + 16 * ((int64_t)blockIdx.x * NT + tid);
@@ -1542,7 +1539,8 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
 #define Q4_ACC(b_) acc[0][b_], acc[1][b_], acc[2][b_], acc[3][b_]
 #define Q4_TH(b_) ((b_) == 0 ? th0 : (b_) == 1 ? th1 : (b_) == 2 ? th2 : th3)
 #define Q4_GMAX(b_, jt_) (__ballot(qs4_group_max<l2>(Q4_ACC(b_), (jt_) + 4u * (unsigned)g4, p.b.xnorm) > Q4_TH(b_)))
-#define Q4_NEED(b_, cc_, cl_, tk_) (((qvalid >> (b_)) & 1u) && ((cc_) - (cl_) >= lim4 || (cc_) > QCAP4 - 16 || ((tk_) == -INFINITY && (cc_) >= 16)))
+    // (a lane whose query does not exist -- the panel's padding -- carries the bound +inf: it never appends, its counts stay 0)
+#define Q4_NEED(b_, cc_, cl_, tk_) ((cc_) - (cl_) >= lim4 || (cc_) > QCAP4 - 16 || ((tk_) == -INFINITY && (cc_) >= 16))
 #define Q4_SLOW(b_, jt_)                                                                                                   \
     do {                                                                                                                   \
         unsigned jb_ = (jt_) + 4u * (unsigned)g4;                                                                          \
@@ -1557,17 +1555,54 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
     // k32 step S (compile-time) of the tile on fragment set S & 1.  In the gaps between its MFMAs: the reads of step S + 1
     // (the next stage's slot once S + 1 starts a stage), in steps 2 and 3 of a stage the DMA pieces of stage t + 3, and in
     // step 0 of a tile the filter of the previous tile (group b in front of group b's first MFMA).
+    // ---- the filter's fast path, one instruction per MFMA gap (inner-product metric) ----
+    // Phase stamps of the first QS4 build (tools/r5_build_phases.sh, 1 M x 768): step 0 of a tile -- 16 MFMAs = 256 cycles -- took 770
+    // with the four groups' maximum trees in front of their MFMAs: everything the wave issues there is on its critical path (one wave
+    // per SIMD), 8 cycles per instruction with the dependent tree levels.  So the maximum of group b is made as a CHAIN of eight
+    // v_max3_f32, one per gap, from the moment the group's last MFMAs of the tile's LAST step have drained (gap G0 = 5 + 4 b behind
+    // MFMA 0 of that step; the chain reads the rows of fragment a = 3, written last, from its sixth link on) into the first step of
+    // the next tile, where the ballot and the branch of group b stand in front of the group's first MFMA (gaps 16 + 4 b).
+#define Q4_V(b_, e_) acc[(e_) >> 2][b_][(e_) & 3]
+#define Q4_TREE1(b_, k_)                                                                                                   \
+    do {                                                                                                                   \
+        float &m_ = (b_) == 0 ? mt0 : (b_) == 1 ? mt1 : (b_) == 2 ? mt2 : mt3;                                             \
+        if ((k_) == 0)      asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(m_) : "v"(Q4_V(b_, 0)), "v"(Q4_V(b_, 1)), "v"(Q4_V(b_, 2))); \
+        else if ((k_) < 7)  asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(m_) : "v"(Q4_V(b_, 2 * (k_) + 1)), "v"(Q4_V(b_, (2 * (k_) + 2) & 15))); \
+        else if ((k_) == 7) asm volatile("v_max3_f32 %0, %0, %1, %1" : "+v"(m_) : "v"(Q4_V(b_, 15)));                      \
+        else {                                                                                                             \
+            const u64 bl_ = __ballot(m_ > Q4_TH(b_));                                                                      \
+            if ((b_) == 0) pm0 = bl_; else if ((b_) == 1) pm1 = bl_; else if ((b_) == 2) pm2 = bl_; else pm3 = bl_;        \
+        }                                                                                                                  \
+    } while (0)
+    // gap g_ (0..15: behind MFMA g_ of the tile's last step; 16..31: behind MFMA g_ - 16 of the next tile's first step)
+#define Q4_TREES(g_)                                                                                                       \
+    do {                                                                                                                   \
+        if ((g_) >= 5 && (g_) <= 13)  Q4_TREE1(0, (g_) - 5);                                                               \
+        if ((g_) >= 9 && (g_) <= 17)  Q4_TREE1(1, (g_) - 9);                                                               \
+        if ((g_) >= 13 && (g_) <= 21) Q4_TREE1(2, (g_) - 13);                                                              \
+        if ((g_) >= 17 && (g_) <= 25) Q4_TREE1(3, (g_) - 17);                                                              \
+    } while (0)
+
     // (written out slot by slot, no loop for hipcc to unroll: where it declined to -- the L2 instantiation at pitch 512 once --
     // the fragment registers of in-flight asm reads were copied around a 16-way switch; tests/test_build_guard.py)
 #define Q4_SLOT(S, i_)                                                                                                     \
     do {                                                                                                                   \
         if ((S) == 0 && ((i_) & 3) == 0 && do_filter) {                                                                    \
-            if ((i_) == 0)  { pm0 = Q4_GMAX(0, jprev); pm1 = Q4_GMAX(1, jprev); if (pm0) Q4_SLOW(0, jprev); }              \
-            if ((i_) == 4)  { pm2 = Q4_GMAX(2, jprev); if (pm1) Q4_SLOW(1, jprev); }                                       \
-            if ((i_) == 8)  { pm3 = Q4_GMAX(3, jprev); if (pm2) Q4_SLOW(2, jprev); }                                       \
-            if ((i_) == 12) { if (pm3) Q4_SLOW(3, jprev); }                                                                \
+            if (l2) {   /* (the L2 filter -- |x|^2 loads, proxy transform -- stays in front of its group's first MFMA) */       \
+                if ((i_) == 0)  { pm0 = Q4_GMAX(0, jprev); pm1 = Q4_GMAX(1, jprev); if (pm0) Q4_SLOW(0, jprev); }          \
+                if ((i_) == 4)  { pm2 = Q4_GMAX(2, jprev); if (pm1) Q4_SLOW(1, jprev); }                                   \
+                if ((i_) == 8)  { pm3 = Q4_GMAX(3, jprev); if (pm2) Q4_SLOW(2, jprev); }                                   \
+                if ((i_) == 12) { if (pm3) Q4_SLOW(3, jprev); }                                                            \
+            } else {    /* (the group maxima were made between the MFMAs of the previous step and of this one: Q4_TREES) */    \
+                if ((i_) == 0  && pm0) Q4_SLOW(0, jprev);                                                                  \
+                if ((i_) == 4  && pm1) Q4_SLOW(1, jprev);                                                                  \
+                if ((i_) == 8  && pm2) Q4_SLOW(2, jprev);                                                                  \
+                if ((i_) == 12 && pm3) Q4_SLOW(3, jprev);                                                                  \
+            }                                                                                                              \
         }                                                                                                                  \
         Q4_MF((S) & 1, S, i_);                                                                                             \
+        if (!l2 && (S) == NS - 1) Q4_TREES(i_);                                                                            \
+        if (!l2 && (S) == 0) Q4_TREES(16 + (i_));                                                                          \
         if ((i_) == RD0) Q4_LOADA(((S) & 1) ^ 1, ((S) + 1) % NS, 0);                                                       \
         if ((i_) == RD0 + RDS) Q4_LOADA(((S) & 1) ^ 1, ((S) + 1) % NS, 1);                                                 \
         if ((i_) == RD0 + 2 * RDS) Q4_LOADA(((S) & 1) ^ 1, ((S) + 1) % NS, 2);                                             \
@@ -1590,9 +1625,11 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
         if (((S) & 3) == 1) {                                                                                              \
             /* stage t + 1 has landed (this wave's pieces: at most the four of stage t + 2 may still be in flight; younger */ \
             /* appends only make the wait longer), then the rendezvous: everybody's pieces, and everybody is done with stage t - 1 */ \
+            Q4_PH_BEGIN();                                                                                                 \
             if (t + 2 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                            \
             else               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
             __builtin_amdgcn_s_barrier();                                                                                  \
+            Q4_PH_END(3);                                                                                                  \
         }                                                                                                                  \
     } while (0)
 
@@ -1601,30 +1638,56 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
         Q4_LOADA(0, 0, 0); Q4_LOADA(0, 0, 1); Q4_LOADA(0, 0, 2); Q4_LOADA(0, 0, 3);
     }
     // (stages written out with literal indices: fragment homes and offsets are template / immediate operands)
+#ifdef LEMON_QS4_PHASES
+    // diagnostic build (tools/r5_build_phases.sh; results unchanged, timing +~10 %): shader-cycle sums per wave 0 of every workgroup --
+    // [0] whole loop, [1] step 0 of every tile (the 16 init MFMAs + the previous tile's filter), [2] maintain(), [3] the wait +
+    // barrier of every stage, [4] tiles, [5] tiles whose filter took a slow path, [6] tiles with a compaction
+    unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_ = 0, pl_ = __builtin_amdgcn_s_memtime();
+#define Q4_PH_BEGIN() do { pt_ = __builtin_amdgcn_s_memtime(); } while (0)
+#define Q4_PH_END(i_) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_[i_] += n_ - pt_; pt_ = n_; } while (0)
+#else
+#define Q4_PH_BEGIN() do { } while (0)
+#define Q4_PH_END(i_) do { } while (0)
+#endif
 #define Q4_STAGE(K)                                                                                                        \
     do {                                                                                                                   \
         const int t = jl * KT2 + (K);                                                                                      \
         const bool more = t + 3 < total;                                                                                   \
+        if ((K) == 0) Q4_PH_BEGIN();                                                                                       \
         Q4_STEP(4 * (K) + 0);                                                                                              \
-        if ((K) == 0 && todo) maintain(todo);                                                                              \
+        if ((K) == 0) Q4_PH_END(1);                                                                                        \
+        if ((K) == 0 && todo) { maintain(todo); Q4_PH_END(2); }                                                            \
         Q4_STEP(4 * (K) + 1);                                                                                              \
         Q4_STEP(4 * (K) + 2);                                                                                              \
         Q4_STEP(4 * (K) + 3);                                                                                              \
     } while (0)
+    u64 pm0 = 0, pm1 = 0, pm2 = 0, pm3 = 0;     // a group's pass mask (ballot of "my maximum beats my bound"), made by Q4_TREES / Q4_GMAX
+    float mt0 = 0.f, mt1 = 0.f, mt2 = 0.f, mt3 = 0.f;
     for (int jl = 0; jl < ntile; ++jl) {
         const float *xt = xbase + (int64_t)jl * RT2 * dpad;
         const bool do_filter = filter_on && jl > 0;
         const unsigned jprev = (unsigned)(t_begin + jl - 1) * RT2;
         u64 todo = 0;
-        u64 pm0 = 0, pm1 = 0, pm2 = 0, pm3 = 0;
         Q4_STAGE(0); Q4_STAGE(1); Q4_STAGE(2); Q4_STAGE(3);
         if constexpr (KT2 > 4) { Q4_STAGE(4); Q4_STAGE(5); }
+#ifdef LEMON_QS4_PHASES
+        ph_[4] += 1; ph_[5] += (pm0 | pm1 | pm2 | pm3) != 0; ph_[6] += todo != 0;
+#endif
         static_assert(KT2 == 4 || KT2 == 6, "stages per tile written out for d = 512 and d = 768");
     }
 #undef Q4_STAGE
+#undef Q4_PH_BEGIN
+#undef Q4_PH_END
     Q4_WAIT(0);                                 // (the reads the last step issued for a tile that does not exist: retired, unused)
+#ifdef LEMON_QS4_PHASES
+    ph_[0] = __builtin_amdgcn_s_memtime() - pl_;
+    if (p.phase_dbg && tid == 0) { for (int i_ = 0; i_ < 7; ++i_) atomicAdd(&p.phase_dbg[i_], ph_[i_]); }
+#endif
 #undef Q4_STEP
 #undef Q4_SLOT
+#undef Q4_TREES
+#undef Q4_TREE1
+#undef Q4_V
 #undef Q4_MF
 #undef Q4_WAIT
 #undef Q4_LOADP
@@ -2122,8 +2185,22 @@ int lemon_search_bf16(lemon_index_t *idx, const float *q_dev, int64_t nq, int k,
             const double bytes = 2.0 * d * ((double)nq_pad / BQ * rows) + (p.last_chunk ? 2.0 * d * cn + 12.0 * k * (double)cn : 0.0);
             LemonProfScope prof(idx, stream, flops, bytes);
             if (qs4) {
+#ifdef LEMON_QS4_PHASES
+                static unsigned long long *dbg4 = nullptr;
+                if (!dbg4) { (void)hipMalloc(&dbg4, 64); }
+                (void)hipMemsetAsync(dbg4, 0, 64, stream);
+                p.phase_dbg = dbg4;
+#endif
                 if (l2m) launch_qs4<true>(dpad_h / BKH, grid, stream, p);
                 else     launch_qs4<false>(dpad_h / BKH, grid, stream, p);
+#ifdef LEMON_QS4_PHASES
+                (void)hipStreamSynchronize(stream);
+                unsigned long long h4[8];
+                (void)hipMemcpy(h4, dbg4, 64, hipMemcpyDeviceToHost);
+                fprintf(stderr, "[qs4 phases] grid=%u tiles/wg=%.0f loop=%.4g cyc/wg  step0=%.1f%% (%.0f cyc/tile) maintain=%.1f%% sync=%.1f%% (%.0f cyc/tile)  tiles with slow path %.1f%%, with compaction %.2f%%\n",
+                        grid, (double)h4[4] / grid, (double)h4[0] / grid, 100.0 * h4[1] / h4[0], (double)h4[1] / (double)h4[4], 100.0 * h4[2] / h4[0],
+                        100.0 * h4[3] / h4[0], (double)h4[3] / (double)h4[4], 100.0 * h4[5] / (double)h4[4], 100.0 * h4[6] / (double)h4[4]);
+#endif
                 if (p.last_chunk) launch_final();
                 continue;
             }
