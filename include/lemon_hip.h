@@ -144,7 +144,8 @@ int lemon_layernorm_f32(const float *x_dev, const float *weight_dev, const float
 /* Token assembly of the towers, one pass each instead of torch's cat / gather + add (+ LayerNorm):
  *   vision (HF CLIPVisionEmbeddings + pre_layrnorm; lib/models/chexzero_clip.py:243-249):
  *     y[b,0] = LN(cls + pos[0]),  y[b,1+p] = LN(patches[b,p] + pos[1+p]);  patches_dev [batch, n_tokens-1, width] is the
- *     patch-embedding GEMM's output, y_dev [batch, n_tokens, width];
+ *     patch-embedding GEMM's output, y_dev [batch, n_tokens, width]; ln_weight_dev = ln_bias_dev = NULL: no LayerNorm (timm's
+ *     VisionTransformer._pos_embed has none: norm_pre is the identity in BiomedCLIP's vit_base_patch16_224);
  *   text (token + position embedding, chexzero_clip.py:363-365): y[b,t] = tok_emb[ids[b,t]] + pos[t] for t < seq_len;
  *     ids_dev int64 with row pitch ids_pitch >= seq_len (the caller's [batch, context] id matrix, truncated in place). */
 int lemon_vision_tokens_ln(const float *patches_dev, const float *cls_dev, const float *pos_dev,
@@ -171,6 +172,11 @@ int lemon_text_tokens(const int64_t *ids_dev, int64_t ids_pitch, const float *to
  * (tools/tune_gemms.py), never the inference path's. */
 #define LEMON_ACT_NONE 0
 #define LEMON_ACT_SILU 1
+/* the exact GELU u/2 (1 + erf(u / sqrt 2)) of the towers of open_clip's BiomedCLIP (lib/models/utils.py:72-78: timm
+ * vit_base_patch16_224 blocks and the PubMedBERT layers both use nn.GELU).  In the library GEMMs it runs as one in-place pass
+ * behind the bias epilogue (hipBLASLt's own GELU epilogue is the tanh approximation); in lemon_linear_f16x3t(_ln) it rides in
+ * the operand epilogue like SiLU. */
+#define LEMON_ACT_GELU 2
 int lemon_linear_f32(const float *x_dev, const float *w_dev, const float *bias_dev, const float *residual_dev,
                      int64_t m, int n, int k, float alpha, int act, float *y_dev, void *stream);
 
@@ -221,6 +227,7 @@ int lemon_attention_f16x3(const float *qkv_dev, int64_t batch, int seq_len, int 
  *     act = LEMON_ACT_NONE, out_operand = 0:  out_dev fp32 [m, n] = alpha * x W^T + bias (+ residual)          (fc2)
  *     act = LEMON_ACT_SILU, out_operand = 1:  out_dev = the activation operand (k' = n) of silu(alpha * x W^T + bias)   (fc1:
  *         the [m, n] fp32 tensor and the split pass over it never exist)
+ *     act = LEMON_ACT_GELU, out_operand = 1:  the same with the exact GELU (BiomedCLIP's towers)
  * with n a multiple of 256 and k a multiple of 16; the caller folds 1 / wscale into alpha.  Results are independent of a row's
  * position in the batch (fixed k order, no split-k).  lemon_unpack_act_f16x3t turns an activation operand back into fp32
  * (hi + lo 2^-11; tests). */

@@ -115,9 +115,13 @@ def split_weight_cached(owner, name, w, ops, mode):
 
 
 class Block(nn.Module):
-    def __init__(self, cfg: TowerConfig, eps):
+    def __init__(self, cfg: TowerConfig, eps, act="quick_gelu"):
         super().__init__()
+        assert act in ("quick_gelu", "gelu")
         self.heads = cfg.heads
+        # 'quick_gelu': z sigmoid(1.702 z) (CLIP, chexzero_clip.py:186-188); 'gelu': the exact one (timm's ViT blocks inside
+        # open_clip's BiomedCLIP, lib/models/utils.py:72-78)
+        self.act = act
         self.ln1 = nn.LayerNorm(cfg.width, eps=eps)
         self.qkv = nn.Linear(cfg.width, 3 * cfg.width)
         self.out = nn.Linear(cfg.width, cfg.width)
@@ -151,16 +155,21 @@ class Block(nn.Module):
                 a, x = a[rows].contiguous(), x[rows].contiguous()
             x = ops.linear(a, self.out.weight, self.out.bias, residual=x)
             # QuickGELU(z) = silu(1.702 z) / 1.702: scale going in (alpha, bias), un-scale in fc2's alpha
-            s = ops.QUICK_GELU_SCALE
-            h = ops.linear(ln(self.ln2, x), self.fc1.weight, self._fc1_bias_scaled(s), act="silu", alpha=s)
+            s, act = self._act_scale(ops)
+            h = ops.linear(ln(self.ln2, x), self.fc1.weight, self._fc1_bias_scaled(s), act=act, alpha=s)
             return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=x, alpha=1.0 / s)
         a = self._sdpa(self.qkv(self.ln1(x)), B, L, W, causal)
         if rows is not None:
             a, x = a[rows], x[rows]
         x = x + self.out(a)
         h = self.fc1(self.ln2(x))
-        h = h * torch.sigmoid(1.702 * h)          # QuickGELU
+        h = h * torch.sigmoid(1.702 * h) if self.act == "quick_gelu" else F.gelu(h)
         return x + self.fc2(h)
+
+    def _act_scale(self, ops):
+        """(s, epilogue name): fc1 runs as act(s (x W^T + b)) and fc2 with alpha / s -- QuickGELU(z) = silu(1.702 z) / 1.702;
+        the exact GELU needs no scale."""
+        return (ops.QUICK_GELU_SCALE, "silu") if self.act == "quick_gelu" else (1.0, "gelu")
 
     def _fc1_bias_scaled(self, s):
         """fc1.bias * s (the QuickGELU scale folded into the SiLU epilogue's input), made once per bias version."""
@@ -175,12 +184,12 @@ class Block(nn.Module):
     def _mlp_hand(self, x, ops, W, mlp):
         """x + fc2(QuickGELU(fc1(LayerNorm(x)))) in the hand-written GEMM (gemm_f16x3.hip): LayerNorm writes the tile-major
         operand, fc1's epilogue applies bias + QuickGELU + the fp16 split and stores fc2's operand, fc2 adds bias and residual."""
-        s = ops.QUICK_GELU_SCALE
+        s, act = self._act_scale(ops)
         m = x.numel() // W
         w1, a1 = self._w_tiled("fc1", ops)
         w2, a2 = self._w_tiled("fc2", ops)
         at = ops.layer_norm_t(x, self.ln2.weight, self.ln2.bias, self.ln2.eps)
-        ht = ops.linear_t(at, w1, m, mlp, W, self._fc1_bias_scaled(s), act="silu", alpha=s * a1)
+        ht = ops.linear_t(at, w1, m, mlp, W, self._fc1_bias_scaled(s), act=act, alpha=s * a1)
         return ops.linear_t(ht, w2, m, W, mlp, self.fc2.bias, residual=x, alpha=a2 / s, out_shape=x.shape)
 
     def _w_split(self, name, ops, mode):
@@ -240,12 +249,12 @@ class Block(nn.Module):
             a6 = ops.split_operand(a, mode)
         w, a_ = self._w_split("out", ops, mode)
         x = ops.linear_split(a6, w, self.out.bias, residual=x, alpha=a_)
-        s = ops.QUICK_GELU_SCALE
+        s, act = self._act_scale(ops)
         if hand in ("block", "fused") and ops.mlp_fused_supported(W, mlp):
             return self._mlp_hand(x, ops, W, mlp)
         w, a_ = self._w_split("fc1", ops, mode)
         h = ops.linear_split(ops.layer_norm_split(x, self.ln2.weight, self.ln2.bias, self.ln2.eps, mode), w,
-                             self._fc1_bias_scaled(s), act="silu", alpha=s * a_)
+                             self._fc1_bias_scaled(s), act=act, alpha=s * a_)
         # fc2: one split pass over the [m, mlp] activations (bf16x6: 16 B per element, ~330 us at the headline shape) buys a
         # GEMM of 1 268 us instead of 1 590 us in the tuner -- and 1 820 us inside the step, where the fp32 GEMMs run at lower
         # clocks than in isolation while the 16-bit ones do not: 17.3 k against 16.7 k scores/s on the same box (twice,
@@ -291,9 +300,9 @@ class Block(nn.Module):
         x, xt, st = ops.linear_t_ln(ops.attention_t(qkv, self.heads, causal), wo, m, W, W, self.out.bias, residual=x, alpha=ao,
                                     out_shape=x.shape, emit=True)
         aff = ops.ln_finalize(st, m, W, self.ln2.eps)
-        s = ops.QUICK_GELU_SCALE
+        s, act = self._act_scale(ops)
         w1, a1, cs1, b1 = self._w_tiled_ln("fc1", self.ln2, ops, s)
-        ht = ops.linear_t_ln(xt, w1, m, mlp, W, b1, act="silu", alpha=s * a1, row_aff=aff, colsum=cs1)
+        ht = ops.linear_t_ln(xt, w1, m, mlp, W, b1, act=act, alpha=s * a1, row_aff=aff, colsum=cs1)
         w2, a2 = self._w_tiled("fc2", ops)
         if not emit:
             return ops.linear_t(ht, w2, m, W, mlp, self.fc2.bias, residual=x, alpha=a2 / s, out_shape=x.shape), None
@@ -306,19 +315,40 @@ class Block(nn.Module):
 
 
 class VisionTower(nn.Module):
-    def __init__(self, cfg: ClipConfig):
+    """CLIP's ViT (HF CLIPVisionTransformer / chexzero_clip.py:226-260).  With act='gelu', patch_bias=True, pre_ln=False it is
+    timm's `vit_base_patch16_224` as open_clip wraps it for BiomedCLIP (lemon_amd/biomed.py): a convolution bias, no LayerNorm
+    in front of the blocks, exact GELU -- same token layout, same pre-LN blocks, CLS pooling behind the final norm."""
+
+    def __init__(self, cfg, act="quick_gelu", patch_bias=False, pre_ln=True, eps=None):
         super().__init__()
         v = cfg.vision
-        self.patch = nn.Conv2d(3, v.width, cfg.patch_size, cfg.patch_size, bias=False)
+        eps = cfg.layer_norm_eps if eps is None else eps
+        self.patch = nn.Conv2d(3, v.width, cfg.patch_size, cfg.patch_size, bias=patch_bias)
         n_pos = (cfg.image_size // cfg.patch_size) ** 2 + 1
         self.cls = nn.Parameter(torch.zeros(v.width))
         self.pos = nn.Parameter(torch.zeros(n_pos, v.width))
-        self.pre_ln = nn.LayerNorm(v.width, eps=cfg.layer_norm_eps)
-        self.blocks = nn.ModuleList([Block(v, cfg.layer_norm_eps) for _ in range(v.layers)])
-        self.post_ln = nn.LayerNorm(v.width, eps=cfg.layer_norm_eps)
+        self.pre_ln = nn.LayerNorm(v.width, eps=eps) if pre_ln else None
+        self.blocks = nn.ModuleList([Block(v, eps, act) for _ in range(v.layers)])
+        self.post_ln = nn.LayerNorm(v.width, eps=eps)
         self.proj = nn.Linear(v.width, cfg.embed_dim, bias=False)
 
+    def _pos_for_gemm(self):
+        """The position embedding the token-assembly kernel adds behind a patch-embedding GEMM: with a convolution bias (timm)
+        the bias rides on the patch tokens' rows (the GEMM paths run the convolution without it), once per parameter version."""
+        if self.patch.bias is None:
+            return self.pos
+        key = (self.pos.data_ptr(), self.pos._version, self.patch.bias.data_ptr(), self.patch.bias._version)
+        cache = self.__dict__.setdefault("_split_cache", {})
+        hit = cache.get("pos_bias")
+        if hit is None or hit[0] != key:
+            pos = self.pos.detach().clone()
+            pos[1:] += self.patch.bias.detach()
+            hit = (key, pos)
+            cache["pos_bias"] = hit
+        return hit[1]
+
     def forward(self, pixel_values):
+        conv = False
         if hasattr(pixel_values, "at"):
             # data.PatchOperand: the patch rows are already the tile-major fp16 operand (lemon_preprocess_u8_f16x3t) -- the patch
             # embedding runs in the hand-written GEMM, no fp32 pixel tensor and no split pass exist
@@ -348,13 +378,19 @@ class VisionTower(nn.Module):
                 x = ops.linear(pixel_values, w)
         else:
             x = self.patch(pixel_values.to(self.patch.weight.dtype)).flatten(2).transpose(1, 2)
+            conv = True                                   # (the convolution added its own bias)
+        pos = self.pos if conv else self._pos_for_gemm()
         fused = x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.shape[-1] % 4 == 0
-        if fused:     # class token + position embedding + pre-LayerNorm in one pass over the token matrix
+        if fused:     # class token + position embedding (+ pre-LayerNorm) in one pass over the token matrix
             from . import ops
-            x = ops.vision_tokens_ln(x, self.cls, self.pos, self.pre_ln.weight, self.pre_ln.bias, self.pre_ln.eps)
+            if self.pre_ln is not None:
+                x = ops.vision_tokens_ln(x, self.cls, pos, self.pre_ln.weight, self.pre_ln.bias, self.pre_ln.eps)
+            else:
+                x = ops.vision_tokens_ln(x, self.cls, pos, None, None)
         else:
-            x = torch.cat([self.cls.expand(x.shape[0], 1, -1), x], dim=1) + self.pos
-            x = self.pre_ln(x)
+            x = torch.cat([self.cls.expand(x.shape[0], 1, -1), x], dim=1) + pos
+            if self.pre_ln is not None:
+                x = self.pre_ln(x)
         carry = None
         for b in self.blocks[:-1]:
             x, carry = b.forward_chain(x, causal=False, carry=carry)
@@ -375,6 +411,10 @@ class TextTower(nn.Module):
         self.blocks = nn.ModuleList([Block(t, cfg.layer_norm_eps) for _ in range(t.layers)])
         self.final_ln = nn.LayerNorm(t.width, eps=cfg.layer_norm_eps)
         self.proj = nn.Linear(t.width, cfg.embed_dim, bias=False)
+
+    def last_token_index(self, input_ids):
+        """a caption's EOT position = argmax of its ids (EOT has the largest id: chexzero_clip.py:374-376)"""
+        return input_ids.argmax(dim=-1)
 
     def seq_len_for(self, eot_max):
         """Token count the tower runs for a batch whose last EOT sits at `eot_max`: the longest prompt rounded up
@@ -559,15 +599,18 @@ class SyntheticTokenizer:
     Callable like the reference uses it: tokenizer(list[str], padding="max_length", truncation=True)
     -> {"input_ids": [[...]], "attention_mask": [[...]]}  (run_lemon.py:151-154)."""
 
-    def __init__(self, vocab_size=49408, context_length=77, eos_token_id=49407):
+    def __init__(self, vocab_size=49408, context_length=77, eos_token_id=49407, sot_token_id=None, word_ids=None):
         self.vocab_size, self.context_length, self.eos = vocab_size, context_length, eos_token_id
-        self.sot = eos_token_id - 1
+        self.sot = eos_token_id - 1 if sot_token_id is None else sot_token_id
+        # word ids fall into [lo, hi): below the SOT / EOT pair by default (CLIP: they are the two largest ids)
+        self.word_ids = (1, self.sot) if word_ids is None else word_ids
 
     def _word_id(self, w):
         h = 2166136261
         for ch in w.lower().encode("utf-8"):
             h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
-        return 1 + h % (self.sot - 1)
+        lo, hi = self.word_ids
+        return lo + h % (hi - lo)
 
     def __call__(self, texts, padding="max_length", truncation=True, **_):
         ids, mask = [], []
@@ -604,8 +647,10 @@ def algorithm_class_from_scratch(name, text_base_name="openai/clip-vit-base-patc
     in-tree branches; the reference hard-codes the authors' cluster paths, :20-25), or 'random[:arch]' for seeded
     random weights.  Tokenizer: the HF tokenizer files of the checkpoint directory when present, else a CLIP BPE
     built from a user-supplied merges file (`bpe_path` / $LEMON_BPE_PATH), else -- random weights only -- the
-    hash-based SyntheticTokenizer.  'biomed_clip' (open_clip BiomedCLIP: a PubMedBERT text tower + WordPiece) is a
-    different model family and is refused."""
+    hash-based SyntheticTokenizer.
+      'biomed_clip'                  open_clip's BiomedCLIP (:72-78): same calling convention as the in-tree branches;
+                                     `text_base_name` = a local copy of the hub snapshot (open_clip_pytorch_model.bin + vocab.txt)
+                                     or 'random[:biomed-tiny]'; WordPiece vocabulary from there, `bpe_path` or $LEMON_VOCAB_PATH."""
     rand = str(text_base_name).startswith("random")
     parts = str(text_base_name).split(":")
     if name == "huggingface_clip":
@@ -657,9 +702,29 @@ def algorithm_class_from_scratch(name, text_base_name="openai/clip-vit-base-patc
                                     "supply its merges file with --bpe_path or LEMON_BPE_PATH")
         return model, tok
     if name == "biomed_clip":
-        raise NotImplementedError(
-            "clip_model='biomed_clip' (lib/models/utils.py:72-79) is open_clip's BiomedCLIP: a PubMedBERT text tower with a "
-            "WordPiece tokenizer, loaded from the HF hub -- not a CLIP-architecture checkpoint; not available in this build")
+        # lib/models/utils.py:72-78: open_clip's BiomedCLIP (timm ViT-B/16 + PubMedBERT, lemon_amd/biomed.py); tokenizer(texts)
+        # -> LongTensor [n, 256], model.encode_text(tokens) (run_lemon.py:148-160)
+        from .biomed import BiomedCLIP, BiomedConfig
+        from .tokenizer import BertWordPiece, find_vocab_file
+        if rand:
+            model = BiomedCLIP(BiomedConfig.named(arch or (parts[1] if len(parts) > 1 else "biomed")))
+        else:
+            model = BiomedCLIP.from_pretrained(text_base_name)
+        if not return_tokenizer:
+            return model
+        vf = find_vocab_file(bpe_path) or (None if rand else find_vocab_file(text_base_name))
+        if vf is not None:
+            tok = BertWordPiece.from_file(vf, model.cfg.context_length)
+            if len(tok.vocab) > model.cfg.vocab_size:
+                raise ValueError(f"{vf!r} holds {len(tok.vocab)} tokens, the model's embedding {model.cfg.vocab_size}")
+        elif rand:
+            # hash-based stand-in with BERT's framing: [CLS] = 2, [SEP] = 3, [PAD] = 0 (synthetic runs only)
+            syn = SyntheticTokenizer(model.cfg.vocab_size, model.cfg.context_length, eos_token_id=3, sot_token_id=2,
+                                     word_ids=(4, model.cfg.vocab_size))
+            tok = lambda texts: torch.tensor(syn(texts)["input_ids"], dtype=torch.long)
+        else:
+            raise FileNotFoundError(f"no vocab.txt beside {text_base_name!r}: supply the BERT vocabulary with --bpe_path or LEMON_VOCAB_PATH")
+        return model, tok
     raise NotImplementedError(name)
 
 

@@ -41,6 +41,13 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
         v[i] = c < nch ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
+    float4 *yr = reinterpret_cast<float4 *>(y + row * (int64_t)width);
+    if (w == nullptr) {                                   // (kernel-uniform) token assembly only: no LayerNorm in front of the blocks
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (lane + 64 * i < nch) yr[lane + 64 * i] = v[i];
+        return;
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     const float mean = s / (float)width;
@@ -57,7 +64,6 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
     const float rstd = rsqrtf(q / (float)width + eps);
     const float4 *w4 = reinterpret_cast<const float4 *>(w);
     const float4 *b4 = reinterpret_cast<const float4 *>(b);
-    float4 *yr = reinterpret_cast<float4 *>(y + row * (int64_t)width);
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
         const int c = lane + 64 * i;
@@ -309,7 +315,8 @@ extern "C" int lemon_vision_tokens_ln(const float *patches_dev, const float *cls
                                       int n_tokens, int width, float *y_dev, void *stream_) {
     LEMON_REQUIRE(batch >= 0 && n_tokens >= 2 && width > 0 && (width & 3) == 0 && width <= 2048, "batch >= 0, n_tokens >= 2, width % 4 == 0, <= 2048");
     if (batch == 0) return LEMON_OK;
-    LEMON_REQUIRE(patches_dev && cls_dev && pos_dev && ln_weight_dev && ln_bias_dev && y_dev, "null pointer");
+    LEMON_REQUIRE(patches_dev && cls_dev && pos_dev && y_dev, "null pointer");
+    LEMON_REQUIRE((ln_weight_dev != nullptr) == (ln_bias_dev != nullptr), "LayerNorm weight and bias come together (both null: no LayerNorm)");
     hipStream_t stream = (hipStream_t)stream_;
     const dim3 grid((unsigned)((batch * n_tokens + 3) / 4)), block(256);
 #define LAUNCH(CH) hipLaunchKernelGGL(k_vision_tokens_ln<CH>, grid, block, 0, stream, patches_dev, cls_dev, pos_dev, ln_weight_dev, \

@@ -52,7 +52,7 @@ struct GemmParams {
     const char *at, *wt;       // tile-major operands
     const float *bias;         // [n] or null
     const float *residual;     // [m, n] fp32 or null (EPI 0)
-    void *out;                 // EPI 0: fp32 [m, n]; EPI 1: tile-major activation operand of the next GEMM (its k = n)
+    void *out;                 // EPI 0: fp32 [m, n]; EPI 1 / 2: tile-major activation operand of the next GEMM (its k = n)
     int64_t m;
     int n, ks, m_tiles, n_tiles;
     int gm, gn;                // super-block of the tile walk: gm m-tiles x gn n-tiles per XCD at a time
@@ -96,7 +96,16 @@ __device__ __forceinline__ h16x8 lds128(unsigned addr, int off) {
     return v;
 }
 
-// EPI 0: fp32 row-major (+ residual); EPI 1: SiLU, fp16 split, tile-major operand
+// The operand epilogues' activation.  EPI 1: SiLU u sigmoid(u) (v_exp_f32 / v_rcp_f32: 1 ulp each) -- QuickGELU with the 1.702
+// folded into alpha and the bias by the caller; EPI 2: the exact GELU u Phi(u) = u/2 (1 + erf(u / sqrt 2)) of the BERT / timm
+// towers (open_clip BiomedCLIP, lib/models/utils.py:72-78; ocml's erff: a few ulp)
+template <int EPI>
+__device__ __forceinline__ float epilogue_act(float u) {
+    if (EPI == 2) return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f));
+    return u * __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+}
+
+// EPI 0: fp32 row-major (+ residual); EPI 1 / 2: SiLU / GELU, fp16 split, tile-major operand
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t(GemmParams p) {
                 h16x4 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v = o[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-o[e]));      // SiLU (v_exp_f32 / v_rcp_f32: 1 ulp each)
+                    const float v = epilogue_act<EPI>(o[e]);
                     unsigned short a_, b_, c_;
                     split2h<false>(v, a_, b_, c_);
                     hi[e] = __builtin_bit_cast(_Float16, a_); lo[e] = __builtin_bit_cast(_Float16, c_);
@@ -710,7 +719,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
             h16x4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float v = o[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-o[e]));
+                const float v = epilogue_act<EPI>(o[e]);
                 unsigned short a_, b_, c_;
                 split2h<false>(v, a_, b_, c_);
                 hi[e] = __builtin_bit_cast(_Float16, a_); lo[e] = __builtin_bit_cast(_Float16, c_);
@@ -855,8 +864,8 @@ static int linear_f16x3t_impl(const uint16_t *at_dev, const uint16_t *wt_dev, co
     LEMON_REQUIRE(((((uintptr_t)row_aff_dev) | ((uintptr_t)colsum_dev) | ((uintptr_t)emit_t_dev) | ((uintptr_t)emit_stats_dev)) & 15) == 0, "16-byte aligned pointers");
     LEMON_REQUIRE(((((uintptr_t)at_dev) | ((uintptr_t)wt_dev) | ((uintptr_t)out_dev) | ((uintptr_t)bias_dev) | ((uintptr_t)residual_dev)) & 15) == 0,
                   "16-byte aligned pointers");
-    LEMON_REQUIRE((act == LEMON_ACT_NONE && !out_operand) || (act == LEMON_ACT_SILU && out_operand && !residual_dev),
-                  "supported forms: act none -> fp32 [m, n] (+ residual); act SiLU -> tile-major operand (no residual)");
+    LEMON_REQUIRE((act == LEMON_ACT_NONE && !out_operand) || ((act == LEMON_ACT_SILU || act == LEMON_ACT_GELU) && out_operand && !residual_dev),
+                  "supported forms: act none -> fp32 [m, n] (+ residual); act SiLU / GELU -> tile-major operand (no residual)");
     LEMON_REQUIRE((m + TM - 1) / TM < ((int64_t)1 << 24), "m < 2^31");
     GemmParams p;
     p.at = reinterpret_cast<const char *>(at_dev); p.wt = reinterpret_cast<const char *>(wt_dev);
@@ -898,6 +907,9 @@ static int linear_f16x3t_impl(const uint16_t *at_dev, const uint16_t *wt_dev, co
             LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<0, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<2, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             g_attr_set[dev] = true;
         }
     }
@@ -920,15 +932,19 @@ static int linear_f16x3t_impl(const uint16_t *at_dev, const uint16_t *wt_dev, co
     }
     if (ev0) LEMON_HIP_CHECK(hipEventRecord(ev0, (hipStream_t)stream_));
     const bool fold = row_aff_dev != nullptr, emit = emit_t_dev != nullptr;
+    const bool gelu = act == LEMON_ACT_GELU;
     if (fold || emit) {
-        if (fold && out_operand) hipLaunchKernelGGL((k_gemm_f16x3t16<1, true, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+        if (fold && out_operand && gelu) hipLaunchKernelGGL((k_gemm_f16x3t16<2, true, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+        else if (fold && out_operand) hipLaunchKernelGGL((k_gemm_f16x3t16<1, true, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
         else if (fold) hipLaunchKernelGGL((k_gemm_f16x3t16<0, true, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
         else hipLaunchKernelGGL((k_gemm_f16x3t16<0, false, true>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
     } else if (mf16) {
-        if (out_operand) hipLaunchKernelGGL((k_gemm_f16x3t16<1, false, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+        if (out_operand && gelu) hipLaunchKernelGGL((k_gemm_f16x3t16<2, false, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+        else if (out_operand) hipLaunchKernelGGL((k_gemm_f16x3t16<1, false, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
         else hipLaunchKernelGGL((k_gemm_f16x3t16<0, false, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
     } else {
-        if (out_operand) hipLaunchKernelGGL(k_gemm_f16x3t<1>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+        if (out_operand && gelu) hipLaunchKernelGGL(k_gemm_f16x3t<2>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+        else if (out_operand) hipLaunchKernelGGL(k_gemm_f16x3t<1>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
         else hipLaunchKernelGGL(k_gemm_f16x3t<0>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
     }
     LEMON_HIP_CHECK(hipGetLastError());

@@ -378,6 +378,19 @@ int recorded_agrees(Problem &p, const hipblasLtMatmulAlgo_t &rec, const hipblasL
     return ok && h[1] == 0 ? 1 : 0;
 }
 
+// y <- y/2 (1 + erf(y / sqrt 2)), four values per thread (the tail one by one)
+__global__ __launch_bounds__(256) void k_gelu_inplace(float *__restrict__ y, int64_t total) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < total && (((uintptr_t)y) & 15) == 0) {
+        float4 v = *reinterpret_cast<float4 *>(y + i);
+        v.x = 0.5f * v.x * (1.0f + erff(v.x * 0.70710678118654752f)); v.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752f));
+        v.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752f)); v.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752f));
+        *reinterpret_cast<float4 *>(y + i) = v;
+    } else {
+        for (int64_t j = i; j < total && j < i + 4; ++j) y[j] = 0.5f * y[j] * (1.0f + erff(y[j] * 0.70710678118654752f));
+    }
+}
+
 }  // namespace
 
 extern "C" int lemon_linear_set_tuning(int enabled) {
@@ -389,7 +402,7 @@ extern "C" int lemon_linear_set_tuning(int enabled) {
 static int linear_impl(int dt, const void *x_dev, const void *w_dev, const float *bias_dev, const float *residual_dev,
                        int64_t m, int n, int k, float alpha, int act, float *y_dev, void *stream_) {
     LEMON_REQUIRE(m >= 0 && n > 0 && k > 0, "m >= 0, n > 0, k > 0");
-    LEMON_REQUIRE(act == LEMON_ACT_NONE || act == LEMON_ACT_SILU, "act must be LEMON_ACT_NONE or LEMON_ACT_SILU");
+    LEMON_REQUIRE(act == LEMON_ACT_NONE || act == LEMON_ACT_SILU || act == LEMON_ACT_GELU, "act must be LEMON_ACT_NONE, _SILU or _GELU");
     LEMON_REQUIRE(!(act != LEMON_ACT_NONE && residual_dev), "activation and residual cannot be combined");
     if (m == 0) return LEMON_OK;
     LEMON_REQUIRE(x_dev && w_dev && y_dev, "null pointer");
@@ -446,6 +459,12 @@ static int linear_impl(int dt, const void *x_dev, const void *w_dev, const float
     const float *c = residual_dev ? residual_dev : y_dev;
     LT_CHECK(hipblasLtMatmul(g_lin.handle, p.desc, &alpha, w_dev, p.la, x_dev, p.lb, &beta, c, p.lc, y_dev, p.lc, &algo,
                              g_lin.ws, g_lin.ws_bytes, stream));
+    if (act == LEMON_ACT_GELU) {
+        // exact (erf) GELU as one in-place pass behind the bias epilogue: the library's GELU epilogue is the tanh approximation
+        const int64_t total = m * (int64_t)n;
+        hipLaunchKernelGGL(k_gelu_inplace, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, stream, y_dev, total);
+        LEMON_HIP_CHECK(hipGetLastError());
+    }
     return LEMON_OK;
 }
 

@@ -102,7 +102,8 @@ def grid_f1(rec, y, hparams, xtol=1e-8, maxfun=500, return_scores=False):
 
 
 ATTENTION_MAX_SEQ = 288
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+_ACT_CODE = {None: ACT_NONE, "silu": ACT_SILU, "gelu": ACT_GELU}      # 'gelu': the exact (erf) GELU of BiomedCLIP's towers
 QUICK_GELU_SCALE = 1.702
 _linear_tuned_loaded = set()      # device indices whose per-device hipBLASLt state has the recorded choices
 
@@ -126,7 +127,8 @@ def _ensure_linear_tuned(lib, device):
 
 def linear(x, weight, bias=None, residual=None, act=None, alpha=1.0):
     """y = act(alpha * x @ weight.T + bias) (+ residual) in ONE hipBLASLt GEMM (SiLU / residual add ride
-    in the epilogue).  x [..., k] float32 CUDA, weight [n, k]; act in (None, 'silu')."""
+    in the epilogue; 'gelu', the exact one, is an in-place pass behind it).  x [..., k] float32 CUDA, weight [n, k]; act in
+    (None, 'silu', 'gelu')."""
     assert x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
     x = x.contiguous()
     weight = weight.contiguous()
@@ -142,7 +144,7 @@ def linear(x, weight, bias=None, residual=None, act=None, alpha=1.0):
         bias = bias.contiguous()
     lib = _lib.load()
     _ensure_linear_tuned(lib, x.device)
-    code = {None: ACT_NONE, "silu": ACT_SILU}[act]
+    code = _ACT_CODE[act]
     with torch.cuda.device(x.device):
         _lib.check(lib.lemon_linear_f32(ptr(x), ptr(weight), ptr(bias) if bias is not None else None,
                                         ptr(residual) if residual is not None else None, m, n, k, float(alpha), code, ptr(y),
@@ -278,7 +280,7 @@ def linear_split(xs, ws, bias=None, residual=None, act=None, alpha=1.0):
         bias = bias.contiguous()
     lib = _lib.load()
     _ensure_linear_tuned(lib, xs.device)
-    code = {None: ACT_NONE, "silu": ACT_SILU}[act]
+    code = _ACT_CODE[act]
     fn, name = (lib.lemon_linear_bf16x6, "lemon_linear_bf16x6") if xs.dtype == torch.bfloat16 else (lib.lemon_linear_f16x3, "lemon_linear_f16x3")
     with torch.cuda.device(xs.device):
         _lib.check(fn(ptr(xs), ptr(ws), ptr(bias) if bias is not None else None, ptr(residual) if residual is not None else None,
@@ -344,13 +346,13 @@ def layer_norm_t(x, weight, bias, eps=1e-5):
 
 def linear_t(at, wt, m, n, k, bias=None, residual=None, act=None, alpha=1.0, out_shape=None):
     """lemon_linear_f16x3t on tile-major operands: act None -> float32 [m, n] (view `out_shape`) = alpha x W^T + bias (+ residual);
-    act 'silu' -> the tile-major activation operand (k' = n) of silu(alpha x W^T + bias)."""
+    act 'silu' / 'gelu' -> the tile-major activation operand (k' = n) of act(alpha x W^T + bias)."""
     assert at.is_cuda and at.dtype == torch.float16 and wt.dtype == torch.float16
     assert at.numel() == _tiled_rows(m) * k * 2 and wt.numel() == n * k * 2
     lib = _lib.load()
     if bias is not None:
         bias = bias.contiguous()
-    if act == "silu":
+    if act in ("silu", "gelu"):
         assert residual is None
         out = torch.empty((_tiled_rows(m) * n * 2,), dtype=torch.float16, device=at.device)
     else:
@@ -363,7 +365,7 @@ def linear_t(at, wt, m, n, k, bias=None, residual=None, act=None, alpha=1.0, out
     with torch.cuda.device(at.device):
         _lib.check(lib.lemon_linear_f16x3t(ptr(at), ptr(wt), ptr(bias) if bias is not None else None,
                                            ptr(residual) if residual is not None else None, m, n, k, float(alpha),
-                                           ACT_SILU if act == "silu" else ACT_NONE, int(act == "silu"), ptr(out), stream_ptr(at.device)),
+                                           _ACT_CODE[act], int(act is not None), ptr(out), stream_ptr(at.device)),
                    "lemon_linear_f16x3t")
     return out
 
@@ -454,7 +456,7 @@ def linear_t_ln(at, wt, m, n, k, bias=None, residual=None, act=None, alpha=1.0, 
     lib = _lib.load()
     if bias is not None:
         bias = bias.contiguous()
-    if act == "silu":
+    if act in ("silu", "gelu"):
         assert residual is None and not emit
         out = torch.empty((_tiled_rows(m) * n * 2,), dtype=torch.float16, device=at.device)
     else:
@@ -474,7 +476,7 @@ def linear_t_ln(at, wt, m, n, k, bias=None, residual=None, act=None, alpha=1.0, 
     with torch.cuda.device(at.device):
         _lib.check(lib.lemon_linear_f16x3t_ln(ptr(at), ptr(wt), ptr(bias) if bias is not None else None,
                                               ptr(residual) if residual is not None else None, m, n, k, float(alpha),
-                                              ACT_SILU if act == "silu" else ACT_NONE, int(act == "silu"), ptr(out),
+                                              _ACT_CODE[act], int(act is not None), ptr(out),
                                               ptr(row_aff) if row_aff is not None else None, ptr(colsum) if colsum is not None else None,
                                               ptr(et) if emit else None, ptr(st) if emit else None, stream_ptr(at.device)),
                    "lemon_linear_f16x3t_ln")
@@ -531,15 +533,17 @@ def layer_norm(x, weight, bias, eps=1e-5):
 
 
 def vision_tokens_ln(patches, cls, pos, ln_weight, ln_bias, eps=1e-5):
-    """[B, nP, W] patch embeddings -> pre-LayerNormed token matrix [B, nP+1, W] (class token + positions) in one pass."""
+    """[B, nP, W] patch embeddings -> pre-LayerNormed token matrix [B, nP+1, W] (class token + positions) in one pass;
+    ln_weight = ln_bias = None: token assembly without the LayerNorm (timm ViT)."""
     assert patches.is_cuda and patches.dtype == torch.float32 and patches.dim() == 3
     patches = patches.contiguous()
     B, nP, W = patches.shape
     y = torch.empty((B, nP + 1, W), dtype=torch.float32, device=patches.device)
     lib = _lib.load()
     with torch.cuda.device(patches.device):
-        _lib.check(lib.lemon_vision_tokens_ln(ptr(patches), ptr(cls.contiguous()), ptr(pos.contiguous()), ptr(ln_weight.contiguous()),
-                                              ptr(ln_bias.contiguous()), float(eps), B, nP + 1, W, ptr(y),
+        _lib.check(lib.lemon_vision_tokens_ln(ptr(patches), ptr(cls.contiguous()), ptr(pos.contiguous()),
+                                              ptr(ln_weight.contiguous()) if ln_weight is not None else None,
+                                              ptr(ln_bias.contiguous()) if ln_bias is not None else None, float(eps), B, nP + 1, W, ptr(y),
                                               stream_ptr(patches.device)), "lemon_vision_tokens_ln")
     return y
 

@@ -219,7 +219,7 @@ class Embedder:
 
     @torch.no_grad()
     def embed_texts(self, input_ids):
-        eot = None if input_ids.is_cuda else input_ids.argmax(dim=-1)       # host ids: EOT positions without a sync
+        eot = None if input_ids.is_cuda else self._last_token(input_ids)    # host ids: EOT positions without a sync
         input_ids = input_ids.to(self.device)
         if self.text_dedup:
             uniq, inv = torch.unique(input_ids, dim=0, return_inverse=True)
@@ -228,6 +228,12 @@ class Embedder:
             e = self._embed_texts(input_ids, eot)
         return ops.normalize_vectors(self._note(e)) if e.shape[0] else e              # :163 / :230-232
 
+    def _last_token(self, ids):
+        """per-row index of the caption's last token: the EOT of the CLIP towers (the largest id, chexzero_clip.py:374-376), the
+        last non-pad token of a BERT tower (lemon_amd/biomed.py)"""
+        tower = getattr(self.model, "text", None)
+        return tower.last_token_index(ids) if hasattr(tower, "last_token_index") else ids.argmax(dim=-1)
+
     def _embed_texts(self, ids, eot=None):
         """ids on the device; eot = per-row EOT position on the HOST (one transfer for the whole array instead of a
         device sync per micro-batch) from which each micro-batch's bucketed token count is taken."""
@@ -235,11 +241,14 @@ class Embedder:
             return torch.empty((0, self.model.cfg.embed_dim), device=self.device)
         tower = getattr(self.model, "text", None)
         if eot is None and hasattr(tower, "seq_len_for"):
-            eot = ids.argmax(dim=-1).cpu()
+            eot = self._last_token(ids).cpu()
         bucketed = eot is not None and hasattr(tower, "seq_len_for")
+        # a tower without a padding mask in its kernels (BERT: bidirectional attention) runs every caption at exactly its own
+        # length: its micro-batches must be single-length groups, so its captions are always sorted
+        exact = bucketed and getattr(tower, "exact_lengths", False)
 
         perm = spans = None
-        if bucketed and self.length_bucketing and ids.shape[0] > self.text_batch_size:
+        if bucketed and (exact or (self.length_bucketing and ids.shape[0] > self.text_batch_size)):
             perm = torch.argsort(eot, stable=True)           # host: shortest captions first
             # micro-batches never straddle a token bucket: every caption runs exactly its own bucket's tokens
             L_sorted = torch.tensor([tower.seq_len_for(int(v)) for v in eot[perm].tolist()])
@@ -256,6 +265,8 @@ class Embedder:
             if bucketed:
                 L = tower.seq_len_for(int(eot[sel].max()))
                 self.text_tokens_run += int(L) * int(rows.shape[0])
+                if exact:
+                    return self.model.encode_text(rows, seq_len=L, lengths=eot[sel] + 1)
                 return self.model.encode_text(rows, seq_len=L)
             return self.model.encode_text(rows)
 

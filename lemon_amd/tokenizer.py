@@ -170,3 +170,138 @@ def find_bpe_file(hint=None):
         elif os.path.exists(cand):
             return cand
     return None
+
+
+# ---- BERT WordPiece: the tokenizer of the `biomed_clip` branch (lib/models/utils.py:74; run_lemon.py:148-149) ------------------
+# open_clip's `get_tokenizer('hf-hub:microsoft/BiomedCLIP-...')` is an HFTokenizer around the checkpoint's BERT uncased
+# tokenizer, called as `tokenizer(texts)` -> LongTensor [n, 256]: whitespace-cleaned text, [CLS] pieces [SEP], cut to the
+# context length ([SEP] kept last), padded with [PAD].  The algorithm is the published BERT one (BasicTokenizer: clean, CJK
+# spacing, lower-case + accent stripping, punctuation split; then greedy longest-match-first WordPiece with '##' continuations),
+# restated here from its description; tests/test_biomed.py compares it with `transformers.BertTokenizer`, token for token.  The vocabulary (vocab.txt of the checkpoint) is DATA the user supplies.
+import unicodedata
+
+
+def _is_punct(ch):
+    cp = ord(ch)
+    if 33 <= cp <= 47 or 58 <= cp <= 64 or 91 <= cp <= 96 or 123 <= cp <= 126:
+        return True
+    return unicodedata.category(ch).startswith("P")
+
+
+def _is_cjk(cp):
+    return (0x4E00 <= cp <= 0x9FFF or 0x3400 <= cp <= 0x4DBF or 0x20000 <= cp <= 0x2A6DF or 0x2A700 <= cp <= 0x2B73F
+            or 0x2B740 <= cp <= 0x2B81F or 0x2B820 <= cp <= 0x2CEAF or 0xF900 <= cp <= 0xFAFF or 0x2F800 <= cp <= 0x2FA1F)
+
+
+class BertWordPiece:
+    """tokenizer(texts, context_length=None) -> LongTensor [n, context_length] (open_clip HFTokenizer.__call__)."""
+
+    def __init__(self, vocab, context_length=256, lower_case=True, max_chars_per_word=100):
+        self.vocab = dict(vocab) if isinstance(vocab, dict) else {t: i for i, t in enumerate(vocab)}
+        self.context_length, self.lower_case, self.max_chars = context_length, lower_case, max_chars_per_word
+        for t in ("[PAD]", "[UNK]", "[CLS]", "[SEP]"):
+            if t not in self.vocab:
+                raise ValueError(f"vocabulary lacks {t}")
+        self.pad, self.unk, self.cls, self.sep = (self.vocab[t] for t in ("[PAD]", "[UNK]", "[CLS]", "[SEP]"))
+        self.never_split = {"[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"}
+
+    @classmethod
+    def from_file(cls, path, context_length=256, lower_case=True):
+        with open(path, encoding="utf-8") as f:
+            toks = [l.rstrip("\n") for l in f]
+        while toks and toks[-1] == "":
+            toks.pop()
+        return cls(toks, context_length, lower_case)
+
+    # -- BasicTokenizer --
+    def _clean(self, text):
+        out = []
+        for ch in text:
+            cp = ord(ch)
+            cat = unicodedata.category(ch)
+            if cp == 0 or cp == 0xFFFD or (cat.startswith("C") and ch not in "\t\n\r"):
+                continue
+            out.append(" " if ch in " \t\n\r" or cat == "Zs" else ch)
+        return "".join(out)
+
+    def _split_word(self, w):
+        if self.lower_case and w not in self.never_split:
+            w = "".join(c for c in unicodedata.normalize("NFD", w.lower()) if unicodedata.category(c) != "Mn")
+        if w in self.never_split:
+            return [w]
+        parts, cur = [], ""
+        for ch in w:
+            if _is_punct(ch):
+                if cur:
+                    parts.append(cur)
+                parts.append(ch)
+                cur = ""
+            else:
+                cur += ch
+        if cur:
+            parts.append(cur)
+        return parts
+
+    def basic(self, text):
+        text = self._clean(text)
+        text = "".join(f" {c} " if _is_cjk(ord(c)) else c for c in text)
+        text = unicodedata.normalize("NFC", text)
+        return [p for w in text.split() for p in self._split_word(w)]
+
+    def wordpiece(self, word):
+        if len(word) > self.max_chars:
+            return [self.unk]
+        ids, start = [], 0
+        while start < len(word):
+            end, hit = len(word), None
+            while start < end:
+                piece = ("##" if start else "") + word[start:end]
+                if piece in self.vocab:
+                    hit = self.vocab[piece]
+                    break
+                end -= 1
+            if hit is None:
+                return [self.unk]
+            ids.append(hit)
+            start = end
+        return ids
+
+    def encode(self, text):
+        """ids without the special tokens"""
+        return [i for w in self.basic(text) for i in self.wordpiece(w)]
+
+    @staticmethod
+    def clean_text(text):
+        # open_clip's default `clean='whitespace'`: basic_clean (ftfy.fix_text when importable, html.unescape twice) + whitespace
+        # collapse -- ftfy skipped when absent, as for the CLIP BPE above
+        try:
+            import ftfy
+            text = ftfy.fix_text(text)
+        except ImportError:
+            pass
+        text = html.unescape(html.unescape(text)).strip()
+        return " ".join(text.split())
+
+    def __call__(self, texts, context_length=None):
+        import torch
+        if isinstance(texts, str):
+            texts = [texts]
+        ctx = context_length or self.context_length
+        out = torch.full((len(texts), ctx), self.pad, dtype=torch.long)
+        for r, t in enumerate(texts):
+            ids = [self.cls] + self.encode(self.clean_text(str(t)))[:ctx - 2] + [self.sep]
+            out[r, :len(ids)] = torch.tensor(ids, dtype=torch.long)
+        return out
+
+
+def find_vocab_file(hint=None):
+    """vocab.txt of a BERT tokenizer: `hint` (file, or a directory holding it), else $LEMON_VOCAB_PATH."""
+    for h in (hint, os.environ.get("LEMON_VOCAB_PATH")):
+        if not h:
+            continue
+        if os.path.isfile(h) and not h.endswith((".bin", ".pt", ".safetensors")):
+            return h
+        d = h if os.path.isdir(h) else os.path.dirname(h)
+        if d and os.path.isfile(os.path.join(d, "vocab.txt")):
+            return os.path.join(d, "vocab.txt")
+    return None

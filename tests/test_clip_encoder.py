@@ -67,8 +67,10 @@ def test_factory_surface():
     assert hasattr(model, "encode_text") and hasattr(model, "encode_image")
     out = tok(["a b c"], padding="max_length", truncation=True)
     assert set(out) >= {"input_ids", "attention_mask"} and len(out["input_ids"][0]) == 16
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(FileNotFoundError):                 # (the biomed_clip branch: tests/test_biomed.py)
         algorithm_class_from_scratch("biomed_clip", "x", None)
+    with pytest.raises(NotImplementedError):
+        algorithm_class_from_scratch("medclip", "x", None)
     with pytest.raises(FileNotFoundError):
         algorithm_class_from_scratch("huggingface_clip", "openai/clip-vit-base-patch32", None)
 
@@ -104,7 +106,7 @@ def test_openai_format_loader_matches_reference_clip(name):
 
 def test_in_tree_branches_of_the_factory(tmp_path):
     """algorithm_class_from_scratch for the in-tree CLIP branches (lib/models/utils.py:82-103): tokenizer -> LongTensor,
-    encode_text(tokens); a checkpoint of the wrong architecture is refused; biomed_clip is refused."""
+    encode_text(tokens); a checkpoint of the wrong architecture is refused; an unknown branch is refused."""
     from tests.encoder_recipe import CONFIGS, openai_state_dict
     model, tok = algorithm_class_from_scratch("cc3m_clip_from_scratch", "random:tiny", None, return_tokenizer=True)
     t = tok(["a b c", "d"])
@@ -117,4 +119,4 @@ def test_in_tree_branches_of_the_factory(tmp_path):
     with pytest.raises(ValueError):
         algorithm_class_from_scratch("chexzero", str(path), None)
     with pytest.raises(NotImplementedError):
-        algorithm_class_from_scratch("biomed_clip", "x", None)
+        algorithm_class_from_scratch("finetune", "x", None)
