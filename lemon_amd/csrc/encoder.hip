@@ -41,13 +41,6 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
         v[i] = c < nch ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
-    float4 *yr = reinterpret_cast<float4 *>(y + row * (int64_t)width);
-    if (w == nullptr) {                                   // (kernel-uniform) token assembly only: no LayerNorm in front of the blocks
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-            if (lane + 64 * i < nch) yr[lane + 64 * i] = v[i];
-        return;
-    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     const float mean = s / (float)width;
@@ -64,6 +57,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ x, 
     const float rstd = rsqrtf(q / (float)width + eps);
     const float4 *w4 = reinterpret_cast<const float4 *>(w);
     const float4 *b4 = reinterpret_cast<const float4 *>(b);
+    float4 *yr = reinterpret_cast<float4 *>(y + row * (int64_t)width);
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
         const int c = lane + 64 * i;
@@ -259,6 +253,13 @@ __global__ __launch_bounds__(256) void k_vision_tokens_ln(const float *__restric
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    if (w == nullptr) {                                   // (kernel-uniform) token assembly only: no LayerNorm in front of the blocks
+        float4 *yo = reinterpret_cast<float4 *>(y + row * (int64_t)width);
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (lane + 64 * i < nch) yo[lane + 64 * i] = v[i];
+        return;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
