@@ -117,7 +117,15 @@ def test_full_size_biomedclip_vs_hf(hip):
     _check(ours.encode_image(px.cuda()).cpu(), ref_i, "full/image")
     _check(ours.encode_text(ids.cuda()).cpu(), ref_t, "full/text")
     from lemon_amd import ops
-    assert ours.text.blocks[0].chain_supported(torch.empty(2, 17, 768, device="cuda")) and ops.gemm_mode() == "f16x3"
+    with torch.no_grad():       # (the default mode ran the folded hand-written chain, not the library form)
+        assert ours.text.blocks[0].chain_supported(torch.empty(2, 17, 768, device="cuda")) and ops.gemm_mode() == "f16x3"
+    ops.gemm_profiling(True)
+    try:
+        ours.encode_text(ids[2:3].cuda())
+        torch.cuda.synchronize()
+        assert ops.gemm_profile_read()["launches"] == 4 * 12        # QKV, output projection, fc1, fc2 of every layer
+    finally:
+        ops.gemm_profiling(False)
 
 
 def test_embedder_runs_every_caption_at_its_own_length(hip):
