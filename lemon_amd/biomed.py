@@ -132,7 +132,7 @@ class BertLayer(Block):
 
     def forward_chain(self, x, carry, last=False):
         """x = LN_prev(y_prev) in fp32; carry = (y_prev as the tile-major operand, its rows' (rstd, -mean rstd), LN_prev): QKV
-        folds LN_prev.  -> (x_out, carry_out); `last`: fc2 leaves no operand behind."""
+        folds LN_prev.  -> (x_out, carry_out); `last`: -> ([B, W] rows of the [CLS] token, None)."""
         from . import ops
         B, L, W = x.shape
         m, mlp = B * L, self.fc1.weight.shape[0]
@@ -140,6 +140,14 @@ class BertLayer(Block):
         yt, aff, ln_prev = carry
         wq, aq, csq, bq = self._w_tiled_ln("qkv", ln_prev, ops, 1.0)
         qkv = ops.linear_t_ln(yt, wq, m, 3 * W, W, bq, alpha=aq, out_shape=(B, L, 3 * W), row_aff=aff, colsum=csq)
+        if last:
+            # the tower reads the [CLS] row only: attention still sees every token's keys and values, the output projection and
+            # the MLP (3/4 of the layer's GEMM work, all row-wise) run for that row alone -- in the library form, B rows
+            a = ops.attention(qkv, self.heads, False)[:, 0].contiguous()
+            x = x[:, 0].contiguous()
+            x = ops.layer_norm(self._gemm(a, "out", ops, "f16x3", residual=x), self.ln1.weight, self.ln1.bias, self.ln1.eps)
+            h = self._gemm(x, "fc1", ops, "f16x3", act="gelu")
+            return ops.layer_norm(self._gemm(h, "fc2", ops, "f16x3", residual=x), self.ln2.weight, self.ln2.bias, self.ln2.eps), None
         wo, ao = self._w_tiled("out", ops)
         y, yt, st = ops.linear_t_ln(ops.attention_t(qkv, self.heads, False), wo, m, W, W, self.out.bias, residual=x, alpha=ao,
                                     out_shape=x.shape, emit=True)
@@ -147,9 +155,6 @@ class BertLayer(Block):
         w1, a1, cs1, b1 = self._w_tiled_ln("fc1", self.ln1, ops, 1.0)
         ht = ops.linear_t_ln(yt, w1, m, mlp, W, b1, act="gelu", alpha=a1, row_aff=ops.ln_finalize(st, m, W, self.ln1.eps), colsum=cs1)
         w2, a2 = self._w_tiled("fc2", ops)
-        if last:
-            y = ops.linear_t(ht, w2, m, W, mlp, self.fc2.bias, residual=x, alpha=a2, out_shape=x.shape)
-            return ops.layer_norm(y, self.ln2.weight, self.ln2.bias, self.ln2.eps), None
         y, yt, st = ops.linear_t_ln(ht, w2, m, W, mlp, self.fc2.bias, residual=x, alpha=a2, out_shape=x.shape, emit=True)
         return (ops.layer_norm(y, self.ln2.weight, self.ln2.bias, self.ln2.eps),
                 (yt, ops.ln_finalize(st, m, W, self.ln2.eps), self.ln2))
@@ -215,7 +220,6 @@ class BertTextTower(nn.Module):
             carry = ops.rowstats_t(e, ln.eps) + (ln,)
             for i, b in enumerate(self.blocks):
                 x, carry = b.forward_chain(x, carry, last=i == n - 1)
-            x = x[:, 0].contiguous()
         else:
             for b in self.blocks[:-1]:
                 x = b(x)
