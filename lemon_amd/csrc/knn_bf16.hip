@@ -1211,6 +1211,12 @@ __device__ __forceinline__ void qs4_dma_piece(const float *__restrict__ src, uns
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(src), "s"(lds_bytes) : "memory");
 }
 
+// the same with the source's constant part in the instruction's offset field (one SGPR pair serves the four pieces of a stage)
+template <int SRC_OFF>
+__device__ __forceinline__ void qs4_dma_piece_off(const float *__restrict__ src, unsigned lds_bytes, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" : : "v"(voff), "s"(src), "s"(lds_bytes), "n"(SRC_OFF) : "memory");
+}
+
 __device__ __forceinline__ unsigned append_slot4(int cnt) {      // (see append_slot: a broken invariant must not leave the list)
     return (unsigned)cnt < (unsigned)(QCAP4 - 1) ? (unsigned)cnt : (unsigned)(QCAP4 - 1);
 }
@@ -1608,9 +1614,10 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
         if ((i_) == RD0 + 2 * RDS) Q4_LOADA(((S) & 1) ^ 1, ((S) + 1) % NS, 2);                                             \
         if ((i_) == RD0 + 3 * RDS) Q4_LOADA(((S) & 1) ^ 1, ((S) + 1) % NS, 3);                                             \
         if ((i_) == RD0 + 4 * RDS) Q4_LOADP(((S) & 1) ^ 1, ((S) + 1) % NS);                                                \
-        if (((S) & 3) >= 2 && ((i_) == DM0 || (i_) == DM1) && more) {                                                      \
-            constexpr int kn_ = (S) / 4 + 3;                                                                               \
-            Q4_PIECE(xt + (int64_t)(kn_ / KT2) * RT2 * dpad, kn_ % KT2, (t + 3) & (NB - 1), 2 * (((S) & 3) - 2) + ((i_) == DM1)); \
+        if (((S) & 3) >= 2 && ((i_) == DM0 || (i_) == DM1)) {                                                              \
+            /* piece pc of stage t + 3: (add,) M0, nop, load -- source and destination base were made per stage */          \
+            constexpr int pc_ = 2 * (((S) & 3) - 2) + ((i_) == DM1);                                                       \
+            qs4_dma_piece_off<(pc_ >> 1) * BK * 4>(ssrc_, pc_ == 0 ? sl0_ : pc_ == 1 ? sl1_ : pc_ == 2 ? sl2_ : sl3_, (pc_ & 1) ? voff1 : voff0); \
         }                                                                                                                  \
     } while (0)
 #define Q4_STEP(S)                                                                                                         \
@@ -1652,7 +1659,15 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
 #define Q4_STAGE(K)                                                                                                        \
     do {                                                                                                                   \
         const int t = jl * KT2 + (K);                                                                                      \
-        const bool more = t + 3 < total;                                                                                   \
+        /* stage t + 3's pieces (issued in steps 2, 3): ALWAYS issued -- behind the end of the launch they re-fetch the launch's  \
+           first stage into a ring slot nobody reads any more -- so that no branch stands between the MFMAs; source pointer and    \
+           the four LDS destinations live in SGPRs from here (made once per stage, not per piece) */                             \
+        const float *ssrc_ = (t + 3 < total) ? xt + (int64_t)(((K) + 3) / KT2) * RT2 * dpad + 2 * (((K) + 3) % KT2) * BK : xbase; \
+        unsigned sl0_ = lds0 + (unsigned)(((t + 3) & (NB - 1)) * STG * 4);                                                 \
+        asm volatile("" : "+s"(ssrc_), "+s"(sl0_));     /* (three SGPRs: the kernel has none to spare for all four destinations) */ \
+        /* (pieces 2, 3 carry the k-slice's 128 source bytes in the instruction's offset field, and LDS-DMA adds that field to   \
+           the LDS address as well: their M0 is 128 short) */                                                                  \
+        const unsigned sl1_ = sl0_ + 1024u, sl2_ = sl0_ + (unsigned)(RT2 * BK * 4 - BK * 4), sl3_ = sl0_ + (unsigned)(RT2 * BK * 4 - BK * 4) + 1024u; \
         if ((K) == 0) Q4_PH_BEGIN();                                                                                       \
         Q4_STEP(4 * (K) + 0);                                                                                              \
         if ((K) == 0) Q4_PH_END(1);                                                                                        \
@@ -1679,6 +1694,7 @@ __global__ __launch_bounds__(NT, 1) void k_scan_f16_qs4(ScanParamsH p) {
 #undef Q4_PH_BEGIN
 #undef Q4_PH_END
     Q4_WAIT(0);                                 // (the reads the last step issued for a tile that does not exist: retired, unused)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (and the pieces issued behind the end of the launch)
 #ifdef LEMON_QS4_PHASES
     ph_[0] = __builtin_amdgcn_s_memtime() - pl_;
     if (p.phase_dbg && tid == 0) { for (int i_ = 0; i_ < 7; ++i_) atomicAdd(&p.phase_dbg[i_], ph_[i_]); }
