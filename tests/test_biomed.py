@@ -105,6 +105,7 @@ def test_embedder_groups_captions_by_exact_length(monkeypatch):
     _, _, ours = hf_pair("tiny", seed=7)
     emb = Embedder.__new__(Embedder)
     emb.model, emb.device, emb.text_batch_size, emb.length_bucketing, emb.range_fallback, emb.text_tokens_run = ours, torch.device("cpu"), 3, False, False, 0
+    emb.text_token_budget = None
     lens = [9, 4, 9, 2, 9, 9, 4, 24, 9]
     ids = caption_ids(ours.cfg, lens)
     seen = []

@@ -292,6 +292,16 @@ def test_caption_length_bucketing_is_exact_and_cuts_batches_at_bucket_boundaries
     ran = sorted(L for cnt, L in calls for _ in range(cnt))
     assert ran == buckets
     assert bucketed.text_tokens_run == sum(buckets) and plain.text_tokens_run >= bucketed.text_tokens_run
+    # text_token_budget: a micro-batch holds budget // L captions of its bucket (same GEMM row count for short and long captions)
+    budgeted = Embedder(model, torch.device("cpu"), batch_size=4, text_batch_size=5, length_bucketing=True, text_token_budget=48)
+    calls.clear()
+    model.encode_text = lambda x, *a, **k: (calls.append((int(x.shape[0]), k.get("seq_len"))), real(x, *a, **k))[1]
+    try:
+        e2 = budgeted._embed_texts(ids, eot)
+    finally:
+        model.encode_text = real
+    assert float((e0 - e2).abs().max()) < 2e-6 and sum(c[0] for c in calls) == n
+    assert all(cnt <= 48 // L for cnt, L in calls) and any(cnt > 5 for cnt, L in calls if L == 8)
 
 
 def test_near_tie_adjudication_names_the_side_that_holds_the_float64_set():
