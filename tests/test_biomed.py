@@ -1,12 +1,10 @@
 """The `biomed_clip` branch of the factory (lib/models/utils.py:72-78) on the CPU: towers against HF ViTModel / BertModel on shared
 random weights, the open_clip checkpoint loader, the WordPiece tokenizer against transformers' BertTokenizer, the factory surface,
 and the exact-length grouping pipeline.Embedder applies to a tower without a padding mask in its kernels."""
-import os
-
 import pytest
 import torch
 
-from lemon_amd.biomed import BiomedCLIP, BiomedConfig
+from lemon_amd.biomed import BiomedCLIP
 from lemon_amd.clip import algorithm_class_from_scratch
 from lemon_amd.tokenizer import BertWordPiece, find_vocab_file
 
