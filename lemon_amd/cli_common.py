@@ -43,9 +43,11 @@ def run_with_tee(fn, args):
 def add_extension_flags(p):
     """Flags that are not in the reference: local weights / data, encoder batching, caches."""
     p.add_argument("--clip_path", default="random",
-                   help="local HF CLIP checkpoint dir (huggingface_clip), local OpenAI-format .pt (in-tree CLIP branches), or random[:arch]")
+                   help="local HF CLIP checkpoint dir (huggingface_clip), local OpenAI-format .pt (in-tree CLIP branches), local copy of the "
+                        "BiomedCLIP hub snapshot -- open_clip_pytorch_model.bin + vocab.txt -- (biomed_clip), or random[:arch]")
     p.add_argument("--bpe_path", default=None,
-                   help="CLIP BPE merges file (bpe_simple_vocab_16e6.txt.gz / merges.txt) when the checkpoint has no tokenizer files")
+                   help="CLIP BPE merges file (bpe_simple_vocab_16e6.txt.gz / merges.txt) when the checkpoint has no tokenizer files; "
+                        "biomed_clip: the BERT vocab.txt when it is not beside the weights")
     p.add_argument("--data_root", default="./data", help="local dataset root, or synthetic:N")
     p.add_argument("--algo", default="auto", choices=["auto", "f32", "bf16"], help="kNN scan algorithm")
     p.add_argument("--encoder_batch", default=512, type=int, help="encoder micro-batch on the GPU")
