@@ -255,6 +255,17 @@ int lemon_unpack_act_f16x3t(const uint16_t *at_dev, int64_t rows, int k, float *
 int lemon_linear_f16x3t_ln(const uint16_t *at_dev, const uint16_t *wt_dev, const float *bias_dev, const float *residual_dev,
                            int64_t m, int n, int k, float alpha, int act, int out_operand, void *out_dev, const float *row_aff_dev,
                            const float *colsum_dev, uint16_t *emit_t_dev, float *emit_stats_dev, void *stream);
+/* The producing GEMM of a block chain (HF CLIPEncoderLayer: self_attn.out_proj and mlp.fc2 with their residual adds;
+ * lib/models/chexzero_clip.py:191-212) in its leanest form -- lemon_linear_f16x3t_ln's emit side with two options:
+ *   residual_t_dev  the residual as the tile-major activation operand [m, n] an emitting GEMM in front left (x = hi + lo 2^-11:
+ *                   22 significant bits -- one more rounding of the size the split products make anyway) instead of residual_dev
+ *                   (fp32 [m, n]); at most one of the two may be given
+ *   out_dev = NULL  no fp32 result: every consumer reads emit_t_dev (the next GEMM as its operand, the one behind it as its
+ *                   residual) -- the output projection then writes 6 instead of 10 bytes per element
+ * emit_t_dev / emit_stats_dev as in lemon_linear_f16x3t_ln (both required); act none; k a multiple of 32. */
+int lemon_linear_f16x3t_chain(const uint16_t *at_dev, const uint16_t *wt_dev, const float *bias_dev, const float *residual_dev,
+                              const uint16_t *residual_t_dev, int64_t m, int n, int k, float alpha, float *out_dev,
+                              uint16_t *emit_t_dev, float *emit_stats_dev, void *stream);
 int lemon_ln_finalize(const float *partials_dev, int64_t rows, int width, float eps, float *row_aff_dev, void *stream);
 int lemon_rowstats_f16x3t(const float *x_dev, float eps, int64_t rows, int width, uint16_t *yt_dev, float *row_aff_dev, void *stream);
 /* Timing of the hand-written GEMM (no reference counterpart; bench.py's roofline object): while profiling is on every

@@ -17,7 +17,7 @@ ALGO_AUTO, ALGO_F32_MFMA, ALGO_BF16_FILTER = 0, 1, 2
 # every symbol include/lemon_hip.h declares
 EXPORTS = [
     "lemon_last_error", "lemon_version", "lemon_normalize_rows", "lemon_paired_distance",
-    "lemon_d1_normalized", "lemon_class_confidence", "lemon_paired_metric", "lemon_preprocess_u8", "lemon_preprocess_u8_f16x3t", "lemon_attention_f32", "lemon_attention_set_f16", "lemon_attention_split3", "lemon_layernorm_f32", "lemon_vision_tokens_ln", "lemon_text_tokens", "lemon_linear_f32", "lemon_linear_bf16x6", "lemon_split3_f32", "lemon_layernorm_split3", "lemon_linear_f16x3", "lemon_pack_weight_f16x3t", "lemon_layernorm_f16x3t", "lemon_linear_f16x3t", "lemon_linear_f16x3t_ln", "lemon_ln_finalize", "lemon_rowstats_f16x3t", "lemon_unpack_act_f16x3t", "lemon_linear_f16x3t_set_profiling", "lemon_linear_f16x3t_set_mfma", "lemon_linear_f16x3t_profile_read", "lemon_attention_f16x3t", "lemon_split_f16x3", "lemon_layernorm_f16x3", "lemon_attention_f16x3", "lemon_linear_load_tuned",
+    "lemon_d1_normalized", "lemon_class_confidence", "lemon_paired_metric", "lemon_preprocess_u8", "lemon_preprocess_u8_f16x3t", "lemon_attention_f32", "lemon_attention_set_f16", "lemon_attention_split3", "lemon_layernorm_f32", "lemon_vision_tokens_ln", "lemon_text_tokens", "lemon_linear_f32", "lemon_linear_bf16x6", "lemon_split3_f32", "lemon_layernorm_split3", "lemon_linear_f16x3", "lemon_pack_weight_f16x3t", "lemon_layernorm_f16x3t", "lemon_linear_f16x3t", "lemon_linear_f16x3t_ln", "lemon_linear_f16x3t_chain", "lemon_ln_finalize", "lemon_rowstats_f16x3t", "lemon_unpack_act_f16x3t", "lemon_linear_f16x3t_set_profiling", "lemon_linear_f16x3t_set_mfma", "lemon_linear_f16x3t_profile_read", "lemon_attention_f16x3t", "lemon_split_f16x3", "lemon_layernorm_f16x3", "lemon_attention_f16x3", "lemon_linear_load_tuned",
     "lemon_linear_dump_tuned", "lemon_linear_set_tuning", "lemon_linear_stamp", "lemon_index_create", "lemon_index_free", "lemon_index_add",
     "lemon_index_ntotal", "lemon_index_dim", "lemon_index_data", "lemon_index_search",
     "lemon_index_set_algo", "lemon_index_set_query_dedup", "lemon_index_last_search_info", "lemon_index_set_profiling",
@@ -82,6 +82,7 @@ def load():
     lib.lemon_layernorm_f16x3t.argtypes = [vp, vp, vp, ctypes.c_float, c_i64, c_int, vp, vp]
     lib.lemon_linear_f16x3t.argtypes = [vp, vp, vp, vp, c_i64, c_int, c_int, ctypes.c_float, c_int, c_int, vp, vp]
     lib.lemon_linear_f16x3t_ln.argtypes = [vp, vp, vp, vp, c_i64, c_int, c_int, ctypes.c_float, c_int, c_int, vp, vp, vp, vp, vp, vp]
+    lib.lemon_linear_f16x3t_chain.argtypes = [vp, vp, vp, vp, vp, c_i64, c_int, c_int, ctypes.c_float, vp, vp, vp, vp]
     lib.lemon_ln_finalize.argtypes = [vp, c_i64, c_int, ctypes.c_float, vp, vp]
     lib.lemon_rowstats_f16x3t.argtypes = [vp, ctypes.c_float, c_i64, c_int, vp, vp, vp]
     lib.lemon_unpack_act_f16x3t.argtypes = [vp, c_i64, c_int, vp, vp]

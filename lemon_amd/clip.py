@@ -297,17 +297,19 @@ class Block(nn.Module):
         wq, aq, csq, bq = self._w_tiled_ln("qkv", self.ln1, ops, 1.0)
         qkv = ops.linear_t_ln(xt, wq, m, 3 * W, W, bq, alpha=aq, out_shape=(B, L, 3 * W), row_aff=aff, colsum=csq)
         wo, ao = self._w_tiled("out", ops)
-        x, xt, st = ops.linear_t_ln(ops.attention_t(qkv, self.heads, causal), wo, m, W, W, self.out.bias, residual=x, alpha=ao,
-                                    out_shape=x.shape, emit=True)
+        # the stream between the output projection and fc2 exists as the operand only (ops.chain_operand_residual): fc1 reads it as
+        # its operand, fc2 as its residual
+        lean = ops.chain_operand_residual()
+        x, xt, st = ops.linear_t_chain(ops.attention_t(qkv, self.heads, causal), wo, m, W, W, self.out.bias, residual=x, alpha=ao,
+                                       out_shape=x.shape, fp32_out=not lean)
         aff = ops.ln_finalize(st, m, W, self.ln2.eps)
         s, act = self._act_scale(ops)
         w1, a1, cs1, b1 = self._w_tiled_ln("fc1", self.ln2, ops, s)
         ht = ops.linear_t_ln(xt, w1, m, mlp, W, b1, act=act, alpha=s * a1, row_aff=aff, colsum=cs1)
         w2, a2 = self._w_tiled("fc2", ops)
-        if not emit:
-            return ops.linear_t(ht, w2, m, W, mlp, self.fc2.bias, residual=x, alpha=a2 / s, out_shape=x.shape), None
-        x, xt, st = ops.linear_t_ln(ht, w2, m, W, mlp, self.fc2.bias, residual=x, alpha=a2 / s, out_shape=x.shape, emit=True)
-        return x, (xt, st)
+        res = dict(residual_t=xt) if lean else dict(residual=x)
+        x, xt, st = ops.linear_t_chain(ht, w2, m, W, mlp, self.fc2.bias, alpha=a2 / s, out_shape=(B, L, W), **res)
+        return x, ((xt, st) if emit else None)
 
     def _sdpa(self, qkv, B, L, W, causal):
         q, k, v = qkv.view(B, L, 3, self.heads, W // self.heads).permute(2, 0, 3, 1, 4)

@@ -61,6 +61,7 @@ struct GemmParams {
     // LayerNorm folded into the GEMM (k_gemm_f16x3t16 only; see "LayerNorm fold" above lemon_linear_f16x3t_ln):
     const float2 *row_aff;     // FOLD: per row (rstd, -mean rstd) of the LayerNorm in front of this GEMM, or null
     const float *colsum;       // FOLD: [n] alpha * sum_k of the packed weight row (the weight carries the LayerNorm gain)
+    const unsigned short *residual_t;   // EMIT: the residual as a tile-major activation operand [m, n] (hi + lo 2^-11) instead of fp32, or null
     unsigned short *emit_t;    // EMIT (EPI 0): the fp32 result also as the tile-major operand of the next GEMM (its k = n), or null
     float *emit_stats;         // EMIT: [m][2 n_tiles][2] per row and 128-column group (mean, sum of squared deviations)
 #ifdef LEMON_GEMM_PHASES
@@ -573,6 +574,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
         float2 *saff = reinterpret_cast<float2 *>(smem + 4 * (2 * 32 * 36) * 4) + wave * 64;
         const int prow = lane >> 3, pcol = 4 * (lane & 7);
         const bool has_res = p.residual != nullptr;
+        // EMIT only: the residual may arrive as a tile-major operand (what the EMIT GEMM in front of this one left: the same tile
+        // offsets as this GEMM's own operand output), and the fp32 result may be left out (out = null) when every consumer reads the
+        // operand form -- the output projection of a block in the chain then writes 6 instead of 10 bytes per element
+        const bool res_t = EMIT && p.residual_t != nullptr;
+        const bool has_out = !EMIT || p.out != nullptr;
         const int64_t m_last = p.m - 1;
         const int64_t mw = (int64_t)mt * TM + wm * (IB * 32);          // the wave's first row
         const bool full = (int64_t)(mt + 1) * TM <= p.m;
@@ -582,7 +588,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
         char *out_w = reinterpret_cast<char *>(reinterpret_cast<float *>(p.out) + wave_off);
         const unsigned lane_off = (unsigned)(prow * N + pcol) * 4u;
         // tile-major operand (halves): ((mt (N / 16) + n / 16) 2 + part) (TM 16) + (r / 32) 512 + ((n / 8) & 1) 256 + (r % 32) 8 + n % 8
-        char *emit_w = reinterpret_cast<char *>(p.emit_t) + 2 * ((((int64_t)mt * (N >> 4) + (n_w >> 4)) * 2) * (TM * 16) + wm * 2 * 512);
+        const int64_t emit_off = 2 * ((((int64_t)mt * (N >> 4) + (n_w >> 4)) * 2) * (TM * 16) + wm * 2 * 512);
+        char *emit_w = reinterpret_cast<char *>(p.emit_t) + emit_off;
+        const char *rest_w = reinterpret_cast<const char *>(p.residual_t) + emit_off;
         const unsigned emit_lane = 2u * (unsigned)(((lane & 7) >> 2) * 2 * (TM * 16) + (((lane & 7) >> 1) & 1) * 256 + prow * 8 + 4 * (lane & 1));
         if (FOLD) { const int64_t m = mw + lane; saff[lane] = p.row_aff[m < m_last ? m : m_last]; }
         auto load_next = [&](int pass, float4 (&r)[4], float4 &bv, float4 &cs) {
@@ -591,7 +599,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
             bv = make_float4(0.f, 0.f, 0.f, 0.f); cs = bv;
             if (p.bias) bv = *reinterpret_cast<const float4 *>(p.bias + n);
             if (FOLD) cs = *reinterpret_cast<const float4 *>(p.colsum + n);
-            if (has_res) {
+            if (res_t) {
+                // (hi in .xy, lo in .zw of the same four registers; rows beyond m are the operand's pad rows: never stored)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const char *a_ = rest_w + (emit_lane + (unsigned)(cpn * 16384 + bpn * 1024 + q * 128));
+                    const float2 h2_ = *reinterpret_cast<const float2 *>(a_), l2_ = *reinterpret_cast<const float2 *>(a_ + TM * 16 * 2);
+                    r[q] = make_float4(h2_.x, h2_.y, l2_.x, l2_.y);
+                }
+            } else if (has_res) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int64_t m = mw + bpn * 32 + 8 * q + prow;
@@ -642,10 +658,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
                     o_[0] = af[q].x * o_[0] + t_[0]; o_[1] = af[q].x * o_[1] + t_[1];                             \
                     o_[2] = af[q].x * o_[2] + t_[2]; o_[3] = af[q].x * o_[3] + t_[3];                             \
                 }                                                                                                \
-                o_[0] += bv.x + r[q].x; o_[1] += bv.y + r[q].y; o_[2] += bv.z + r[q].z; o_[3] += bv.w + r[q].w;   \
+                float rr_[4] = {r[q].x, r[q].y, r[q].z, r[q].w};                                                 \
+                if (res_t) {   /* hi + lo 2^-11, each term exact in fp32, one fused step (v_fma_mix_f32) */            \
+                    const h16x4 rh_ = __builtin_bit_cast(h16x4, make_float2(r[q].x, r[q].y)), rl_ = __builtin_bit_cast(h16x4, make_float2(r[q].z, r[q].w)); \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) rr_[e] = __builtin_fmaf((float)rl_[e], 0.00048828125f, (float)rh_[e]); \
+                }                                                                                                \
+                o_[0] += bv.x + rr_[0]; o_[1] += bv.y + rr_[1]; o_[2] += bv.z + rr_[2]; o_[3] += bv.w + rr_[3];   \
                 const float4 o4_ = make_float4(o_[0], o_[1], o_[2], o_[3]);                                      \
-                if (!(MASKED)) *reinterpret_cast<float4 *>(out_w + (lane_off + 4u * (unsigned)((bp * 32 + 8 * q) * N + cp * 32))) = o4_; \
-                else if (m < p.m) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + m * N + n) = o4_; \
+                if (has_out) {                                                                                   \
+                    if (!(MASKED)) *reinterpret_cast<float4 *>(out_w + (lane_off + 4u * (unsigned)((bp * 32 + 8 * q) * N + cp * 32))) = o4_; \
+                    else if (m < p.m) *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + m * N + n) = o4_; \
+                }                                                                                                \
                 if (EMIT) {                                                                                      \
                     /* (rows beyond m land in the operand's pad rows: never read into a stored result)                \
                        lo 2^11 = o 2^11 - hi 2^11 exactly, in one fused step from the fp16 value (v_fma_mix_f32) */    \
@@ -837,7 +860,8 @@ extern "C" int lemon_unpack_act_f16x3t(const uint16_t *at_dev, int64_t rows, int
 // rstd -- a factor sqrt(1 + mean^2 / var) on the GEMM's error, 1.0x for the zero-mean rows of a transformer's residual stream.
 static int linear_f16x3t_impl(const uint16_t *at_dev, const uint16_t *wt_dev, const float *bias_dev, const float *residual_dev,
                               int64_t m, int n, int k, float alpha, int act, int out_operand, void *out_dev,
-                              const float *row_aff_dev, const float *colsum_dev, uint16_t *emit_t_dev, float *emit_stats_dev, void *stream_);
+                              const float *row_aff_dev, const float *colsum_dev, uint16_t *emit_t_dev, float *emit_stats_dev, void *stream_,
+                              const uint16_t *residual_t_dev = nullptr);
 
 extern "C" int lemon_linear_f16x3t(const uint16_t *at_dev, const uint16_t *wt_dev, const float *bias_dev, const float *residual_dev,
                                    int64_t m, int n, int k, float alpha, int act, int out_operand, void *out_dev, void *stream_) {
@@ -855,12 +879,28 @@ extern "C" int lemon_linear_f16x3t_ln(const uint16_t *at_dev, const uint16_t *wt
     return linear_f16x3t_impl(at_dev, wt_dev, bias_dev, residual_dev, m, n, k, alpha, act, out_operand, out_dev, row_aff_dev, colsum_dev, emit_t_dev, emit_stats_dev, stream_);
 }
 
+// The producing GEMM of a block chain (output projection, fc2) in its leanest form: lemon_linear_f16x3t_ln's EMIT side with
+//   residual_t_dev  the residual as the tile-major operand an EMIT GEMM in front left (x = hi + lo 2^-11: 22 significant bits, one
+//                   more rounding of the size the split GEMMs make anyway), instead of residual_dev (fp32); at most one of the two
+//   out_dev = NULL  no fp32 result: the consumers read emit_t_dev (the next GEMM as its operand, the one after as its residual)
+extern "C" int lemon_linear_f16x3t_chain(const uint16_t *at_dev, const uint16_t *wt_dev, const float *bias_dev, const float *residual_dev,
+                                         const uint16_t *residual_t_dev, int64_t m, int n, int k, float alpha, float *out_dev,
+                                         uint16_t *emit_t_dev, float *emit_stats_dev, void *stream_) {
+    LEMON_REQUIRE(emit_t_dev && emit_stats_dev, "the chain form always leaves the operand and its row statistics");
+    LEMON_REQUIRE(!(residual_dev && residual_t_dev), "one residual: fp32 or operand form");
+    LEMON_REQUIRE(k % 32 == 0, "k a multiple of 32 (16x16x32 kernel)");
+    LEMON_REQUIRE((((uintptr_t)residual_t_dev) & 15) == 0, "16-byte aligned pointers");
+    return linear_f16x3t_impl(at_dev, wt_dev, bias_dev, residual_dev, m, n, k, alpha, LEMON_ACT_NONE, 0, out_dev, nullptr, nullptr, emit_t_dev,
+                              emit_stats_dev, stream_, residual_t_dev);
+}
+
 static int linear_f16x3t_impl(const uint16_t *at_dev, const uint16_t *wt_dev, const float *bias_dev, const float *residual_dev,
                               int64_t m, int n, int k, float alpha, int act, int out_operand, void *out_dev,
-                              const float *row_aff_dev, const float *colsum_dev, uint16_t *emit_t_dev, float *emit_stats_dev, void *stream_) {
+                              const float *row_aff_dev, const float *colsum_dev, uint16_t *emit_t_dev, float *emit_stats_dev, void *stream_,
+                              const uint16_t *residual_t_dev) {
     LEMON_REQUIRE(m >= 0 && n > 0 && k > 0 && n % TN == 0 && k % 16 == 0, "m >= 0, n a multiple of 256, k a multiple of 16");
     if (m == 0) return LEMON_OK;
-    LEMON_REQUIRE(at_dev && wt_dev && out_dev, "null pointer");
+    LEMON_REQUIRE(at_dev && wt_dev && (out_dev || emit_t_dev), "null pointer");
     LEMON_REQUIRE(((((uintptr_t)row_aff_dev) | ((uintptr_t)colsum_dev) | ((uintptr_t)emit_t_dev) | ((uintptr_t)emit_stats_dev)) & 15) == 0, "16-byte aligned pointers");
     LEMON_REQUIRE(((((uintptr_t)at_dev) | ((uintptr_t)wt_dev) | ((uintptr_t)out_dev) | ((uintptr_t)bias_dev) | ((uintptr_t)residual_dev)) & 15) == 0,
                   "16-byte aligned pointers");
@@ -872,6 +912,7 @@ static int linear_f16x3t_impl(const uint16_t *at_dev, const uint16_t *wt_dev, co
     p.bias = bias_dev; p.residual = residual_dev; p.out = out_dev;
     p.row_aff = reinterpret_cast<const float2 *>(row_aff_dev); p.colsum = colsum_dev;
     p.emit_t = reinterpret_cast<unsigned short *>(emit_t_dev); p.emit_stats = emit_stats_dev;
+    p.residual_t = reinterpret_cast<const unsigned short *>(residual_t_dev);
     p.m = m; p.n = n; p.ks = k / 16; p.m_tiles = (int)((m + TM - 1) / TM); p.n_tiles = n / TN; p.alpha = alpha;
     // super-block of the tile walk: gn = the largest divisor of the n-tile count up to 4 (a gn that does not divide it leaves
     // every other XCD with half-empty super-blocks: +25 % time measured), gm so that an XCD's 64 resident workgroups cover one

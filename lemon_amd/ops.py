@@ -483,6 +483,45 @@ def linear_t_ln(at, wt, m, n, k, bias=None, residual=None, act=None, alpha=1.0, 
     return (out, et, st) if emit else out
 
 
+def chain_operand_residual():
+    """LEMON_CHAIN_RES (default 1): inside a block chain (ln_fold_enabled) the output projection leaves its result only as the
+    next GEMM's operand + row statistics (no fp32 tensor: 6 instead of 10 bytes written per element of the GEMM that is bound by
+    its epilogue's traffic), and fc2 takes its residual from that operand (hi + lo 2^-11: 22 significant bits, one more rounding
+    of the size the split products make anyway).  0: fp32 residual stream between all GEMMs (A/B aid)."""
+    import os
+    return os.environ.get("LEMON_CHAIN_RES", "1") != "0"
+
+
+def linear_t_chain(at, wt, m, n, k, bias=None, residual=None, residual_t=None, alpha=1.0, out_shape=None, fp32_out=True):
+    """lemon_linear_f16x3t_chain: alpha x W^T + bias + residual -> (fp32 [m, n] or None, the same as the next GEMM's tile-major
+    operand, its row-statistics partials [m, n / 128, 2]); the residual is fp32 [m, n] (`residual`) or a tile-major operand
+    (`residual_t`)."""
+    assert at.is_cuda and at.dtype == torch.float16 and wt.dtype == torch.float16
+    assert at.numel() == _tiled_rows(m) * k * 2 and wt.numel() == n * k * 2 and k % 32 == 0
+    assert residual is None or residual_t is None
+    lib = _lib.load()
+    if bias is not None:
+        bias = bias.contiguous()
+    out = None
+    if fp32_out:
+        out = torch.empty(out_shape if out_shape is not None else (m, n), dtype=torch.float32, device=at.device)
+        assert out.numel() == m * n
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.numel() == m * n
+        residual = residual.contiguous()
+    if residual_t is not None:
+        assert residual_t.dtype == torch.float16 and residual_t.numel() == _tiled_rows(m) * n * 2
+    et = torch.empty((_tiled_rows(m) * n * 2,), dtype=torch.float16, device=at.device)
+    st = torch.empty((m, n // 128, 2), dtype=torch.float32, device=at.device)
+    with torch.cuda.device(at.device):
+        _lib.check(lib.lemon_linear_f16x3t_chain(ptr(at), ptr(wt), ptr(bias) if bias is not None else None,
+                                                 ptr(residual) if residual is not None else None,
+                                                 ptr(residual_t) if residual_t is not None else None, m, n, k, float(alpha),
+                                                 ptr(out) if out is not None else None, ptr(et), ptr(st), stream_ptr(at.device)),
+                   "lemon_linear_f16x3t_chain")
+    return out, et, st
+
+
 def gemm_profiling(on):
     """HIP events around every lemon_linear_f16x3t launch from now on (bench.py: the roofline of the step's dominant kernel)."""
     _lib.check(_lib.load().lemon_linear_f16x3t_set_profiling(int(bool(on))), "lemon_linear_f16x3t_set_profiling")

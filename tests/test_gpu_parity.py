@@ -1157,6 +1157,40 @@ def test_layernorm_folded_into_the_gemm_matches_float64(hip, m, k, n, mean_over_
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("m,k,n", [(300, 128, 256), (1000, 768, 768), (129, 2048, 768), (2600, 64, 512)])
+def test_chain_gemm_with_the_residual_in_operand_form_and_no_fp32_result(hip, m, k, n):
+    # lemon_linear_f16x3t_chain (the output projection / fc2 of a block chain): (a) with an fp32 residual and an fp32 result it is
+    # lemon_linear_f16x3t_ln's emit form bit for bit; (b) with the residual handed over as the operand an emitting GEMM left
+    # (hi + lo 2^-11) the result is that of the fp32 call on the operand's own values -- bit for bit --, i.e. within 2^-22 of
+    # the residual's magnitude of the call on the original fp32 residual; (c) without an fp32 result the operand and the row
+    # statistics it leaves are the same bits
+    from lemon_amd import ops
+    g = torch.Generator().manual_seed(m + 3 * k + n)
+    x = torch.randn(m, k, generator=g)
+    w, b = 0.05 * torch.randn(n, k, generator=g), 0.1 * torch.randn(n, generator=g)
+    res = torch.randn(m, n, generator=g) * (0.2 + 3 * torch.rand(m, 1, generator=g)) + 5.0 * torch.randn(m, 1, generator=g)
+    xc, wc, bc, rc = (t.cuda() for t in (x, w, b, res))
+    ws = ops.weight_scale_f16x3(wc)
+    wt = ops.pack_weight_t(wc, ws)
+    at, _ = ops.rowstats_t(xc, 1e-5)
+    rt, _ = ops.rowstats_t(rc, 1e-5)                         # the residual as a tile-major operand
+    r_back = ops.unpack_act_t(rt, m, n)                     # ... and the values it holds
+    assert bool(((r_back - rc).abs() <= 2.0 ** -21 * rc.abs() + 1e-30).all())
+    out0, et0, st0 = ops.linear_t_ln(at, wt, m, n, k, bc, residual=rc, alpha=1.0 / ws, emit=True)
+    out1, et1, st1 = ops.linear_t_chain(at, wt, m, n, k, bc, residual=rc, alpha=1.0 / ws)
+    assert torch.equal(out0, out1) and torch.equal(st0, st1)
+    assert torch.equal(ops.unpack_act_t(et0, m, n), ops.unpack_act_t(et1, m, n))        # (rows of the tile padding are not defined)
+    want, wet, wst = ops.linear_t_chain(at, wt, m, n, k, bc, residual=r_back, alpha=1.0 / ws)
+    out2, et2, st2 = ops.linear_t_chain(at, wt, m, n, k, bc, residual_t=rt, alpha=1.0 / ws)
+    assert torch.equal(out2, want) and torch.equal(st2, wst) and torch.equal(ops.unpack_act_t(et2, m, n), ops.unpack_act_t(wet, m, n))
+    assert float((out2 - out1).abs().max()) <= 2.0 ** -21 * float(rc.abs().max())
+    none, et3, st3 = ops.linear_t_chain(at, wt, m, n, k, bc, residual_t=rt, alpha=1.0 / ws, fp32_out=False)
+    assert none is None and torch.equal(st3, st2) and torch.equal(ops.unpack_act_t(et3, m, n), ops.unpack_act_t(et2, m, n))
+    with pytest.raises(AssertionError):
+        ops.linear_t_chain(at, wt, m, n, k, bc, residual=rc, residual_t=rt)              # one residual only
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,k,n", [(300, 128, 256), (1000, 768, 768), (129, 2048, 768), (2600, 64, 512)])
 def test_gemm_emits_the_next_layernorms_operand_and_statistics(hip, m, k, n):
     # the producing side of the fold: the fp32 result is the plain kernel's (same products, the bias / residual additions in
     # another order: last-bit differences), the operand it also writes is the fp16 split of exactly what it stored, and the
