@@ -298,9 +298,13 @@ __device__ __forceinline__ void mfma16(f32x4 &acc, const h16x8 &a, const h16x8 &
 #endif
 }
 
-template <int EPI, bool FOLD, bool EMIT>
+// LEAN (EMIT only): which of the chain's two options the instantiation is built for -- 0: fp32 residual, fp32 result (the classic emit
+// form); 1: no fp32 result (the output projection inside a chain); 2: residual in operand form (fc2 inside a chain); 3: both, decided
+// at run time (one instantiation carrying both options spilled six registers in its epilogue)
+template <int EPI, bool FOLD, bool EMIT, int LEAN = 0>
 __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
     static_assert(!EMIT || EPI == 0, "the operand + statistics output rides on the fp32 epilogue");
+    static_assert(LEAN == 0 || EMIT, "the chain options belong to the emitting form");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -577,8 +581,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
         // EMIT only: the residual may arrive as a tile-major operand (what the EMIT GEMM in front of this one left: the same tile
         // offsets as this GEMM's own operand output), and the fp32 result may be left out (out = null) when every consumer reads the
         // operand form -- the output projection of a block in the chain then writes 6 instead of 10 bytes per element
-        const bool res_t = EMIT && p.residual_t != nullptr;
-        const bool has_out = !EMIT || p.out != nullptr;
+        const bool res_t = LEAN == 2 || (LEAN == 3 && p.residual_t != nullptr);
+        const bool has_out = LEAN == 0 || LEAN == 2 || (LEAN == 3 && p.out != nullptr);
         const int64_t m_last = p.m - 1;
         const int64_t mw = (int64_t)mt * TM + wm * (IB * 32);          // the wave's first row
         const bool full = (int64_t)(mt + 1) * TM <= p.m;
@@ -948,6 +952,9 @@ static int linear_f16x3t_impl(const uint16_t *at_dev, const uint16_t *wt_dev, co
             LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<0, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<0, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<0, false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<0, false, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             LEMON_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gemm_f16x3t16<2, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -978,7 +985,10 @@ static int linear_f16x3t_impl(const uint16_t *at_dev, const uint16_t *wt_dev, co
         if (fold && out_operand && gelu) hipLaunchKernelGGL((k_gemm_f16x3t16<2, true, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
         else if (fold && out_operand) hipLaunchKernelGGL((k_gemm_f16x3t16<1, true, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
         else if (fold) hipLaunchKernelGGL((k_gemm_f16x3t16<0, true, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
-        else hipLaunchKernelGGL((k_gemm_f16x3t16<0, false, true>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+        else if (!residual_t_dev && out_dev) hipLaunchKernelGGL((k_gemm_f16x3t16<0, false, true>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+        else if (!residual_t_dev) hipLaunchKernelGGL((k_gemm_f16x3t16<0, false, true, 1>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+        else if (out_dev) hipLaunchKernelGGL((k_gemm_f16x3t16<0, false, true, 2>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
+        else hipLaunchKernelGGL((k_gemm_f16x3t16<0, false, true, 3>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
     } else if (mf16) {
         if (out_operand && gelu) hipLaunchKernelGGL((k_gemm_f16x3t16<2, false, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);
         else if (out_operand) hipLaunchKernelGGL((k_gemm_f16x3t16<1, false, false>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream_, p);

@@ -259,7 +259,7 @@ def test_gemm16_variants_register_discipline():
     meta = _kernel_meta("gemm_f16x3.hip")
     bodies = _kernel_bodies(_kernel_asm("gemm_f16x3.hip"))
     names = [n for n in bodies if "k_gemm_f16x3t16ILi" in n]
-    assert len(names) == 7, sorted(names)        # fp32; SiLU, GELU operand; fold x (fp32, SiLU, GELU); emit
+    assert len(names) == 10, sorted(names)       # fp32; SiLU, GELU operand; fold x (fp32, SiLU, GELU); emit x four chain forms (LEAN)
     for n in names:
         assert meta[n]["vgpr_count"] <= 256, (n, meta[n])            # (arch + accumulation registers: two waves per SIMD)
         if "Lb0ELb0E" in n:
