@@ -497,9 +497,9 @@ def bench_cifar(args, world, rank, dev):
                  "the SAMPLE is embedded again with LayerNorm kernels (`fold_fallback_rows`); measured on real-checkpoint-like statistics -- gains of 30, "
                  "40-1000x outlier channels, rows up to |mean|/sigma 7.9 -- 0.7-1.8x the fp32 chain's error, tests/test_gpu_parity.py::"
                  "test_folded_layernorm_chain_on_real_checkpoint_statistics); "
-                 f"LEMON_CHAIN_RES={int(_ops.chain_operand_residual())}: inside the chain the stream between the output projection and fc2 exists only as "
-                 "that operand (hi + lo 2^-11: 22 significant bits, read by fc1 as its operand and by fc2 as its residual; no fp32 tensor from the "
-                 "output projection); also the patch embedding and the last block's all-token QKV; the pooled rows of the "
+                 f"LEMON_CHAIN_RES={int(_ops.chain_operand_residual())}: inside the chain the residual stream exists only as that operand (hi + lo 2^-11: 22 "
+                 "significant bits per hop, read by the next GEMM as its operand and by the one behind it as its residual; fp32 is written by the last "
+                 "chained block only); also the patch embedding and the last block's all-token QKV; the pooled rows of the "
                  "last block (and what the mode leaves out): lemon_linear_f16x3 on hipBLASLt -- both fp32 operands "
                  "split into two fp16 parts (hi = f16(v), lo = the exact remainder kept to 11 bits: 22 bits + sign), weights pre-scaled by a "
                  "power of two, hi.hi + hi.lo + lo.hi summed by one fp16 GEMM with fp32 accumulation (error vs float64 at the "

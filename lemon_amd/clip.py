@@ -275,17 +275,21 @@ class Block(nn.Module):
             cache[(name, "tiled_ln")] = hit
         return hit[1:]
 
-    def forward_chain(self, x, causal, carry=None, emit=True):
+    def forward_chain(self, x, causal, carry=None, emit=True, fp32_out=True):
         """forward(x, causal) for a run of consecutive blocks: -> (x_out, carry_out).  Where the hand-written GEMMs run the
         whole block (LEMON_GEMM=f16x3, LEMON_MLP=block) the two LayerNorms are FOLDED into them (ops.ln_fold_enabled): `carry` =
         (this block's input as the tile-major operand, its row-statistics partials) as the previous block's fc2 left them (None:
         made here with one pass), and with `emit` this block's fc2 leaves the same for the next one."""
-        B, L, W = x.shape
-        mlp = self.fc1.weight.shape[0]
         from . import ops
-        ok = (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and W % 32 == 0 and mlp % 32 == 0 and W <= 1024
-              and ops.gemm_mode() == "f16x3" and ops.mlp_mode() == "block" and ops.ln_fold_enabled()
-              and ops.block_fused_supported(W, mlp, self.heads, L))
+        mlp = self.fc1.weight.shape[0]
+        if x is None:            # (full lean form: the block in front left its result as the operand only; it checked `ok`)
+            B, L, W = carry[2]
+            ok = True
+        else:
+            B, L, W = x.shape
+            ok = (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and W % 32 == 0 and mlp % 32 == 0 and W <= 1024
+                  and ops.gemm_mode() == "f16x3" and ops.mlp_mode() == "block" and ops.ln_fold_enabled()
+                  and ops.block_fused_supported(W, mlp, self.heads, L))
         if not ok:
             return self(x, causal), None
         ops.select_attention_arithmetic("f16x3")
@@ -297,19 +301,21 @@ class Block(nn.Module):
         wq, aq, csq, bq = self._w_tiled_ln("qkv", self.ln1, ops, 1.0)
         qkv = ops.linear_t_ln(xt, wq, m, 3 * W, W, bq, alpha=aq, out_shape=(B, L, 3 * W), row_aff=aff, colsum=csq)
         wo, ao = self._w_tiled("out", ops)
-        # the stream between the output projection and fc2 exists as the operand only (ops.chain_operand_residual): fc1 reads it as
-        # its operand, fc2 as its residual
+        # inside the chain the residual stream exists as the GEMMs' operand only (ops.chain_operand_residual): the next GEMM reads
+        # it as its operand, the one behind it as its residual; fp32 is written where the caller asks for it (fp32_out: the last
+        # chained block)
         lean = ops.chain_operand_residual()
-        x, xt, st = ops.linear_t_chain(ops.attention_t(qkv, self.heads, causal), wo, m, W, W, self.out.bias, residual=x, alpha=ao,
-                                       out_shape=x.shape, fp32_out=not lean)
+        res = dict(residual_t=xt) if lean == 2 else dict(residual=x)
+        x, xt, st = ops.linear_t_chain(ops.attention_t(qkv, self.heads, causal), wo, m, W, W, self.out.bias, alpha=ao,
+                                       out_shape=(B, L, W), fp32_out=not lean, **res)
         aff = ops.ln_finalize(st, m, W, self.ln2.eps)
         s, act = self._act_scale(ops)
         w1, a1, cs1, b1 = self._w_tiled_ln("fc1", self.ln2, ops, s)
         ht = ops.linear_t_ln(xt, w1, m, mlp, W, b1, act=act, alpha=s * a1, row_aff=aff, colsum=cs1)
         w2, a2 = self._w_tiled("fc2", ops)
         res = dict(residual_t=xt) if lean else dict(residual=x)
-        x, xt, st = ops.linear_t_chain(ht, w2, m, W, mlp, self.fc2.bias, alpha=a2 / s, out_shape=(B, L, W), **res)
-        return x, ((xt, st) if emit else None)
+        x, xt, st = ops.linear_t_chain(ht, w2, m, W, mlp, self.fc2.bias, alpha=a2 / s, out_shape=(B, L, W), fp32_out=fp32_out or lean < 2, **res)
+        return x, ((xt, st, (B, L, W)) if emit else None)
 
     def _sdpa(self, qkv, B, L, W, causal):
         q, k, v = qkv.view(B, L, 3, self.heads, W // self.heads).permute(2, 0, 3, 1, 4)
@@ -394,8 +400,9 @@ class VisionTower(nn.Module):
             if self.pre_ln is not None:
                 x = self.pre_ln(x)
         carry = None
-        for b in self.blocks[:-1]:
-            x, carry = b.forward_chain(x, causal=False, carry=carry)
+        n_chain = len(self.blocks) - 1
+        for i, b in enumerate(self.blocks[:-1]):
+            x, carry = b.forward_chain(x, causal=False, carry=carry, fp32_out=i == n_chain - 1)
         batch = torch.arange(x.shape[0], device=x.device)
         x = self.blocks[-1](x, causal=False, rows=(batch, torch.zeros_like(batch)), carry=carry)   # CLS rows of the last block
         if fused:
@@ -439,8 +446,9 @@ class TextTower(nn.Module):
         else:
             x = self.tok(input_ids[:, :L]) + self.pos[:L]
         carry = None
-        for b in self.blocks[:-1]:
-            x, carry = b.forward_chain(x, causal=True, carry=carry)
+        n_chain = len(self.blocks) - 1
+        for i, b in enumerate(self.blocks[:-1]):
+            x, carry = b.forward_chain(x, causal=True, carry=carry, fp32_out=i == n_chain - 1)
         x = self.blocks[-1](x, causal=True, rows=(torch.arange(x.shape[0], device=x.device), eot), carry=carry)   # EOT rows only
         if fused:
             return ops.linear(ops.layer_norm(x, self.final_ln.weight, self.final_ln.bias, self.final_ln.eps), self.proj.weight)

@@ -298,9 +298,9 @@ __device__ __forceinline__ void mfma16(f32x4 &acc, const h16x8 &a, const h16x8 &
 #endif
 }
 
-// LEAN (EMIT only): which of the chain's two options the instantiation is built for -- 0: fp32 residual, fp32 result (the classic emit
-// form); 1: no fp32 result (the output projection inside a chain); 2: residual in operand form (fc2 inside a chain); 3: both, decided
-// at run time (one instantiation carrying both options spilled six registers in its epilogue)
+// LEAN (EMIT only): which of the chain's two options the instantiation is built for -- bit 0: no fp32 result (the output projection
+// inside a chain), bit 1: residual in operand form (fc2 inside a chain); 0 = the classic emit form.  (One instantiation deciding both
+// at run time spilled six registers in its epilogue.)
 template <int EPI, bool FOLD, bool EMIT, int LEAN = 0>
 __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
     static_assert(!EMIT || EPI == 0, "the operand + statistics output rides on the fp32 epilogue");
@@ -581,8 +581,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f16x3t16(GemmParams p) {
         // EMIT only: the residual may arrive as a tile-major operand (what the EMIT GEMM in front of this one left: the same tile
         // offsets as this GEMM's own operand output), and the fp32 result may be left out (out = null) when every consumer reads the
         // operand form -- the output projection of a block in the chain then writes 6 instead of 10 bytes per element
-        const bool res_t = LEAN == 2 || (LEAN == 3 && p.residual_t != nullptr);
-        const bool has_out = LEAN == 0 || LEAN == 2 || (LEAN == 3 && p.out != nullptr);
+        constexpr bool res_t = (LEAN & 2) != 0;
+        constexpr bool has_out = (LEAN & 1) == 0;
         const int64_t m_last = p.m - 1;
         const int64_t mw = (int64_t)mt * TM + wm * (IB * 32);          // the wave's first row
         const bool full = (int64_t)(mt + 1) * TM <= p.m;

@@ -484,12 +484,16 @@ def linear_t_ln(at, wt, m, n, k, bias=None, residual=None, act=None, alpha=1.0, 
 
 
 def chain_operand_residual():
-    """LEMON_CHAIN_RES (default 1): inside a block chain (ln_fold_enabled) the output projection leaves its result only as the
-    next GEMM's operand + row statistics (no fp32 tensor: 6 instead of 10 bytes written per element of the GEMM that is bound by
-    its epilogue's traffic), and fc2 takes its residual from that operand (hi + lo 2^-11: 22 significant bits, one more rounding
-    of the size the split products make anyway).  0: fp32 residual stream between all GEMMs (A/B aid)."""
+    """LEMON_CHAIN_RES: how the residual stream travels inside a block chain (ln_fold_enabled).
+    2 (default): as the GEMMs' tile-major operand only -- the output projection and fc2 leave their result as the next GEMM's
+       operand + row statistics (no fp32 tensor: 6 instead of 10 bytes written per element) and take their residual from the
+       operand the GEMM in front left (hi + lo 2^-11: 22 significant bits per hop, the size of the terms the split products drop
+       anyway); only the last chained block also writes fp32 (the pooled last block and the final LayerNorm read it);
+    1: only the stream between the output projection and fc2 is carried that way (fc2 writes fp32 at every block boundary);
+    0: fp32 residual stream between all GEMMs (A/B aid)."""
     import os
-    return os.environ.get("LEMON_CHAIN_RES", "1") != "0"
+    v = os.environ.get("LEMON_CHAIN_RES", "2")
+    return 0 if v == "0" else (1 if v == "1" else 2)
 
 
 def linear_t_chain(at, wt, m, n, k, bias=None, residual=None, residual_t=None, alpha=1.0, out_shape=None, fp32_out=True):

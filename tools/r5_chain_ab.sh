@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 P="--steps 4 --warmup 2 --no_cpu_baseline --no_knn_1m --no_mscoco --no_f32_gemm_check"
 for r in 1 2 3; do
-  for v in 1 0; do
+  for v in ${MODES:-1 0}; do
     LEMON_CHAIN_RES=$v timeout -k 10 300 python3 $R/bench.py $P > $OUT/r5_chain_res${v}_$r.json 2> $OUT/r5_chain_res${v}_$r.err || exit 1
     python3 - <<PY
 import json
